@@ -1,0 +1,391 @@
+// gemm.hip -- fp32 MFMA GEMM kernels (gfx950).  See gemm.h for the contract.
+//
+// Replaces the reference's eager `lin(x)` / autograd matmul chains:
+//   network/field.py:133-150 (SDFNetwork.forward), :158-170 (.gradient), :265-289 (NeRFNetwork),
+//   :371-408 (make_predictor stacks) and their autograd backward / double backward.
+#include "gemm.h"
+
+#define TBM 128
+#define TBN 128
+#define TBK 32
+#define NT_LDS 36   // padded row stride (floats): 36*r mod 64 hits every 16-B slot once per 16 rows
+
+// ------------------------------------------------------------------------------------------------
+// NT kernel
+// ------------------------------------------------------------------------------------------------
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NuGemmNT g) {
+    __shared__ __attribute__((aligned(16))) float smem[2][2][TBM * NT_LDS];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = tid >> 6;
+    const int wr = wid >> 1, wc = wid & 1;
+    const int z = blockIdx.z;
+    const int ntn = (g.N + TBN - 1) / TBN;
+    const int mt = blockIdx.x / ntn, nt = blockIdx.x - mt * ntn;
+    const int m0 = mt * TBM, n0 = nt * TBN;
+
+    const float* __restrict__ A = g.A + (long long)z * g.sA;
+    const float* __restrict__ B = g.B + (long long)z * g.sB;
+
+    // global->register staging: 4 float4 of A and 4 of B per thread per k-tile
+    const int c4 = tid & 7;
+    const int r0 = tid >> 3;
+    const float* ap[4];
+    const float* bp[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int ra = m0 + r0 + 32 * i;
+        ra = ra < g.M ? ra : g.M - 1;
+        ap[i] = A + (long long)ra * g.lda + 4 * c4;
+        bp[i] = B + (long long)(n0 + r0 + 32 * i) * g.ldb + 4 * c4;
+    }
+    f32x4 ra4[4], rb4[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        ra4[i] = *reinterpret_cast<const f32x4*>(ap[i]);
+        rb4[i] = *reinterpret_cast<const f32x4*>(bp[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        *reinterpret_cast<f32x4*>(&smem[0][0][(r0 + 32 * i) * NT_LDS + 4 * c4]) = ra4[i];
+        *reinterpret_cast<f32x4*>(&smem[0][1][(r0 + 32 * i) * NT_LDS + 4 * c4]) = rb4[i];
+    }
+    __syncthreads();
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int nk = g.K / TBK;
+    const int li = lane & 31, lh = lane >> 5;
+    const int a_off = (wr * 64 + li) * NT_LDS + 4 * lh;
+    const int b_off = (wc * 64 + li) * NT_LDS + 4 * lh;
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                ra4[i] = *reinterpret_cast<const f32x4*>(ap[i] + (kt + 1) * TBK);
+                rb4[i] = *reinterpret_cast<const f32x4*>(bp[i] + (kt + 1) * TBK);
+            }
+        }
+        const float* As = smem[cur][0];
+        const float* Bs = smem[cur][1];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            f32x4 a0 = *reinterpret_cast<const f32x4*>(&As[a_off + kk * 8]);
+            f32x4 a1 = *reinterpret_cast<const f32x4*>(&As[a_off + 32 * NT_LDS + kk * 8]);
+            f32x4 b0 = *reinterpret_cast<const f32x4*>(&Bs[b_off + kk * 8]);
+            f32x4 b1 = *reinterpret_cast<const f32x4*>(&Bs[b_off + 32 * NT_LDS + kk * 8]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b0[e], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b1[e], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b0[e], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b1[e], acc[1][1], 0, 0, 0);
+            }
+        }
+        if (kt + 1 < nk) {
+            const int nxt = cur ^ 1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                *reinterpret_cast<f32x4*>(&smem[nxt][0][(r0 + 32 * i) * NT_LDS + 4 * c4]) = ra4[i];
+                *reinterpret_cast<f32x4*>(&smem[nxt][1][(r0 + 32 * i) * NT_LDS + 4 * c4]) = rb4[i];
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue ----
+    float* __restrict__ C = g.C + (long long)z * g.sC;
+    float* __restrict__ C2 = g.C2 ? g.C2 + (long long)z * g.sC2 : nullptr;
+    const float* __restrict__ bias = g.bias ? g.bias + (long long)z * g.sBias : nullptr;
+    const float* __restrict__ H = g.H ? g.H + (long long)z * g.sH : nullptr;
+    const float* __restrict__ D = g.D ? g.D + (long long)z * g.sD : nullptr;
+    const float* __restrict__ Cadd = g.Cadd ? g.Cadd + (long long)z * g.sCadd : nullptr;
+    const int zero_to = g.zero_to > g.N ? g.zero_to : g.N;
+
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+        const int col = n0 + wc * 64 + tn * 32 + li;
+        if (col >= zero_to) continue;
+        const bool live = col < g.N;
+        float bv = 0.0f;
+        if (EPI <= NU_EPI_BIAS_SOFTPLUS) bv = (live && bias) ? bias[col] : 0.0f;
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wr * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (row >= g.M) continue;
+                float v = g.alpha * acc[tm][tn][r];
+                float out = 0.0f, out2 = 0.0f;
+                if (live) {
+                    if (EPI == NU_EPI_BIAS_NONE) {
+                        out = v + bv;
+                    } else if (EPI == NU_EPI_BIAS_RELU) {
+                        out = fmaxf(v + bv, 0.0f);
+                    } else if (EPI == NU_EPI_BIAS_SOFTPLUS) {
+                        out = nu_softplus100(v + bv);
+                    } else if (EPI == NU_EPI_MUL_DRELU) {
+                        float h = H[(long long)row * g.ldh + col];
+                        out = h > 0.0f ? v : 0.0f;
+                    } else if (EPI == NU_EPI_MUL_DSP) {
+                        float h = H[(long long)row * g.ldh + col];
+                        out = v * nu_softplus100_grad_from_h(h);
+                    } else if (EPI == NU_EPI_Q_SP) {
+                        float h = H[(long long)row * g.ldh + col];
+                        float sp = nu_softplus100_grad_from_h(h);
+                        float d = D[(long long)row * g.ldd + col];
+                        out = v * sp;
+                        out2 = v * d * 100.0f * (1.0f - sp);
+                    } else if (EPI == NU_EPI_B_SP) {
+                        float h = H[(long long)row * g.ldh + col];
+                        out = v * nu_softplus100_grad_from_h(h) + Cadd[(long long)row * g.ldadd + col];
+                    } else {
+                        out = v;
+                    }
+                }
+                C[(long long)row * g.ldc + col] = out;
+                if (EPI == NU_EPI_Q_SP) C2[(long long)row * g.ldc2 + col] = out2;
+            }
+        }
+    }
+}
+
+int nu_gemm_nt_launch(const NuGemmNT& g, hipStream_t stream) {
+    if (g.M <= 0) return NU_OK;
+    if (g.N <= 0 || g.K <= 0 || (g.K % TBK) != 0 || g.lda < g.K || g.ldb < g.K) return NU_ERR_ARG;
+    if ((g.lda & 3) || (g.ldb & 3)) return NU_ERR_ARG;
+    if (((uintptr_t)g.A & 15) || ((uintptr_t)g.B & 15)) return NU_ERR_ARG;
+    const int ntn = nu_cdiv(g.N, TBN);
+    const long long nblk = (long long)nu_cdiv(g.M, TBM) * ntn;
+    if (nblk > 0x7fffffffLL) return NU_ERR_ARG;
+    dim3 grid((unsigned)nblk, 1, g.groups > 0 ? g.groups : 1), block(256);
+    switch (g.epi) {
+#define NU_CASE(E) case E: hipLaunchKernelGGL(gemm_nt_kernel<E>, grid, block, 0, stream, g); break;
+        NU_CASE(NU_EPI_BIAS_NONE)
+        NU_CASE(NU_EPI_BIAS_RELU)
+        NU_CASE(NU_EPI_BIAS_SOFTPLUS)
+        NU_CASE(NU_EPI_MUL_DRELU)
+        NU_CASE(NU_EPI_MUL_DSP)
+        NU_CASE(NU_EPI_Q_SP)
+        NU_CASE(NU_EPI_B_SP)
+        NU_CASE(NU_EPI_PLAIN)
+#undef NU_CASE
+        default: return NU_ERR_ARG;
+    }
+    return nu_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// TN kernel (weight gradients): split over the reduced (point) dimension, partial slabs out.
+// ------------------------------------------------------------------------------------------------
+#define TN_LDS 128
+
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(NuGemmTN g) {
+    __shared__ __attribute__((aligned(16))) float smem[2][2][TBK * TN_LDS];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = tid >> 6;
+    const int wr = wid >> 1, wc = wid & 1;
+    const int t2 = (g.N2 + 127) / 128;
+    const int n1t = blockIdx.x / t2, n2t = blockIdx.x - n1t * t2;
+    const int n1_0 = n1t * 128, n2_0 = n2t * 128;
+    const int split = blockIdx.y;
+    const int grp = blockIdx.z;
+    const int N1p = ((g.N1 + 127) / 128) * 128, N2p = t2 * 128;
+
+    int rows_per = (g.P + g.S - 1) / g.S;
+    rows_per = ((rows_per + TBK - 1) / TBK) * TBK;
+    const int p_begin = split * rows_per;
+    int p_end = p_begin + rows_per;
+    p_end = p_end < g.P ? p_end : g.P;
+    const int ntile = p_end > p_begin ? (p_end - p_begin + TBK - 1) / TBK : 0;
+    const int npair = g.A1 ? 2 : 1;
+    const int total = ntile * npair;
+
+    const int c4 = tid & 31;
+    const int r0 = tid >> 5;  // 0..7
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+    const bool do_bias = (g.bias_slab != nullptr) && (n2t == 0);
+
+    f32x4 ra4[4], rb4[4];
+    auto load_tile = [&](int t) {
+        const int pair = t / ntile;  // ntile > 0 whenever called
+        const int kt = t - pair * ntile;
+        const float* __restrict__ A = pair ? g.A1 + (long long)grp * g.sA1 : g.A0 + (long long)grp * g.sA0;
+        const float* __restrict__ B = pair ? g.B1 + (long long)grp * g.sB1 : g.B0 + (long long)grp * g.sB0;
+        const int lda = pair ? g.lda1 : g.lda0;
+        const int ldb = pair ? g.ldb1 : g.ldb0;
+        const int ca = n1_0 + 4 * c4, cb = n2_0 + 4 * c4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int p = p_begin + kt * TBK + r0 + 8 * i;
+            f32x4 va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
+            if (p < p_end) {
+                if (ca + 3 < lda) va = *reinterpret_cast<const f32x4*>(A + (long long)p * lda + ca);
+                if (cb + 3 < ldb) vb = *reinterpret_cast<const f32x4*>(B + (long long)p * ldb + cb);
+            }
+            ra4[i] = va;
+            rb4[i] = vb;
+            if (do_bias && pair == 0) bsum += va;
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<f32x4*>(&smem[buf][0][(r0 + 8 * i) * TN_LDS + 4 * c4]) = ra4[i];
+            *reinterpret_cast<f32x4*>(&smem[buf][1][(r0 + 8 * i) * TN_LDS + 4 * c4]) = rb4[i];
+        }
+    };
+
+    if (total > 0) {
+        load_tile(0);
+        store_tile(0);
+    }
+    __syncthreads();
+
+    const int li = lane & 31, lh = lane >> 5;
+    for (int t = 0; t < total; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < total) load_tile(t + 1);
+        const float* As = smem[cur][0];
+        const float* Bs = smem[cur][1];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int ro = (2 * s + lh) * TN_LDS;
+            float a0 = As[ro + wr * 64 + li];
+            float a1 = As[ro + wr * 64 + 32 + li];
+            float b0 = Bs[ro + wc * 64 + li];
+            float b1 = Bs[ro + wc * 64 + 32 + li];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (t + 1 < total) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    float* __restrict__ slab = g.slab + (long long)grp * g.sSlab + (long long)split * N1p * N2p;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+            const int col = n2_0 + wc * 64 + tn * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = n1_0 + wr * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                slab[(long long)row * N2p + col] = acc[tm][tn][r];
+            }
+        }
+
+    if (do_bias) {
+        // reduce the 8 row-groups that share a column quad
+        float* red = &smem[0][0][0];
+        *reinterpret_cast<f32x4*>(&red[r0 * 128 + 4 * c4]) = bsum;
+        __syncthreads();
+        if (tid < 128) {
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s += red[i * 128 + tid];
+            g.bias_slab[(long long)grp * g.sBiasSlab + (long long)split * N1p + n1_0 + tid] = s;
+        }
+    }
+}
+
+int nu_gemm_tn_launch(const NuGemmTN& g, hipStream_t stream) {
+    if (g.N1 <= 0 || g.N2 <= 0 || g.S <= 0) return NU_ERR_ARG;
+    if ((g.lda0 & 3) || (g.ldb0 & 3) || (g.A1 && ((g.lda1 & 3) || (g.ldb1 & 3)))) return NU_ERR_ARG;
+    dim3 grid(nu_cdiv(g.N1, 128) * nu_cdiv(g.N2, 128), g.S, g.groups > 0 ? g.groups : 1), block(256);
+    hipLaunchKernelGGL(gemm_tn_kernel, grid, block, 0, stream, g);
+    return nu_launch_status();
+}
+
+__global__ void slab_reduce_kernel(const float* __restrict__ slab, int S, int N1, int N2, int N1p, int N2p,
+                                   float* __restrict__ out, int ldo, float alpha, int accumulate) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= N1 * N2) return;
+    const int n1 = idx / N2, n2 = idx - n1 * N2;
+    const float* p = slab + (long long)n1 * N2p + n2;
+    const long long stride = (long long)N1p * N2p;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int s = 0;
+    for (; s + 3 < S; s += 4) {
+        s0 += p[(long long)s * stride];
+        s1 += p[(long long)(s + 1) * stride];
+        s2 += p[(long long)(s + 2) * stride];
+        s3 += p[(long long)(s + 3) * stride];
+    }
+    for (; s < S; ++s) s0 += p[(long long)s * stride];
+    float v = alpha * ((s0 + s1) + (s2 + s3));
+    float* o = out + (long long)n1 * ldo + n2;
+    *o = accumulate ? *o + v : v;
+}
+
+int nu_slab_reduce_launch(const float* slab, int S, int N1, int N2, float* out, int ldo, float alpha,
+                          int accumulate, hipStream_t stream) {
+    const int n = N1 * N2;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(nu_cdiv(n, 256)), dim3(256), 0, stream, slab, S, N1, N2,
+                       nu_rup(N1, 128), nu_rup(N2, 128), out, ldo, alpha, accumulate);
+    return nu_launch_status();
+}
+
+int nu_bias_slab_reduce_launch(const float* bslab, int S, int N1, float* out, int accumulate, hipStream_t stream) {
+    // a bias slab is a [S][N1p][1]-shaped slab: reuse the reducer with N2p = 1
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(nu_cdiv(N1, 256)), dim3(256), 0, stream, bslab, S, N1, 1,
+                       nu_rup(N1, 128), 1, out, 1, 1.0f, accumulate);
+    return nu_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// C ABI (test / bench entry points for the raw GEMMs)
+// ------------------------------------------------------------------------------------------------
+extern "C" int nu_gemm_nt(const float* A, int lda, const float* B, int ldb, int M, int N, int K, float* C, int ldc,
+                          float* C2, int ldc2, const float* bias, const float* H, int ldh, const float* D, int ldd,
+                          const float* Cadd, int ldadd, int zero_to, float alpha, int epi, hipStream_t stream) {
+    NuGemmNT g = {};
+    g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.M = M; g.N = N; g.K = K;
+    g.C = C; g.ldc = ldc; g.C2 = C2; g.ldc2 = ldc2; g.bias = bias; g.H = H; g.ldh = ldh; g.D = D; g.ldd = ldd;
+    g.Cadd = Cadd; g.ldadd = ldadd; g.zero_to = zero_to; g.alpha = alpha; g.groups = 1; g.epi = epi;
+    return nu_gemm_nt_launch(g, stream);
+}
+
+extern "C" long long nu_gemm_tn_workspace_bytes(int N1, int N2, int S) {
+    return (long long)S * nu_rup(N1, 128) * (nu_rup(N2, 128) + 1) * sizeof(float);
+}
+
+// C[N1,N2] = A0^T B0 (+ A1^T B1); bias_out[N1] = column sums of A0 (optional)
+extern "C" int nu_gemm_tn(const float* A0, int lda0, const float* B0, int ldb0, const float* A1, int lda1,
+                          const float* B1, int ldb1, int P, int N1, int N2, float* C, int ldc, float* bias_out,
+                          int S, void* workspace, long long workspace_bytes, hipStream_t stream) {
+    if (workspace_bytes < nu_gemm_tn_workspace_bytes(N1, N2, S)) return NU_ERR_WORKSPACE;
+    NuGemmTN g = {};
+    g.A0 = A0; g.lda0 = lda0; g.B0 = B0; g.ldb0 = ldb0; g.A1 = A1; g.lda1 = lda1; g.B1 = B1; g.ldb1 = ldb1;
+    g.P = P; g.N1 = N1; g.N2 = N2; g.S = S; g.groups = 1;
+    g.slab = (float*)workspace;
+    g.bias_slab = bias_out ? g.slab + (long long)S * nu_rup(N1, 128) * nu_rup(N2, 128) : nullptr;
+    int rc = nu_gemm_tn_launch(g, stream);
+    if (rc) return rc;
+    rc = nu_slab_reduce_launch(g.slab, S, N1, N2, C, ldc, 1.0f, 0, stream);
+    if (rc) return rc;
+    if (bias_out) rc = nu_bias_slab_reduce_launch(g.bias_slab, S, N1, bias_out, 0, stream);
+    return rc;
+}

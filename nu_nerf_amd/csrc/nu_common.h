@@ -1,0 +1,77 @@
+// nu_common.h -- shared device/host helpers for the NU-NeRF gfx950 hot-path library.
+//
+// Everything in csrc/ is written for gfx950 (MI355X, CDNA4) only: 64-wide wavefronts,
+// fp32-input MFMA (v_mfma_f32_32x32x2_f32) for the MLP contractions, LDS-staged tiles.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define NU_OK 0
+#define NU_ERR_ARG (-1)
+#define NU_ERR_LAUNCH (-2)
+#define NU_ERR_WORKSPACE (-3)
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define NU_WAVE 64
+
+// ceil-div / round-up helpers (host + device)
+static __host__ __device__ inline int nu_cdiv(int a, int b) { return (a + b - 1) / b; }
+static __host__ __device__ inline int nu_rup(int a, int b) { return nu_cdiv(a, b) * b; }
+static __host__ __device__ inline long long nu_cdivl(long long a, long long b) { return (a + b - 1) / b; }
+
+// Softplus(beta=100) with torch's threshold semantics (reference: network/field.py:126-127,
+// nn.Softplus(beta=100) -> x*beta > 20 ? x : log1p(exp(x*beta))/beta).
+static __device__ inline float nu_softplus100(float x) {
+    float bx = 100.0f * x;
+    return bx > 20.0f ? x : log1pf(expf(bx)) * 0.01f;
+}
+// d softplus / d preact expressed through the POST-activation value h = softplus(a):
+// sigma(beta*a) = 1 - exp(-beta*h).  Lets the training path store only h.
+static __device__ inline float nu_softplus100_grad_from_h(float h) { return -expm1f(-100.0f * h); }
+
+static __device__ inline float nu_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// sRGB transfer (reference: utils/raw_utils.py:5-17). eps = FLT_EPSILON.
+static __device__ inline float nu_linear_to_srgb(float x) {
+    const float eps = 1.1920928955078125e-07f;
+    float s0 = (323.0f / 25.0f) * x;
+    float s1 = (211.0f * powf(fmaxf(x, eps), 5.0f / 12.0f) - 11.0f) / 200.0f;
+    return x <= 0.0031308f ? s0 : s1;
+}
+// derivative of the above w.r.t. x
+static __device__ inline float nu_linear_to_srgb_grad(float x) {
+    const float eps = 1.1920928955078125e-07f;
+    if (x <= 0.0031308f) return 323.0f / 25.0f;
+    if (x < eps) return 0.0f;  // clamp region (unreachable: eps < 0.0031308)
+    return (211.0f / 200.0f) * (5.0f / 12.0f) * powf(x, 5.0f / 12.0f - 1.0f);
+}
+
+static inline int nu_launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? NU_OK : NU_ERR_LAUNCH;
+}
+
+// wave-level inclusive scans / reductions over 64 lanes
+static __device__ inline float nu_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+static __device__ inline float nu_wave_incl_sum(float v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        float t = __shfl_up(v, o, 64);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+static __device__ inline float nu_wave_incl_prod(float v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        float t = __shfl_up(v, o, 64);
+        if (lane >= o) v *= t;
+    }
+    return v;
+}

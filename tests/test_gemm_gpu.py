@@ -1,0 +1,129 @@
+"""GPU parity of the raw fp32-MFMA GEMM kernels (csrc/gemm.hip) against torch fp32 matmul.
+
+These are floating-point kernels, so the checker here is a plain torch fp32/fp64 reference of the
+same op (tolerance 2e-5 relative to the row's |a|.|b| mass: the MFMA is a k-ordered fp32 fma chain).
+"""
+import ctypes
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _nt(A, B, N, epi, bias=None, H=None, D=None, Cadd=None, zero_to=0, alpha=1.0, ldc=None):
+    from nu_nerf_amd import _lib as L
+    lib = L.load()
+    M, lda = A.shape
+    K = B.shape[1]
+    ldc = ldc or max(N, zero_to)
+    C = torch.full((M, ldc), float("nan"), device=A.device)
+    C2 = torch.full((M, ldc), float("nan"), device=A.device) if epi == 5 else None
+    rc = lib.nu_gemm_nt(L.ptr(A), lda, L.ptr(B), B.shape[1], M, N, K, L.ptr(C), ldc, L.ptr(C2), ldc,
+                        L.ptr(bias), L.ptr(H), H.shape[1] if H is not None else 0,
+                        L.ptr(D), D.shape[1] if D is not None else 0,
+                        L.ptr(Cadd), Cadd.shape[1] if Cadd is not None else 0,
+                        zero_to, ctypes.c_float(alpha), epi, L.stream())
+    L.check(rc, "nu_gemm_nt")
+    return C, C2
+
+
+def _packB(W, Kp):
+    N, K = W.shape
+    Np = (N + 127) // 128 * 128
+    B = torch.zeros(Np, Kp, device=W.device)
+    B[:N, :K] = W
+    return B
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 1, 32), (127, 3, 64), (300, 217, 256), (1000, 257, 288), (4099, 256, 96)])
+def test_nt_bias_epilogues(gpu, M, N, K):
+    torch.manual_seed(M * 7 + N)
+    A = torch.randn(M, K, device=gpu)
+    W = torch.randn(N, K, device=gpu) / K ** 0.5
+    b = torch.randn(N, device=gpu)
+    B = _packB(W, K)
+    ref = (A.double() @ W.double().t() + b.double())
+    for epi, fn in [(0, lambda x: x), (1, torch.relu),
+                    (2, lambda x: torch.nn.functional.softplus(x, beta=100))]:
+        C, _ = _nt(A, B, N, epi, bias=b)
+        torch.testing.assert_close(C[:, :N].double(), fn(ref), rtol=2e-5, atol=2e-5)
+
+
+def test_nt_zero_fill_and_untouched_columns(gpu):
+    M, N, K = 200, 217, 64
+    A = torch.randn(M, K, device=gpu)
+    W = torch.randn(N, K, device=gpu)
+    B = _packB(W, K)
+    C, _ = _nt(A, B, N, 7, zero_to=240, ldc=256)
+    assert torch.all(C[:, N:240] == 0)
+    assert torch.isnan(C[:, 240:]).all()  # never written
+    torch.testing.assert_close(C[:, :N], A @ W.t(), rtol=2e-5, atol=2e-4)
+
+
+def test_nt_derivative_epilogues(gpu):
+    M, N, K = 777, 256, 256
+    torch.manual_seed(3)
+    A = torch.randn(M, K, device=gpu)
+    W = torch.randn(N, K, device=gpu) / 16
+    B = _packB(W, K)
+    pre = torch.randn(M, N, device=gpu) * 0.02
+    Hsp = torch.nn.functional.softplus(pre, beta=100)
+    Hre = torch.relu(pre)
+    D = torch.randn(M, N, device=gpu)
+    Cadd = torch.randn(M, N, device=gpu)
+    v = (A.double() @ W.double().t())
+    sp = torch.sigmoid(100 * pre.double())
+    C, _ = _nt(A, B, N, 3, H=Hre)
+    torch.testing.assert_close(C.double(), v * (pre > 0), rtol=2e-5, atol=2e-5)
+    C, _ = _nt(A, B, N, 4, H=Hsp)
+    torch.testing.assert_close(C.double(), v * sp, rtol=2e-5, atol=2e-5)
+    C, C2 = _nt(A, B, N, 5, H=Hsp, D=D)
+    torch.testing.assert_close(C.double(), v * sp, rtol=2e-5, atol=2e-5)
+    torch.testing.assert_close(C2.double(), v * D.double() * 100 * sp * (1 - sp), rtol=2e-4, atol=2e-3)
+    C, _ = _nt(A, B, N, 6, H=Hsp, Cadd=Cadd, alpha=0.5)
+    torch.testing.assert_close(C.double(), 0.5 * v * sp + Cadd.double(), rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("P,N1,N2,S", [(1, 1, 1, 1), (1000, 257, 256, 7), (5000, 256, 39, 16), (333, 3, 256, 4)])
+def test_tn_weight_grad(gpu, P, N1, N2, S):
+    from nu_nerf_amd import _lib as L
+    lib = L.load()
+    lib.nu_gemm_tn_workspace_bytes.restype = ctypes.c_longlong
+    torch.manual_seed(P)
+    lda, ldb = (N1 + 3) // 4 * 4 + 4, (N2 + 3) // 4 * 4
+    A0 = torch.randn(P, lda, device=gpu)
+    B0 = torch.randn(P, ldb, device=gpu)
+    A1 = torch.randn(P, lda, device=gpu)
+    B1 = torch.randn(P, ldb, device=gpu)
+    wsb = lib.nu_gemm_tn_workspace_bytes(N1, N2, S)
+    ws = torch.empty(wsb // 4, device=gpu)
+    C = torch.full((N1, N2), float("nan"), device=gpu)
+    bo = torch.full((N1,), float("nan"), device=gpu)
+    rc = lib.nu_gemm_tn(L.ptr(A0), lda, L.ptr(B0), ldb, L.ptr(A1), lda, L.ptr(B1), ldb, P, N1, N2,
+                        L.ptr(C), N2, L.ptr(bo), S, L.ptr(ws), ctypes.c_longlong(wsb), L.stream())
+    L.check(rc, "nu_gemm_tn")
+    ref = A0[:, :N1].double().t() @ B0[:, :N2].double() + A1[:, :N1].double().t() @ B1[:, :N2].double()
+    tol = 3e-5 * P ** 0.5
+    torch.testing.assert_close(C.double(), ref, rtol=2e-5, atol=tol)
+    torch.testing.assert_close(bo.double(), A0[:, :N1].double().sum(0), rtol=2e-5, atol=tol)
+
+
+def test_gemm_throughput_smoke(gpu):
+    """Not a pass/fail perf gate: prints achieved TFLOP/s of the 256x256 layer GEMM."""
+    M, N, K = 262144, 256, 256
+    A = torch.randn(M, K, device=gpu)
+    W = torch.randn(N, K, device=gpu) / 16
+    B = _packB(W, K)
+    b = torch.zeros(N, device=gpu)
+    for _ in range(3):
+        _nt(A, B, N, 2, bias=b)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        _nt(A, B, N, 2, bias=b)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 10
+    print(f"\n[gemm_nt 262144x256x256 softplus] {ms:.3f} ms  {2 * M * N * K / ms / 1e9:.1f} TFLOP/s")
