@@ -143,9 +143,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NuGemmNT g) {
                     } else if (EPI == NU_EPI_Q_SP) {
                         float h = H[(long long)row * g.ldh + col];
                         float sp = nu_softplus100_grad_from_h(h);
-                        float d = D[(long long)row * g.ldd + col];
+                        float d = D[(long long)row * g.ldd + col];  // delta = gbar * sp'
                         out = v * sp;
-                        out2 = v * d * 100.0f * (1.0f - sp);
+                        out2 = v * d * 100.0f * expf(-100.0f * h);  // sp''/sp' = beta * (1 - sp')
                     } else if (EPI == NU_EPI_B_SP) {
                         float h = H[(long long)row * g.ldh + col];
                         out = v * nu_softplus100_grad_from_h(h) + Cadd[(long long)row * g.ldadd + col];
