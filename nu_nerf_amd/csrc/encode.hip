@@ -1,0 +1,411 @@
+// encode.hip -- input encodings of the three MLP stacks, one wavefront per point, lane = output column
+// so every row write is a contiguous burst.
+//
+// Reference semantics restated:
+//   positional encoding [x, sin(2^k x), cos(2^k x)]_k            network/field.py:14-61
+//   integrated directional encoding (72-d)                       utils/ref_utils.py:84-114
+//   SDF input-gradient through the embedding (J_emb^T)           network/field.py:158-170 (autograd)
+//   shading directions n^, v^, r = 2(v.n)n - v, NoV              network/field.py:686-689
+//   NeRF++ inputs (x/|x|, 1/|x|), view = -d                      network/renderer_zerothick.py:687-690
+#include "nu_common.h"
+#include "ide_table.h"
+
+// Per-point record written by the partition kernel (render.hip): 8 floats
+//   [0..2] position x, [3] dist (section length), [4..6] unit ray direction d, [7] unused
+#define NU_PT 8
+
+// column -> (is_raw, k, coord, is_cos) for an L-frequency embedding of a D-vector:
+// col < D : x[col];  else q = col - D, k = q / (2D), r = q % (2D), c = r % D, cos if r >= D
+static __device__ inline float nu_embed_col(const float* x, int D, int col) {
+    if (col < D) return x[col];
+    const int q = col - D;
+    const int k = q / (2 * D);
+    const int r = q - k * 2 * D;
+    const int c = r >= D ? r - D : r;
+    const float a = x[c] * (float)(1 << k);
+    return r >= D ? cosf(a) : sinf(a);
+}
+
+// ------------------------------------------------------------------------------------------------
+// SDF inputs:  E[p, 0:39] (+ zero pad to 64),  U4[p, 217:256] = embedding,  YX[p, 257:260] = x, rest of YX pad = 0
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sdf_embed_kernel(const float* __restrict__ pt, int pt_ld, int P,
+                                                        float* __restrict__ E, float* __restrict__ U4,
+                                                        float* __restrict__ YX) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwave = (gridDim.x * blockDim.x) >> 6;
+    for (int p = wave; p < P; p += nwave) {
+        float x[3];
+        x[0] = pt[(long long)p * pt_ld + 0];
+        x[1] = pt[(long long)p * pt_ld + 1];
+        x[2] = pt[(long long)p * pt_ld + 2];
+        const float v = lane < 39 ? nu_embed_col(x, 3, lane) : 0.f;
+        E[(long long)p * 64 + lane] = v;
+        if (U4 && lane < 39) U4[(long long)p * 256 + 217 + lane] = v;
+        if (YX && lane < 31) YX[(long long)p * 288 + 257 + lane] = lane < 3 ? x[lane] : 0.f;
+    }
+}
+
+extern "C" int nu_sdf_embed(const float* pt, int pt_ld, int P, float* E, float* U4, float* YX, hipStream_t stream) {
+    if (P <= 0) return NU_OK;
+    int blocks = nu_cdiv(P, 4);
+    blocks = blocks < 8192 ? blocks : 8192;
+    hipLaunchKernelGGL(sdf_embed_kernel, dim3(blocks), dim3(256), 0, stream, pt, pt_ld, P, E, U4, YX);
+    return nu_launch_status();
+}
+
+// n[p, c] = sum_col J[col][c] * (G0[p,col] + Gs[p,col]),  J = d emb / d x evaluated from the stored embedding E.
+__global__ __launch_bounds__(256) void embed_jt_kernel(const float* __restrict__ E, const float* __restrict__ G0, int ldg0,
+                                                       const float* __restrict__ Gs, int ldgs, int P,
+                                                       float* __restrict__ n) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwave = (gridDim.x * blockDim.x) >> 6;
+    for (int p = wave; p < P; p += nwave) {
+        float t = 0.f;
+        int c = 0;
+        if (lane < 39) {
+            float g = G0[(long long)p * ldg0 + lane];
+            if (Gs) g += Gs[(long long)p * ldgs + lane];
+            if (lane < 3) {
+                c = lane;
+                t = g;
+            } else {
+                const int q = lane - 3;
+                const int k = q / 6;
+                const int r = q - 6 * k;
+                c = r >= 3 ? r - 3 : r;
+                const float f = (float)(1 << k);
+                // d sin(f x)/dx = f cos(f x) (cos sits 3 columns later); d cos(f x)/dx = -f sin(f x)
+                const float other = r >= 3 ? -E[(long long)p * 64 + lane - 3] : E[(long long)p * 64 + lane + 3];
+                t = g * f * other;
+            }
+        }
+        const float s0 = nu_wave_sum(c == 0 ? t : 0.f);
+        const float s1 = nu_wave_sum(c == 1 ? t : 0.f);
+        const float s2 = nu_wave_sum(c == 2 ? t : 0.f);
+        if (lane < 3) n[(long long)p * 3 + lane] = lane == 0 ? s0 : (lane == 1 ? s1 : s2);
+    }
+}
+extern "C" int nu_embed_jt(const float* E, const float* G0, int ldg0, const float* Gs, int ldgs, int P, float* n,
+                           hipStream_t stream) {
+    if (P <= 0) return NU_OK;
+    int blocks = nu_cdiv(P, 4);
+    blocks = blocks < 8192 ? blocks : 8192;
+    hipLaunchKernelGGL(embed_jt_kernel, dim3(blocks), dim3(256), 0, stream, E, G0, ldg0, Gs, ldgs, P, n);
+    return nu_launch_status();
+}
+
+// q0[p, col] = sum_c J[col][c] * nbar[p, c]  -> Q0[p, 0:39] (pad zero to 64) and Q4[p, 217:256]
+__global__ __launch_bounds__(256) void embed_j_kernel(const float* __restrict__ E, const float* __restrict__ nbar, int P,
+                                                      float* __restrict__ Q0, float* __restrict__ Q4) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwave = (gridDim.x * blockDim.x) >> 6;
+    for (int p = wave; p < P; p += nwave) {
+        float v = 0.f;
+        if (lane < 39) {
+            if (lane < 3) {
+                v = nbar[(long long)p * 3 + lane];
+            } else {
+                const int q = lane - 3;
+                const int k = q / 6;
+                const int r = q - 6 * k;
+                const int c = r >= 3 ? r - 3 : r;
+                const float f = (float)(1 << k);
+                const float other = r >= 3 ? -E[(long long)p * 64 + lane - 3] : E[(long long)p * 64 + lane + 3];
+                v = f * other * nbar[(long long)p * 3 + c];
+            }
+        }
+        Q0[(long long)p * 64 + lane] = v;
+        if (lane < 39) Q4[(long long)p * 256 + 217 + lane] = v;
+    }
+}
+extern "C" int nu_embed_j(const float* E, const float* nbar, int P, float* Q0, float* Q4, hipStream_t stream) {
+    if (P <= 0) return NU_OK;
+    int blocks = nu_cdiv(P, 4);
+    blocks = blocks < 8192 ? blocks : 8192;
+    hipLaunchKernelGGL(embed_j_kernel, dim3(blocks), dim3(256), 0, stream, E, nbar, P, Q0, Q4);
+    return nu_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// IDE: lane i < 36 evaluates term i.  Returns (re, im) and optionally the partials.
+// ------------------------------------------------------------------------------------------------
+struct NuIdeTerm {
+    float re, im;          // value
+    float are, aim;        // (x+iy)^m
+    float pre, pim;        // (x+iy)^(m-1)   (0 for m = 0)
+    float poly, dpoly;     // P(z), P'(z)
+    float att;             // exp(-sigma * kappa_inv)
+    float sigma;
+    int m;
+};
+
+static __device__ inline NuIdeTerm nu_ide_term(int i, float x, float y, float z, float kappa_inv) {
+    NuIdeTerm t;
+    const int m = c_ide_m[i], l = c_ide_l[i];
+    float ar = 1.f, ai = 0.f, pr = 0.f, pi = 0.f;
+    for (int j = 0; j < m; ++j) {
+        pr = ar; pi = ai;
+        const float nr = ar * x - ai * y;
+        const float ni = ar * y + ai * x;
+        ar = nr; ai = ni;
+    }
+    // Horner over k = l-m .. 0
+    float poly = 0.f, dpoly = 0.f;
+    for (int k = l - m; k >= 0; --k) {
+        dpoly = dpoly * z + poly;
+        poly = poly * z + c_ide_mat[i][k];
+    }
+    const float sigma = 0.5f * (float)l * (float)(l + 1);
+    const float att = expf(-sigma * kappa_inv);
+    t.are = ar; t.aim = ai; t.pre = pr; t.pim = pi; t.poly = poly; t.dpoly = dpoly; t.att = att; t.sigma = sigma; t.m = m;
+    t.re = ar * poly * att;
+    t.im = ai * poly * att;
+    return t;
+}
+
+// write one 72-d IDE row (+ zero pad up to `width`) starting at column c0 of a row with `width` columns after c0
+static __device__ inline void nu_ide_write(float* row, int lane, float x, float y, float z, float kinv, int padto) {
+    if (lane < 36) {
+        NuIdeTerm t = nu_ide_term(lane, x, y, z, kinv);
+        row[lane] = t.re;
+        row[36 + lane] = t.im;
+    }
+    for (int c = 72 + lane; c < padto; c += 64) row[c] = 0.f;
+}
+
+// gradient of sum_i (gre_i * re_i + gim_i * im_i) w.r.t. (x, y, z, kappa_inv); lanes >= 36 contribute 0.
+static __device__ inline void nu_ide_grad(const float* grow, int lane, float x, float y, float z, float kinv,
+                                          float& dx, float& dy, float& dz, float& dk) {
+    float ax = 0.f, ay = 0.f, az = 0.f, ak = 0.f;
+    if (lane < 36) {
+        const float gre = grow[lane], gim = grow[36 + lane];
+        NuIdeTerm t = nu_ide_term(lane, x, y, z, kinv);
+        const float pe = t.poly * t.att;
+        // conj(g) * m * A' * P * E  ->  real part = d/dx, -imag part = d/dy
+        const float cr = (float)t.m * pe * (gre * t.pre + gim * t.pim);
+        const float ci = (float)t.m * pe * (gre * t.pim - gim * t.pre);
+        ax = cr;
+        ay = -ci;
+        az = (gre * t.are + gim * t.aim) * t.dpoly * t.att;
+        ak = -t.sigma * (gre * t.re + gim * t.im);
+    }
+    dx = nu_wave_sum(ax);
+    dy = nu_wave_sum(ay);
+    dz = nu_wave_sum(az);
+    dk = nu_wave_sum(ak);
+}
+
+__global__ __launch_bounds__(256) void ide_kernel(const float* __restrict__ dirs, const float* __restrict__ kinv, int P,
+                                                  float* __restrict__ out, int ldo) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwave = (gridDim.x * blockDim.x) >> 6;
+    for (int p = wave; p < P; p += nwave)
+        nu_ide_write(out + (long long)p * ldo, lane, dirs[p * 3LL], dirs[p * 3LL + 1], dirs[p * 3LL + 2],
+                     kinv ? kinv[p] : 0.f, ldo);
+}
+// stand-alone IDE (test entry + the per-ray colour_spec query IDE(d, 0), renderer_zerothick.py:780)
+extern "C" int nu_ide(const float* dirs, const float* kappa_inv, int P, float* out, int ldo, hipStream_t stream) {
+    if (P <= 0) return NU_OK;
+    if (ldo < 72) return NU_ERR_ARG;
+    int blocks = nu_cdiv(P, 4);
+    blocks = blocks < 8192 ? blocks : 8192;
+    hipLaunchKernelGGL(ide_kernel, dim3(blocks), dim3(256), 0, stream, dirs, kappa_inv, P, out, ldo);
+    return nu_launch_status();
+}
+
+__global__ __launch_bounds__(256) void ide_bwd_kernel(const float* __restrict__ dirs, const float* __restrict__ kinv,
+                                                      const float* __restrict__ gout, int ldg, int P,
+                                                      float* __restrict__ ddirs, float* __restrict__ dk) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwave = (gridDim.x * blockDim.x) >> 6;
+    for (int p = wave; p < P; p += nwave) {
+        float dx, dy, dz, dkk;
+        nu_ide_grad(gout + (long long)p * ldg, lane, dirs[p * 3LL], dirs[p * 3LL + 1], dirs[p * 3LL + 2],
+                    kinv ? kinv[p] : 0.f, dx, dy, dz, dkk);
+        if (lane == 0) {
+            ddirs[p * 3LL] = dx; ddirs[p * 3LL + 1] = dy; ddirs[p * 3LL + 2] = dz;
+            if (dk) dk[p] = dkk;
+        }
+    }
+}
+extern "C" int nu_ide_bwd(const float* dirs, const float* kappa_inv, const float* gout, int ldg, int P, float* ddirs,
+                          float* dkappa, hipStream_t stream) {
+    if (P <= 0) return NU_OK;
+    int blocks = nu_cdiv(P, 4);
+    blocks = blocks < 8192 ? blocks : 8192;
+    hipLaunchKernelGGL(ide_bwd_kernel, dim3(blocks), dim3(256), 0, stream, dirs, kappa_inv, gout, ldg, P, ddirs, dkappa);
+    return nu_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Shading-stack inputs (P inner points).  Buffers (row-major, zero padded):
+//   OLin [3P, 96] : IDE(n^,1) | IDE(r,rho) | IDE(r,0)                    -> outer_light
+//   ILin [2P,128] : [E(39), IDE(r,rho)(72)] | [E(39), IDE(r,0)(72)]      -> inner_light
+//   IWin [P, 96]  : [E(39), embed(r,6)(39)]                              -> inner_weight (inputs detached)
+//   RLin [P, 96]  : [E(39), embed(v^,6)(39)]                             -> refrac_light
+//   SD   [P, 8]   : n^(3), NoV, 1/|n|, rho, 0, 0
+// ------------------------------------------------------------------------------------------------
+static __device__ inline void nu_shade_dirs(const float* n, const float* d, float* nh, float* vh, float* r, float& nov,
+                                            float& inv_norm) {
+    const float nn = sqrtf(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+    inv_norm = 1.0f / fmaxf(nn, 1e-12f);
+    const float vn = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    const float ivn = 1.0f / fmaxf(vn, 1e-12f);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { nh[c] = n[c] * inv_norm; vh[c] = -d[c] * ivn; }
+    nov = nh[0] * vh[0] + nh[1] * vh[1] + nh[2] * vh[2];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) r[c] = nov * nh[c] * 2.0f - vh[c];
+}
+
+__global__ __launch_bounds__(256) void shade_encode_fwd_kernel(const float* __restrict__ nrm, const float* __restrict__ pt,
+                                                               int pt_ld, const float* __restrict__ E,
+                                                               const float* __restrict__ Mraw, int ldm, int P,
+                                                               float* __restrict__ OLin, float* __restrict__ ILin,
+                                                               float* __restrict__ IWin, float* __restrict__ RLin,
+                                                               float* __restrict__ SD) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwave = (gridDim.x * blockDim.x) >> 6;
+    for (int p = wave; p < P; p += nwave) {
+        float n[3], d[3], nh[3], vh[3], r[3], nov, inorm;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { n[c] = nrm[p * 3LL + c]; d[c] = pt[(long long)p * pt_ld + 4 + c]; }
+        nu_shade_dirs(n, d, nh, vh, r, nov, inorm);
+        const float rho = nu_sigmoid(Mraw[(long long)p * ldm + 1]);
+        const float e = lane < 39 ? E[(long long)p * 64 + lane] : 0.f;
+
+        nu_ide_write(OLin + (long long)p * 96, lane, nh[0], nh[1], nh[2], 1.0f, 96);
+        nu_ide_write(OLin + (long long)(P + p) * 96, lane, r[0], r[1], r[2], rho, 96);
+        nu_ide_write(OLin + (long long)(2LL * P + p) * 96, lane, r[0], r[1], r[2], 0.0f, 96);
+
+        float* il0 = ILin + (long long)p * 128;
+        float* il1 = ILin + (long long)(P + p) * 128;
+        if (lane < 39) { il0[lane] = e; il1[lane] = e; }
+        nu_ide_write(il0 + 39, lane, r[0], r[1], r[2], rho, 128 - 39);
+        nu_ide_write(il1 + 39, lane, r[0], r[1], r[2], 0.0f, 128 - 39);
+
+        float* iw = IWin + (long long)p * 96;
+        float* rl = RLin + (long long)p * 96;
+        if (lane < 39) {
+            iw[lane] = e;
+            rl[lane] = e;
+            iw[39 + lane] = nu_embed_col(r, 3, lane);
+            rl[39 + lane] = nu_embed_col(vh, 3, lane);
+        } else if (lane < 39 + 18) {
+            iw[78 + lane - 39] = 0.f;
+            rl[78 + lane - 39] = 0.f;
+        }
+        if (lane < 8) {
+            float v = 0.f;
+            if (lane < 3) v = nh[lane];
+            else if (lane == 3) v = nov;
+            else if (lane == 4) v = inorm;
+            else if (lane == 5) v = rho;
+            SD[(long long)p * 8 + lane] = v;
+        }
+    }
+}
+extern "C" int nu_shade_encode_fwd(const float* nrm, const float* pt, int pt_ld, const float* E, const float* Mraw,
+                                   int ldm, int P, float* OLin, float* ILin, float* IWin, float* RLin, float* SD,
+                                   hipStream_t stream) {
+    if (P <= 0) return NU_OK;
+    int blocks = nu_cdiv(P, 4);
+    blocks = blocks < 8192 ? blocks : 8192;
+    hipLaunchKernelGGL(shade_encode_fwd_kernel, dim3(blocks), dim3(256), 0, stream, nrm, pt, pt_ld, E, Mraw, ldm, P, OLin,
+                       ILin, IWin, RLin, SD);
+    return nu_launch_status();
+}
+
+// backward: gradients w.r.t. the IDE inputs (dOLin, dILin cols 39..110) and dNoV (from the combine kernel)
+//   -> dn_shade[P,3] (w.r.t. the RAW sdf gradient n), and dMraw[p,1] += d rho * rho (1 - rho)
+__global__ __launch_bounds__(256) void shade_encode_bwd_kernel(const float* __restrict__ nrm, const float* __restrict__ pt,
+                                                               int pt_ld, const float* __restrict__ SD,
+                                                               const float* __restrict__ dOLin,
+                                                               const float* __restrict__ dILin,
+                                                               const float* __restrict__ dNoV, int P,
+                                                               float* __restrict__ dn, float* __restrict__ dMraw, int ldm) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwave = (gridDim.x * blockDim.x) >> 6;
+    for (int p = wave; p < P; p += nwave) {
+        float n[3], d[3], nh[3], vh[3], r[3], nov, inorm;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { n[c] = nrm[p * 3LL + c]; d[c] = pt[(long long)p * pt_ld + 4 + c]; }
+        nu_shade_dirs(n, d, nh, vh, r, nov, inorm);
+        const float rho = SD[(long long)p * 8 + 5];
+        float gx, gy, gz, gk;
+        float dnh[3], dr[3] = {0.f, 0.f, 0.f}, drho = 0.f;
+        nu_ide_grad(dOLin + (long long)p * 96, lane, nh[0], nh[1], nh[2], 1.0f, gx, gy, gz, gk);
+        dnh[0] = gx; dnh[1] = gy; dnh[2] = gz;
+        nu_ide_grad(dOLin + (long long)(P + p) * 96, lane, r[0], r[1], r[2], rho, gx, gy, gz, gk);
+        dr[0] += gx; dr[1] += gy; dr[2] += gz; drho += gk;
+        nu_ide_grad(dOLin + (long long)(2LL * P + p) * 96, lane, r[0], r[1], r[2], 0.0f, gx, gy, gz, gk);
+        dr[0] += gx; dr[1] += gy; dr[2] += gz;
+        nu_ide_grad(dILin + (long long)p * 128 + 39, lane, r[0], r[1], r[2], rho, gx, gy, gz, gk);
+        dr[0] += gx; dr[1] += gy; dr[2] += gz; drho += gk;
+        nu_ide_grad(dILin + (long long)(P + p) * 128 + 39, lane, r[0], r[1], r[2], 0.0f, gx, gy, gz, gk);
+        dr[0] += gx; dr[1] += gy; dr[2] += gz;
+        if (lane == 0) {
+            // r = 2 NoV n^ - v^ ; NoV = n^ . v^
+            const float dnov = dNoV[p] + 2.0f * (dr[0] * nh[0] + dr[1] * nh[1] + dr[2] * nh[2]);
+            float t[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) t[c] = dnh[c] + 2.0f * nov * dr[c] + dnov * vh[c];
+            // n^ = n / |n|
+            const float dotp = t[0] * nh[0] + t[1] * nh[1] + t[2] * nh[2];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) dn[p * 3LL + c] = (t[c] - nh[c] * dotp) * inorm;
+            dMraw[(long long)p * ldm + 1] += drho * rho * (1.0f - rho);
+        }
+    }
+}
+extern "C" int nu_shade_encode_bwd(const float* nrm, const float* pt, int pt_ld, const float* SD, const float* dOLin,
+                                   const float* dILin, const float* dNoV, int P, float* dn, float* dMraw, int ldm,
+                                   hipStream_t stream) {
+    if (P <= 0) return NU_OK;
+    int blocks = nu_cdiv(P, 4);
+    blocks = blocks < 8192 ? blocks : 8192;
+    hipLaunchKernelGGL(shade_encode_bwd_kernel, dim3(blocks), dim3(256), 0, stream, nrm, pt, pt_ld, SD, dOLin, dILin, dNoV,
+                       P, dn, dMraw, ldm);
+    return nu_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// NeRF++ inputs (P outer points):  E4[p, 0:84] (pad to 96) = embed((x/|x|, 1/|x|), 10);
+//   U5[p, 256:340] = same embedding (skip concat, pad to 352);  V[p, 256:283] = embed(-d, 4) (pad to 288)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void nerf_embed_kernel(const float* __restrict__ pt, int pt_ld, int P,
+                                                         float* __restrict__ E4, float* __restrict__ U5,
+                                                         float* __restrict__ V) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwave = (gridDim.x * blockDim.x) >> 6;
+    for (int p = wave; p < P; p += nwave) {
+        float x[4], vd[3];
+        const float px = pt[(long long)p * pt_ld], py = pt[(long long)p * pt_ld + 1], pz = pt[(long long)p * pt_ld + 2];
+        const float nn = sqrtf(px * px + py * py + pz * pz);
+        x[0] = px / nn; x[1] = py / nn; x[2] = pz / nn; x[3] = 1.0f / nn;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) vd[c] = -pt[(long long)p * pt_ld + 4 + c];
+        for (int col = lane; col < 96; col += 64) {
+            const float v = col < 84 ? nu_embed_col(x, 4, col) : 0.f;
+            E4[(long long)p * 96 + col] = v;
+            U5[(long long)p * 352 + 256 + col] = v;  // cols 340..351 get the zero pad
+        }
+        if (lane < 32) V[(long long)p * 288 + 256 + lane] = lane < 27 ? nu_embed_col(vd, 3, lane) : 0.f;
+    }
+}
+extern "C" int nu_nerf_embed(const float* pt, int pt_ld, int P, float* E4, float* U5, float* V, hipStream_t stream) {
+    if (P <= 0) return NU_OK;
+    int blocks = nu_cdiv(P, 4);
+    blocks = blocks < 8192 ? blocks : 8192;
+    hipLaunchKernelGGL(nerf_embed_kernel, dim3(blocks), dim3(256), 0, stream, pt, pt_ld, P, E4, U5, V);
+    return nu_launch_status();
+}

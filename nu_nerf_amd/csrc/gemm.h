@@ -24,7 +24,8 @@ enum NuEpi {
     NU_EPI_Q_SP = 5,           // C = v * sp'(H);  C2 = v * D[row,col] * 100 * (1 - sp'(H))
     NU_EPI_B_SP = 6,           // C = v * sp'(H) + Cadd[row,col]
     NU_EPI_PLAIN = 7,          // C = v
-    NU_EPI_COUNT = 8
+    NU_EPI_B_RELU = 8,         // C = v * (H > 0) + Cadd[row,col]
+    NU_EPI_COUNT = 9
 };
 
 struct NuGemmNT {
@@ -38,6 +39,7 @@ struct NuGemmNT {
     const float* D; int ldd;      // delta aux (NU_EPI_Q_SP)
     const float* Cadd; int ldadd; // additive aux (NU_EPI_B_SP)
     int zero_to;                  // cols in [N, zero_to) of C (and C2) are written as 0
+    int act_cols;                 // derivative epilogues: cols >= act_cols are written as plain v (0 => all cols)
     float alpha;
     // grouped launch: blockIdx.z in [0, groups); element strides per group
     int groups;
@@ -65,3 +67,5 @@ int nu_slab_reduce_launch(const float* slab, int S, int N1, int N2, float* out, 
                           int accumulate, hipStream_t stream);
 // out[n1] (+)= sum_s bias_slab[s][n1]
 int nu_bias_slab_reduce_launch(const float* bslab, int S, int N1, float* out, int accumulate, hipStream_t stream);
+int nu_slab_reduce_strided_launch(const float* slab, int S, int N1, int N2, int N1p, int N2p, float* out, int ldo,
+                                  float alpha, int accumulate, hipStream_t stream);

@@ -111,6 +111,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NuGemmNT g) {
     const float* __restrict__ D = g.D ? g.D + (long long)z * g.sD : nullptr;
     const float* __restrict__ Cadd = g.Cadd ? g.Cadd + (long long)z * g.sCadd : nullptr;
     const int zero_to = g.zero_to > g.N ? g.zero_to : g.N;
+    const int act_cols = g.act_cols > 0 ? g.act_cols : 0x7fffffff;
 
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn) {
@@ -127,7 +128,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NuGemmNT g) {
                 if (row >= g.M) continue;
                 float v = g.alpha * acc[tm][tn][r];
                 float out = 0.0f, out2 = 0.0f;
-                if (live) {
+                if (live && EPI >= NU_EPI_MUL_DRELU && EPI != NU_EPI_PLAIN && col >= act_cols) {
+                    out = v;
+                } else if (live) {
                     if (EPI == NU_EPI_BIAS_NONE) {
                         out = v + bv;
                     } else if (EPI == NU_EPI_BIAS_RELU) {
@@ -149,6 +152,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NuGemmNT g) {
                     } else if (EPI == NU_EPI_B_SP) {
                         float h = H[(long long)row * g.ldh + col];
                         out = v * nu_softplus100_grad_from_h(h) + Cadd[(long long)row * g.ldadd + col];
+                    } else if (EPI == NU_EPI_B_RELU) {
+                        float h = H[(long long)row * g.ldh + col];
+                        out = (h > 0.0f ? v : 0.0f) + Cadd[(long long)row * g.ldadd + col];
                     } else {
                         out = v;
                     }
@@ -179,6 +185,7 @@ int nu_gemm_nt_launch(const NuGemmNT& g, hipStream_t stream) {
         NU_CASE(NU_EPI_Q_SP)
         NU_CASE(NU_EPI_B_SP)
         NU_CASE(NU_EPI_PLAIN)
+        NU_CASE(NU_EPI_B_RELU)
 #undef NU_CASE
         default: return NU_ERR_ARG;
     }
@@ -348,6 +355,15 @@ int nu_slab_reduce_launch(const float* slab, int S, int N1, int N2, float* out, 
     return nu_launch_status();
 }
 
+int nu_slab_reduce_strided_launch(const float* slab, int S, int N1, int N2, int N1p, int N2p, float* out, int ldo,
+                                  float alpha, int accumulate, hipStream_t stream) {
+    const int n = N1 * N2;
+    if (n <= 0) return NU_OK;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(nu_cdiv(n, 256)), dim3(256), 0, stream, slab, S, N1, N2, N1p, N2p,
+                       out, ldo, alpha, accumulate);
+    return nu_launch_status();
+}
+
 int nu_bias_slab_reduce_launch(const float* bslab, int S, int N1, float* out, int accumulate, hipStream_t stream) {
     // a bias slab is a [S][N1p][1]-shaped slab: reuse the reducer with N2p = 1
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(nu_cdiv(N1, 256)), dim3(256), 0, stream, bslab, S, N1, 1,
@@ -387,5 +403,35 @@ extern "C" int nu_gemm_tn(const float* A0, int lda0, const float* B0, int ldb0, 
     rc = nu_slab_reduce_launch(g.slab, S, N1, N2, C, ldc, 1.0f, 0, stream);
     if (rc) return rc;
     if (bias_out) rc = nu_bias_slab_reduce_launch(g.bias_slab, S, N1, bias_out, 0, stream);
+    return rc;
+}
+
+// struct-pointer entry points (what the Python host layer binds; one pointer argument keeps ctypes cheap)
+extern "C" int nu_gemm_nt_ex(const NuGemmNT* g, hipStream_t stream) { return nu_gemm_nt_launch(*g, stream); }
+
+// Weight-gradient GEMM + deterministic split reduction.
+//   dW[N1, N2] (ld = ldw) = A0^T B0 (+ A1^T B1);   db[N1] = column sums of A0 (optional)
+// grouped: `groups` independent problems at element strides (sA*, sB*, sW, sDb).
+extern "C" long long nu_wgrad_workspace_bytes(int N1, int N2, int S, int groups) {
+    return (long long)(groups > 0 ? groups : 1) * S * nu_rup(N1, 128) * (nu_rup(N2, 128) + 1) * sizeof(float);
+}
+extern "C" int nu_wgrad(const NuGemmTN* gin, float* dW, int ldw, long long sW, float* db, long long sDb,
+                        void* workspace, long long workspace_bytes, hipStream_t stream) {
+    NuGemmTN g = *gin;
+    const int groups = g.groups > 0 ? g.groups : 1;
+    if (g.P <= 0) return NU_ERR_ARG;
+    if (workspace_bytes < nu_wgrad_workspace_bytes(g.N1, g.N2, g.S, groups)) return NU_ERR_WORKSPACE;
+    const long long slab_per = (long long)g.S * nu_rup(g.N1, 128) * nu_rup(g.N2, 128);
+    const long long bias_per = (long long)g.S * nu_rup(g.N1, 128);
+    g.slab = (float*)workspace;
+    g.sSlab = slab_per;
+    g.bias_slab = db ? g.slab + slab_per * groups : nullptr;
+    g.sBiasSlab = bias_per;
+    g.groups = groups;
+    int rc = nu_gemm_tn_launch(g, stream);
+    for (int z = 0; z < groups && rc == NU_OK; ++z) {
+        rc = nu_slab_reduce_launch(g.slab + z * slab_per, g.S, g.N1, g.N2, dW + z * sW, ldw, 1.0f, 0, stream);
+        if (rc == NU_OK && db) rc = nu_bias_slab_reduce_launch(g.bias_slab + z * bias_per, g.S, g.N1, db + z * sDb, 0, stream);
+    }
     return rc;
 }

@@ -1,0 +1,356 @@
+// mlp.hip -- support kernels around the MFMA GEMMs: weight packing (weight-norm folded), gradient
+// unpacking (weight-norm chain rule), skinny output heads (N <= 8), column sums, row scaling.
+//
+// Reference semantics restated here:
+//   nn.utils.weight_norm (legacy, dim=0)  W = v * (g / ||v||_row)        network/field.py:121-122, :386-393
+//   the 1-, 3-wide output layers of make_predictor / NeRFNetwork heads     network/field.py:393, :260-261
+#include "gemm.h"
+
+// ------------------------------------------------------------------------------------------------
+// pack / unpack
+// ------------------------------------------------------------------------------------------------
+struct NuPackDesc {
+    const float* v;      // [N, K] weight_v (or plain weight)
+    const float* g;      // [N] weight_g, or null for a plain Linear
+    const int* colmap;   // [K] original column -> packed column, or null (identity)
+    float* Wp;           // packed [>=N][Kp] (row stride Kp), forward operand
+    float* WpT;          // packed transpose [>=Kp][ldT]: WpT[kp*ldT + n], or null
+    const float* dWp;    // gradient in packed layout [N][ldd]
+    long long dv_off;    // offsets (floats) into the flat gradient buffer
+    long long dg_off;    // (-1: none)
+    const float* bias;   // [N] bias parameter (or null)
+    float* bias_p;       // packed bias destination (or null): bias_p[n] = bias[n]
+    float scale;         // extra factor folded into the packed weight (1/sqrt(2) at the SDF skip)
+    int N, K, Kp, ldT, ldd;
+    int row_begin;       // first global row of this descriptor in the batched launch
+    int col_off;         // added to every packed column index (block-diagonal heads)
+};
+
+static __device__ inline int nu_find_desc(const NuPackDesc* __restrict__ d, int nd, int row) {
+    int lo = 0, hi = nd - 1;
+    while (lo < hi) {
+        int mid = (lo + hi + 1) >> 1;
+        if (d[mid].row_begin <= row) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(64) void pack_kernel(const NuPackDesc* __restrict__ descs, int nd) {
+    const int row = blockIdx.x;
+    const int lane = threadIdx.x;
+    const NuPackDesc d = descs[nu_find_desc(descs, nd, row)];
+    const int n = row - d.row_begin;
+    const float* __restrict__ v = d.v + (long long)n * d.K;
+    float s = d.scale;
+    if (d.g) {
+        float ss = 0.f;
+        for (int k = lane; k < d.K; k += 64) ss += v[k] * v[k];
+        ss = nu_wave_sum(ss);
+        s *= d.g[n] / sqrtf(ss);
+    }
+    for (int k = lane; k < d.K; k += 64) {
+        const int kp = (d.colmap ? d.colmap[k] : k) + d.col_off;
+        const float w = v[k] * s;
+        d.Wp[(long long)n * d.Kp + kp] = w;
+        if (d.WpT) d.WpT[(long long)kp * d.ldT + n] = w;
+    }
+    if (lane == 0 && d.bias_p) d.bias_p[n] = d.bias[n];
+}
+
+__global__ __launch_bounds__(64) void unpack_kernel(const NuPackDesc* __restrict__ descs, int nd,
+                                                    float* __restrict__ flat) {
+    const int row = blockIdx.x;
+    const int lane = threadIdx.x;
+    const NuPackDesc d = descs[nu_find_desc(descs, nd, row)];
+    const int n = row - d.row_begin;
+    const float* __restrict__ v = d.v + (long long)n * d.K;
+    const float* __restrict__ dw = d.dWp + (long long)n * d.ldd;
+    float* __restrict__ dv = flat + d.dv_off + (long long)n * d.K;
+    if (d.g) {
+        float ss = 0.f, dot = 0.f;
+        for (int k = lane; k < d.K; k += 64) {
+            const int kp = (d.colmap ? d.colmap[k] : k) + d.col_off;
+            const float vv = v[k];
+            ss += vv * vv;
+            dot += d.scale * dw[kp] * vv;
+        }
+        ss = nu_wave_sum(ss);
+        dot = nu_wave_sum(dot);
+        const float norm = sqrtf(ss);
+        const float gn = d.g[n] / norm;
+        const float c2 = gn * dot / ss;
+        for (int k = lane; k < d.K; k += 64) {
+            const int kp = (d.colmap ? d.colmap[k] : k) + d.col_off;
+            dv[k] = gn * d.scale * dw[kp] - c2 * v[k];
+        }
+        if (lane == 0) flat[d.dg_off + n] = dot / norm;
+    } else {
+        for (int k = lane; k < d.K; k += 64) {
+            const int kp = (d.colmap ? d.colmap[k] : k) + d.col_off;
+            dv[k] = d.scale * dw[kp];
+        }
+    }
+}
+
+extern "C" int nu_pack_layers(const void* descs, int ndesc, int total_rows, hipStream_t stream) {
+    if (total_rows <= 0) return NU_OK;
+    hipLaunchKernelGGL(pack_kernel, dim3(total_rows), dim3(64), 0, stream, (const NuPackDesc*)descs, ndesc);
+    return nu_launch_status();
+}
+extern "C" int nu_unpack_grads(const void* descs, int ndesc, int total_rows, float* flat_grads, hipStream_t stream) {
+    if (total_rows <= 0) return NU_OK;
+    hipLaunchKernelGGL(unpack_kernel, dim3(total_rows), dim3(64), 0, stream, (const NuPackDesc*)descs, ndesc, flat_grads);
+    return nu_launch_status();
+}
+extern "C" int nu_pack_desc_size() { return (int)sizeof(NuPackDesc); }
+
+// ------------------------------------------------------------------------------------------------
+// skinny heads: out[p, j] = sum_k H[p, k] * Ws[j, k] + b[j],  j < NO <= 8.   HBM-bound (reads H once).
+// ------------------------------------------------------------------------------------------------
+template <int NO>
+__global__ __launch_bounds__(256) void skinny_fwd_kernel(const float* __restrict__ H, int ldh, int P, int K,
+                                                         const float* __restrict__ Ws, int ldw,
+                                                         const float* __restrict__ b, float* __restrict__ out, int ldo) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwave = (gridDim.x * blockDim.x) >> 6;
+    const int nchunk = K >> 2;  // float4 chunks per row
+    for (int p = wave; p < P; p += nwave) {
+        float acc[NO];
+#pragma unroll
+        for (int j = 0; j < NO; ++j) acc[j] = 0.f;
+        for (int c = lane; c < nchunk; c += 64) {
+            const f32x4 h = *reinterpret_cast<const f32x4*>(H + (long long)p * ldh + 4 * c);
+#pragma unroll
+            for (int j = 0; j < NO; ++j) {
+                const f32x4 w = *reinterpret_cast<const f32x4*>(Ws + (long long)j * ldw + 4 * c);
+                acc[j] += h[0] * w[0] + h[1] * w[1] + h[2] * w[2] + h[3] * w[3];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NO; ++j) acc[j] = nu_wave_sum(acc[j]);
+        if (lane == 0) {
+#pragma unroll
+            for (int j = 0; j < NO; ++j) out[(long long)p * ldo + j] = acc[j] + (b ? b[j] : 0.f);
+        }
+    }
+}
+
+extern "C" int nu_skinny_fwd(const float* H, int ldh, int P, int K, const float* Ws, int ldw, const float* b, int NO,
+                             float* out, int ldo, hipStream_t stream) {
+    if (P <= 0) return NU_OK;
+    if ((K & 3) || (ldh & 3) || (ldw & 3)) return NU_ERR_ARG;
+    const int blocks = nu_cdiv(P, 4) < 4096 ? nu_cdiv(P, 4) : 4096;
+    dim3 grid(blocks), block(256);
+    switch (NO) {
+#define NU_CASE(n) case n: hipLaunchKernelGGL(skinny_fwd_kernel<n>, grid, block, 0, stream, H, ldh, P, K, Ws, ldw, b, out, ldo); break;
+        NU_CASE(1) NU_CASE(2) NU_CASE(3) NU_CASE(4) NU_CASE(6)
+#undef NU_CASE
+        default: return NU_ERR_ARG;
+    }
+    return nu_launch_status();
+}
+
+// backward of a skinny head (feeding a ReLU hidden layer):
+//   dH[p,k]   = (sum_j dy[p,j] Ws[j,k]) * (relu_mask ? H[p,k] > 0 : 1)      (written, or added to dH if accumulate)
+//   dWs[j,k]  = sum_p dy[p,j] H[p,k]      (per-block partial -> slab[blk][j][k])
+//   db[j]     = sum_p dy[p,j]             (per-block partial -> bslab[blk][j])
+template <int NO, int KT>  // KT = K / 256 columns per thread
+__global__ __launch_bounds__(256) void skinny_bwd_kernel(const float* __restrict__ dy, int ldy,
+                                                         const float* __restrict__ H, int ldh, int P,
+                                                         const float* __restrict__ Ws, int ldw, float* __restrict__ dH,
+                                                         int lddh, int relu_mask, int accumulate,
+                                                         float* __restrict__ slab, float* __restrict__ bslab) {
+    const int tid = threadIdx.x;
+    const int K = KT * 256;
+    int rows_per = (P + gridDim.x - 1) / gridDim.x;
+    const int p0 = blockIdx.x * rows_per;
+    int p1 = p0 + rows_per;
+    p1 = p1 < P ? p1 : P;
+    float w[NO][KT], acc[NO][KT], bacc[NO];
+#pragma unroll
+    for (int j = 0; j < NO; ++j) {
+        bacc[j] = 0.f;
+#pragma unroll
+        for (int t = 0; t < KT; ++t) {
+            w[j][t] = Ws[(long long)j * ldw + tid + 256 * t];
+            acc[j][t] = 0.f;
+        }
+    }
+    for (int p = p0; p < p1; ++p) {
+        float g[NO];
+#pragma unroll
+        for (int j = 0; j < NO; ++j) {
+            g[j] = dy[(long long)p * ldy + j];
+            bacc[j] += g[j];
+        }
+#pragma unroll
+        for (int t = 0; t < KT; ++t) {
+            const long long o = (long long)p * ldh + tid + 256 * t;
+            const float h = H[o];
+            float d = 0.f;
+#pragma unroll
+            for (int j = 0; j < NO; ++j) {
+                d += g[j] * w[j][t];
+                acc[j][t] += g[j] * h;
+            }
+            if (relu_mask && !(h > 0.f)) d = 0.f;
+            const long long od = (long long)p * lddh + tid + 256 * t;
+            dH[od] = accumulate ? dH[od] + d : d;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NO; ++j) {
+#pragma unroll
+        for (int t = 0; t < KT; ++t) slab[((long long)blockIdx.x * NO + j) * K + tid + 256 * t] = acc[j][t];
+    }
+    if (tid == 0) {
+#pragma unroll
+        for (int j = 0; j < NO; ++j) bslab[(long long)blockIdx.x * NO + j] = bacc[j];
+    }
+}
+
+// K == 128 variant handled by KT=1 with 128 active columns is not needed: heads in this model have K in {128,256,1024};
+// K=128 uses a dedicated instantiation with half the block idle.
+template <int NO>
+__global__ __launch_bounds__(128) void skinny_bwd128_kernel(const float* __restrict__ dy, int ldy,
+                                                            const float* __restrict__ H, int ldh, int P,
+                                                            const float* __restrict__ Ws, int ldw, float* __restrict__ dH,
+                                                            int lddh, int relu_mask, int accumulate,
+                                                            float* __restrict__ slab, float* __restrict__ bslab) {
+    const int tid = threadIdx.x;
+    int rows_per = (P + gridDim.x - 1) / gridDim.x;
+    const int p0 = blockIdx.x * rows_per;
+    int p1 = p0 + rows_per;
+    p1 = p1 < P ? p1 : P;
+    float w[NO], acc[NO], bacc[NO];
+#pragma unroll
+    for (int j = 0; j < NO; ++j) { w[j] = Ws[(long long)j * ldw + tid]; acc[j] = 0.f; bacc[j] = 0.f; }
+    for (int p = p0; p < p1; ++p) {
+        const float h = H[(long long)p * ldh + tid];
+        float d = 0.f;
+#pragma unroll
+        for (int j = 0; j < NO; ++j) {
+            const float g = dy[(long long)p * ldy + j];
+            bacc[j] += g;
+            d += g * w[j];
+            acc[j] += g * h;
+        }
+        if (relu_mask && !(h > 0.f)) d = 0.f;
+        const long long od = (long long)p * lddh + tid;
+        dH[od] = accumulate ? dH[od] + d : d;
+    }
+#pragma unroll
+    for (int j = 0; j < NO; ++j) slab[((long long)blockIdx.x * NO + j) * 128 + tid] = acc[j];
+    if (tid == 0) {
+#pragma unroll
+        for (int j = 0; j < NO; ++j) bslab[(long long)blockIdx.x * NO + j] = bacc[j];
+    }
+}
+
+#define NU_SKINNY_BLOCKS 1024
+extern "C" long long nu_skinny_bwd_workspace_bytes(int K, int NO) {
+    return (long long)NU_SKINNY_BLOCKS * NO * (K + 1) * sizeof(float);
+}
+
+extern "C" int nu_skinny_bwd(const float* dy, int ldy, const float* H, int ldh, int P, int K, const float* Ws, int ldw,
+                             int NO, float* dH, int lddh, int relu_mask, int accumulate, float* dWs, int lddw,
+                             float* db, void* workspace, long long workspace_bytes, hipStream_t stream) {
+    if (P <= 0) return NU_ERR_ARG;
+    if (workspace_bytes < nu_skinny_bwd_workspace_bytes(K, NO)) return NU_ERR_WORKSPACE;
+    int blocks = nu_cdiv(P, 64);
+    blocks = blocks < NU_SKINNY_BLOCKS ? blocks : NU_SKINNY_BLOCKS;
+    float* slab = (float*)workspace;
+    float* bslab = slab + (long long)NU_SKINNY_BLOCKS * NO * K;
+#define NU_ARGS dy, ldy, H, ldh, P, Ws, ldw, dH, lddh, relu_mask, accumulate, slab, bslab
+    if (K == 128) {
+        switch (NO) {
+            case 1: hipLaunchKernelGGL(skinny_bwd128_kernel<1>, dim3(blocks), dim3(128), 0, stream, NU_ARGS); break;
+            case 3: hipLaunchKernelGGL(skinny_bwd128_kernel<3>, dim3(blocks), dim3(128), 0, stream, NU_ARGS); break;
+            default: return NU_ERR_ARG;
+        }
+    } else if (K == 256) {
+        switch (NO) {
+            case 1: hipLaunchKernelGGL((skinny_bwd_kernel<1, 1>), dim3(blocks), dim3(256), 0, stream, NU_ARGS); break;
+            case 3: hipLaunchKernelGGL((skinny_bwd_kernel<3, 1>), dim3(blocks), dim3(256), 0, stream, NU_ARGS); break;
+            default: return NU_ERR_ARG;
+        }
+    } else if (K == 1024) {
+        switch (NO) {
+            case 6: hipLaunchKernelGGL((skinny_bwd_kernel<6, 4>), dim3(blocks), dim3(256), 0, stream, NU_ARGS); break;
+            default: return NU_ERR_ARG;
+        }
+    } else {
+        return NU_ERR_ARG;
+    }
+#undef NU_ARGS
+    int rc = nu_launch_status();
+    if (rc) return rc;
+    // slab is [blocks][NO][K]: view as S=blocks slabs of an NO x K matrix with exact strides
+    rc = nu_slab_reduce_strided_launch(slab, blocks, NO, K, NO, K, dWs, lddw, 1.0f, 0, stream);
+    if (rc) return rc;
+    if (db) rc = nu_slab_reduce_strided_launch(bslab, blocks, NO, 1, NO, 1, db, 1, 1.0f, 0, stream);
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// column sums (deterministic two-stage):  out[c] (+)= sum_p A[p, c],  c < ncols
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ A, int lda, int P, int ncols,
+                                                             float* __restrict__ part) {
+    const int c = blockIdx.y * 256 + threadIdx.x;
+    int rows_per = (P + gridDim.x - 1) / gridDim.x;
+    const int p0 = blockIdx.x * rows_per;
+    int p1 = p0 + rows_per;
+    p1 = p1 < P ? p1 : P;
+    if (c >= ncols) return;
+    float s = 0.f;
+    for (int p = p0; p < p1; ++p) s += A[(long long)p * lda + c];
+    part[(long long)blockIdx.x * ncols + c] = s;
+}
+
+#define NU_COLSUM_BLOCKS 512
+extern "C" long long nu_colsum_workspace_bytes(int ncols) { return (long long)NU_COLSUM_BLOCKS * ncols * sizeof(float); }
+extern "C" int nu_colsum(const float* A, int lda, int P, int ncols, float* out, int accumulate, void* workspace,
+                         long long workspace_bytes, hipStream_t stream) {
+    if (P <= 0 || ncols <= 0) return NU_ERR_ARG;
+    if (workspace_bytes < nu_colsum_workspace_bytes(ncols)) return NU_ERR_WORKSPACE;
+    int blocks = nu_cdiv(P, 128);
+    blocks = blocks < NU_COLSUM_BLOCKS ? blocks : NU_COLSUM_BLOCKS;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(blocks, nu_cdiv(ncols, 256)), dim3(256), 0, stream, A, lda, P, ncols,
+                       (float*)workspace);
+    int rc = nu_launch_status();
+    if (rc) return rc;
+    return nu_slab_reduce_strided_launch((const float*)workspace, blocks, 1, ncols, 1, ncols, out, ncols, 1.0f,
+                                         accumulate, stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// D[p, k] = w[k] * sp'(H[p, k])   -- seed of the SDF reverse sweep (delta_7 = W8[sdf row] * softplus'(a_7))
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rowscale_dsp_kernel(const float* __restrict__ H, int ldh, long long P, int K,
+                                                           const float* __restrict__ w, float* __restrict__ D, int ldd) {
+    const int kq = K >> 2;
+    const long long total = P * kq;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long p = i / kq;
+        const int c = (int)(i - p * kq) * 4;
+        const f32x4 h = *reinterpret_cast<const f32x4*>(H + p * ldh + c);
+        const f32x4 ww = *reinterpret_cast<const f32x4*>(w + c);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = ww[e] * nu_softplus100_grad_from_h(h[e]);
+        *reinterpret_cast<f32x4*>(D + p * ldd + c) = o;
+    }
+}
+extern "C" int nu_rowscale_dsp(const float* H, int ldh, int P, int K, const float* w, float* D, int ldd,
+                               hipStream_t stream) {
+    if (P <= 0) return NU_OK;
+    if ((K & 3) || (ldh & 3) || (ldd & 3)) return NU_ERR_ARG;
+    const long long total = (long long)P * (K >> 2);
+    long long blocks = nu_cdivl(total, 256);
+    blocks = blocks < 8192 ? blocks : 8192;
+    hipLaunchKernelGGL(rowscale_dsp_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, H, ldh, (long long)P, K, w, D, ldd);
+    return nu_launch_status();
+}

@@ -1,0 +1,763 @@
+"""Host-side orchestration of the stage-1 hot path over the C ABI of libnunerf.so.
+
+This is the Python counterpart of the reference's Python host code (network/renderer_zerothick.py,
+network/field.py): it owns the packed-weight tables and sequences the HIP kernels -- fp32-MFMA GEMM
+sweeps for the three MLP stacks (forward, SDF input-gradient, backward and the second-order sweeps),
+encoders, NeuS alpha, shading combine and the composite.  No arithmetic of the path happens in torch:
+torch only provides device memory and the current stream.
+
+Buffer conventions (all fp32 row-major; leading dims are multiples of 32 with zero/finite padding):
+  SDF net (P inner points)                                   reference: field.py:133-170
+    E  [P, 64]   embedding (39) | 0                U4 [P,256]  h4 (217) | embedding (39)
+    H1..H3, H5..H8 [P,256] post-softplus           YX [P,288]  sdf | feat (256) | x (3) | 0
+    D0..D7 [P,256] delta_l = gbar_{l+1} * sp'(a_l)  (reverse sweep producing n = d sdf / d x)
+    Q*, C*  tangent sweep / second-order terms (Appendix B of SURVEY.md)
+  NeRF++ (P outer points)                                    reference: field.py:265-289
+    E4 [P,96], N1..N4,N6..N8 [P,256], U5 [P,352] = h5 | emb(84) | 0, V [P,288] = feature | view(27) | 0
+  shading stack                                              reference: field.py:684-777
+    materials: YX -> M1 [P,1024] -> M2 -> M3 -> Mraw [P,8]  (4 predictors batched / grouped)
+    lights: OLin [3P+R, 96], ILin [2P,128], IWin [P,96], RLin [P,96] -> 3 hidden [rows,256] -> raw heads
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+c_int, c_ll, c_f, c_p = ctypes.c_int, ctypes.c_longlong, ctypes.c_float, ctypes.c_void_p
+
+EPI_BIAS_NONE, EPI_BIAS_RELU, EPI_BIAS_SOFTPLUS, EPI_MUL_DRELU, EPI_MUL_DSP, EPI_Q_SP, EPI_B_SP, EPI_PLAIN, EPI_B_RELU = range(9)
+
+
+class GemmNT(ctypes.Structure):
+    _fields_ = [("A", c_p), ("lda", c_int), ("B", c_p), ("ldb", c_int), ("M", c_int), ("N", c_int), ("K", c_int),
+                ("C", c_p), ("ldc", c_int), ("C2", c_p), ("ldc2", c_int), ("bias", c_p), ("H", c_p), ("ldh", c_int),
+                ("D", c_p), ("ldd", c_int), ("Cadd", c_p), ("ldadd", c_int), ("zero_to", c_int), ("act_cols", c_int),
+                ("alpha", c_f), ("groups", c_int), ("sA", c_ll), ("sB", c_ll), ("sC", c_ll), ("sC2", c_ll),
+                ("sBias", c_ll), ("sH", c_ll), ("sD", c_ll), ("sCadd", c_ll), ("epi", c_int)]
+
+
+class GemmTN(ctypes.Structure):
+    _fields_ = [("A0", c_p), ("lda0", c_int), ("B0", c_p), ("ldb0", c_int), ("A1", c_p), ("lda1", c_int),
+                ("B1", c_p), ("ldb1", c_int), ("P", c_int), ("N1", c_int), ("N2", c_int), ("slab", c_p),
+                ("bias_slab", c_p), ("S", c_int), ("groups", c_int), ("sA0", c_ll), ("sB0", c_ll), ("sA1", c_ll),
+                ("sB1", c_ll), ("sSlab", c_ll), ("sBiasSlab", c_ll)]
+
+
+class PackDesc(ctypes.Structure):
+    _fields_ = [("v", c_p), ("g", c_p), ("colmap", c_p), ("Wp", c_p), ("WpT", c_p), ("dWp", c_p), ("dv_off", c_ll),
+                ("dg_off", c_ll), ("bias", c_p), ("bias_p", c_p), ("scale", c_f), ("N", c_int), ("K", c_int),
+                ("Kp", c_int), ("ldT", c_int), ("ldd", c_int), ("row_begin", c_int), ("col_off", c_int)]
+
+
+def rup(a, b):
+    return (a + b - 1) // b * b
+
+
+def addr(t, off=0):
+    """Device address of element `off` (in floats/ints of 4 bytes) of tensor t; 0 for None."""
+    if t is None:
+        return 0
+    return t.data_ptr() + 4 * off
+
+
+class _Layer:
+    """One packed linear layer (python record; the device table is built from these)."""
+
+    def __init__(self, name, v, g, b, N, K, Kp, *, scale=1.0, colmap=None, col_off=0, v_row0=0):
+        self.name, self.v, self.g, self.b = name, v, g, b
+        self.N, self.K, self.Kp, self.scale, self.colmap, self.col_off, self.v_row0 = N, K, Kp, scale, colmap, col_off, v_row0
+        self.Wp = self.WpT = self.dWp = self.bias_p = None  # (tensor, element offset)
+        self.ldT = self.ldd = 0
+        self.dv_off = self.dg_off = self.db_off = -1
+
+
+class Stage1Engine:
+    """Packed weights + kernel sequencing for NeROShapeRenderer's hot path on one GPU."""
+
+    def __init__(self, params, device, cfg):
+        self.lib = L.load()
+        self.dev = torch.device(device)
+        if self.dev.type != "cuda":
+            raise L.NuNerfLibraryError("Stage1Engine needs a CUDA(HIP) device: there is no CPU fallback")
+        self.cfg = cfg
+        self.p = params  # dict name -> Parameter/Tensor on device
+        self.exp_max = float(cfg.get('light_exp_max', 3.0))
+        self.sphere_direction = bool(cfg.get('sphere_direction', False))
+        if self.sphere_direction:
+            raise NotImplementedError("sphere_direction=True (144-d outer_light) is a later-round row")
+        lib = self.lib
+        for fn in ("nu_wgrad_workspace_bytes", "nu_skinny_bwd_workspace_bytes", "nu_colsum_workspace_bytes",
+                   "nu_gemm_tn_workspace_bytes"):
+            getattr(lib, fn).restype = c_ll
+        assert lib.nu_pack_desc_size() == ctypes.sizeof(PackDesc), "PackDesc ABI mismatch"
+        self._ws = None
+        self._ptr_sig = None
+        self._build_layers()
+
+    # ------------------------------------------------------------------ buffers
+    def zeros(self, *shape, dtype=torch.float32):
+        return torch.zeros(*shape, dtype=dtype, device=self.dev)
+
+    def empty(self, *shape, dtype=torch.float32):
+        return torch.empty(*shape, dtype=dtype, device=self.dev)
+
+    def workspace(self, nbytes):
+        n = (int(nbytes) + 3) // 4
+        if self._ws is None or self._ws.numel() < n:
+            self._ws = torch.empty(max(n, 1 << 20), dtype=torch.float32, device=self.dev)
+        return self._ws
+
+    def stream(self):
+        return c_p(torch.cuda.current_stream(self.dev).cuda_stream)
+
+    # ------------------------------------------------------------------ layer tables
+    def _build_layers(self):
+        p = self.p
+        z = self.zeros
+        layers = []
+        self.grad_views = {}   # param name -> (offset, shape)
+        self._goff = 0
+
+        def galloc(n):
+            o = self._goff
+            self._goff += n
+            return o
+
+        def reg(name, off):
+            self.grad_views[name] = (off, tuple(p[name].shape))
+
+        # ---- SDF network ----
+        sdf = []
+        for l in range(9):
+            pre = f'sdf_network.lin{l}'
+            v = p[pre + '.weight_v']
+            N, K = v.shape
+            Kp = 64 if l == 0 else 256
+            lay = _Layer(pre, v, p[pre + '.weight_g'], p[pre + '.bias'], N, K, Kp,
+                         scale=(1.0 / math.sqrt(2.0)) if l == 4 else 1.0)
+            lay.Wp = (z(rup(N, 128), Kp), 0)
+            ldT = 288 if l == 8 else rup(N, 32)
+            lay.WpT, lay.ldT = (z(rup(Kp, 128), ldT), 0), ldT
+            lay.dWp, lay.ldd = (z(N, Kp), 0), Kp
+            lay.dv_off, lay.dg_off, lay.db_off = galloc(N * K), galloc(N), galloc(N)
+            reg(pre + '.weight_v', lay.dv_off); reg(pre + '.weight_g', lay.dg_off); reg(pre + '.bias', lay.db_off)
+            sdf.append(lay)
+        self.sdf = sdf
+        layers += sdf
+        self.var_off = galloc(1)
+        reg('deviation_network.variance', self.var_off)
+
+        # ---- NeRF++ ----
+        nerf = []
+        cm5 = np.concatenate([256 + np.arange(84), np.arange(256)]).astype(np.int32)   # [emb(84), h(256)] -> h | emb
+        self._colmaps = {'n5': torch.from_numpy(cm5).to(self.dev)}
+
+        def plain(name, Kp, colmap=None, NT_rows=True):
+            w = p[name + '.weight']
+            N, K = w.shape
+            lay = _Layer(name, w, None, p[name + '.bias'], N, K, Kp, colmap=colmap)
+            lay.Wp = (z(rup(N, 128), Kp), 0)
+            lay.WpT, lay.ldT = (z(rup(Kp, 128), rup(N, 32)), 0), rup(N, 32)
+            lay.dWp, lay.ldd = (z(N, Kp), 0), Kp
+            lay.dv_off, lay.db_off = galloc(N * K), galloc(N)
+            reg(name + '.weight', lay.dv_off); reg(name + '.bias', lay.db_off)
+            return lay
+        for i in range(8):
+            Kp = 96 if i == 0 else (352 if i == 5 else 256)
+            nerf.append(plain(f'outer_nerf.pts_linears.{i}', Kp, self._colmaps['n5'] if i == 5 else None))
+        self.nerf = nerf
+        self.nerf_feat = plain('outer_nerf.feature_linear', 256)
+        self.nerf_alpha = plain('outer_nerf.alpha_linear', 256)
+        self.nerf_view = plain('outer_nerf.views_linears.0', 288)
+        self.nerf_rgb = plain('outer_nerf.rgb_linear', 128)
+        layers += nerf + [self.nerf_feat, self.nerf_alpha, self.nerf_view, self.nerf_rgb]
+
+        # ---- shading: material predictors (batched) ----
+        mats = ['metallic_predictor', 'roughness_predictor', 'albedo_predictor', 'transmisstion_weight']
+        cmM = np.concatenate([1 + np.arange(256), 257 + np.arange(3)]).astype(np.int32)   # [feat, x] -> YX columns
+        self._colmaps['m0'] = torch.from_numpy(cmM).to(self.dev)
+        self.WpM0, self.WpTM0, self.bM0, self.dWpM0 = z(1024, 288), z(384, 1024), z(1024), z(1024, 288)
+        self.WpM = [None, z(4, 256, 256), z(4, 256, 256)]
+        self.WpTM = [None, z(4, 256, 256), z(4, 256, 256)]
+        self.bM = [None, z(4, 256), z(4, 256)]
+        self.dWpM = [None, z(4, 256, 256), z(4, 256, 256)]
+        self.Ws6, self.b6, self.dWs6 = z(6, 1024), z(8), z(6, 1024)
+        self.mat_layers = []
+        db0 = galloc(1024)
+        db12 = [None, galloc(1024), galloc(1024)]
+        db6 = galloc(6)
+        head_row = [0, 1, 2, 5]
+        self.mat_db = (db0, db12, db6)
+        for i, name in enumerate(mats):
+            pre = f'color_network.{name}'
+            for j, idx in enumerate((0, 2, 4, 6)):
+                q = f'{pre}.{idx}'
+                v = p[q + '.weight_v']
+                N, K = v.shape
+                if j == 0:
+                    lay = _Layer(q, v, p[q + '.weight_g'], p[q + '.bias'], N, K, 288, colmap=self._colmaps['m0'])
+                    lay.Wp = (self.WpM0, i * 256 * 288)
+                    lay.WpT, lay.ldT = (self.WpTM0, i * 256), 1024
+                    lay.dWp, lay.ldd = (self.dWpM0, i * 256 * 288), 288
+                    lay.bias_p = (self.bM0, i * 256)
+                    lay.db_off = db0 + i * 256
+                elif j < 3:
+                    lay = _Layer(q, v, p[q + '.weight_g'], p[q + '.bias'], N, K, 256)
+                    lay.Wp = (self.WpM[j], i * 65536)
+                    lay.WpT, lay.ldT = (self.WpTM[j], i * 65536), 256
+                    lay.dWp, lay.ldd = (self.dWpM[j], i * 65536), 256
+                    lay.bias_p = (self.bM[j], i * 256)
+                    lay.db_off = db12[j] + i * 256
+                else:
+                    lay = _Layer(q, v, p[q + '.weight_g'], p[q + '.bias'], N, K, 1024, col_off=i * 256)
+                    lay.Wp = (self.Ws6, head_row[i] * 1024)
+                    lay.dWp, lay.ldd = (self.dWs6, head_row[i] * 1024), 1024
+                    lay.bias_p = (self.b6, head_row[i])
+                    lay.db_off = db6 + head_row[i]
+                lay.dv_off, lay.dg_off = galloc(N * K), galloc(N)
+                reg(q + '.weight_v', lay.dv_off); reg(q + '.weight_g', lay.dg_off); reg(q + '.bias', lay.db_off)
+                self.mat_layers.append(lay)
+        layers += self.mat_layers
+
+        # ---- shading: light predictors ----
+        def predictor(name, Kp0):
+            pre = f'color_network.{name}'
+            out = []
+            for j, idx in enumerate((0, 2, 4, 6)):
+                q = f'{pre}.{idx}'
+                v = p[q + '.weight_v']
+                N, K = v.shape
+                Kp = Kp0 if j == 0 else 256
+                lay = _Layer(q, v, p[q + '.weight_g'], p[q + '.bias'], N, K, Kp)
+                lay.Wp = (z(rup(N, 128) if j < 3 else N, Kp), 0)
+                if j < 3:
+                    lay.WpT, lay.ldT = (z(rup(Kp, 128), 256), 0), 256
+                lay.dWp, lay.ldd = (z(N, Kp), 0), Kp
+                lay.dv_off, lay.dg_off, lay.db_off = galloc(N * K), galloc(N), galloc(N)
+                reg(q + '.weight_v', lay.dv_off); reg(q + '.weight_g', lay.dg_off); reg(q + '.bias', lay.db_off)
+                out.append(lay)
+            return out
+        self.outer_light = predictor('outer_light', 96)
+        self.inner_light = predictor('inner_light', 128)
+        self.inner_weight = predictor('inner_weight', 96)
+        self.refrac_light = predictor('refrac_light', 96)
+        layers += self.outer_light + self.inner_light + self.inner_weight + self.refrac_light
+        self.layers = layers
+        self.n_grad = self._goff
+        self.lut = p['color_network.FG_LUT']
+        # parameters that never receive a gradient in stage 1: color_network.iors.*, infinity_far_bkgr.*
+        self._desc_dev = None
+
+    def _signature(self):
+        return tuple(l.v.data_ptr() for l in self.layers[:4]) + (self.layers[-1].v.data_ptr(),)
+
+    def _upload_descs(self):
+        descs = (PackDesc * len(self.layers))()
+        row = 0
+        for i, l in enumerate(self.layers):
+            d = descs[i]
+            d.v = addr(l.v, l.v_row0 * l.K)
+            d.g = addr(l.g, l.v_row0) if l.g is not None else 0
+            d.colmap = addr(l.colmap) if l.colmap is not None else 0
+            d.Wp = addr(*l.Wp)
+            d.WpT = addr(*l.WpT) if l.WpT is not None else 0
+            d.dWp = addr(*l.dWp)
+            d.dv_off, d.dg_off = l.dv_off, l.dg_off
+            d.bias = addr(l.b) if (l.bias_p is not None) else 0
+            d.bias_p = addr(*l.bias_p) if l.bias_p is not None else 0
+            d.scale, d.N, d.K, d.Kp, d.ldT, d.ldd, d.row_begin, d.col_off = l.scale, l.N, l.K, l.Kp, l.ldT, l.ldd, row, l.col_off
+            row += l.N
+        self.total_rows = row
+        raw = bytes(descs)
+        host = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
+        self._desc_dev = host.to(self.dev)
+        self._ptr_sig = self._signature()
+
+    def pack(self):
+        """Fold weight-norm, pad/permute and transpose every layer's weight: one launch."""
+        if self._desc_dev is None or self._ptr_sig != self._signature():
+            self._upload_descs()
+        L.check(self.lib.nu_pack_layers(c_p(self._desc_dev.data_ptr()), len(self.layers), self.total_rows, self.stream()),
+                "nu_pack_layers")
+
+    def unpack_grads(self, flat):
+        L.check(self.lib.nu_unpack_grads(c_p(self._desc_dev.data_ptr()), len(self.layers), self.total_rows,
+                                         c_p(flat.data_ptr()), self.stream()), "nu_unpack_grads")
+
+    # ------------------------------------------------------------------ raw launches
+    def nt(self, A, lda, B, ldb, M, N, K, C, ldc, epi, *, C2=0, ldc2=0, bias=0, H=0, ldh=0, D=0, ldd=0, Cadd=0,
+           ldadd=0, zero_to=0, act_cols=0, alpha=1.0, groups=1, sA=0, sB=0, sC=0, sC2=0, sBias=0, sH=0, sD=0, sCadd=0):
+        if M <= 0:
+            return
+        g = GemmNT(A, lda, B, ldb, M, N, K, C, ldc, C2, ldc2, bias, H, ldh, D, ldd, Cadd, ldadd, zero_to, act_cols,
+                   alpha, groups, sA, sB, sC, sC2, sBias, sH, sD, sCadd, epi)
+        L.check(self.lib.nu_gemm_nt_ex(ctypes.byref(g), self.stream()), "nu_gemm_nt_ex")
+
+    def wgrad(self, A0, lda0, B0, ldb0, P, N1, N2, dW, ldw, db, *, A1=0, lda1=0, B1=0, ldb1=0, groups=1, sA0=0, sB0=0,
+              sA1=0, sB1=0, sW=0, sDb=0):
+        tiles = ((N1 + 127) // 128) * ((N2 + 127) // 128) * groups
+        S = max(1, min((P + 255) // 256, max(1, 1024 // tiles)))
+        nbytes = self.lib.nu_wgrad_workspace_bytes(N1, N2, S, groups)
+        ws = self.workspace(nbytes)
+        g = GemmTN(A0, lda0, B0, ldb0, A1, lda1, B1, ldb1, P, N1, N2, 0, 0, S, groups, sA0, sB0, sA1, sB1, 0, 0)
+        L.check(self.lib.nu_wgrad(ctypes.byref(g), c_p(dW), ldw, c_ll(sW), c_p(db), c_ll(sDb), c_p(ws.data_ptr()),
+                                  c_ll(ws.numel() * 4), self.stream()), "nu_wgrad")
+
+    def skinny_fwd(self, H, ldh, P, K, Ws, ldw, b, NO, out, ldo):
+        L.check(self.lib.nu_skinny_fwd(c_p(H), ldh, P, K, c_p(Ws), ldw, c_p(b), NO, c_p(out), ldo, self.stream()),
+                "nu_skinny_fwd")
+
+    def skinny_bwd(self, dy, ldy, H, ldh, P, K, Ws, ldw, NO, dH, lddh, relu_mask, accumulate, dWs, lddw, db):
+        nbytes = self.lib.nu_skinny_bwd_workspace_bytes(K, NO)
+        ws = self.workspace(nbytes)
+        L.check(self.lib.nu_skinny_bwd(c_p(dy), ldy, c_p(H), ldh, P, K, c_p(Ws), ldw, NO, c_p(dH), lddh, relu_mask,
+                                       accumulate, c_p(dWs), lddw, c_p(db), c_p(ws.data_ptr()), c_ll(ws.numel() * 4),
+                                       self.stream()), "nu_skinny_bwd")
+
+    def colsum(self, A, lda, P, ncols, out, accumulate):
+        ws = self.workspace(self.lib.nu_colsum_workspace_bytes(ncols))
+        L.check(self.lib.nu_colsum(c_p(A), lda, P, ncols, c_p(out), accumulate, c_p(ws.data_ptr()), c_ll(ws.numel() * 4),
+                                   self.stream()), "nu_colsum")
+
+    # ------------------------------------------------------------------ SDF network
+    def sdf_forward(self, X, x_ld, P, *, keep=True, want_feat=True):
+        """SDF MLP forward on P points (X: device address of [P, x_ld] rows whose first 3 floats are x).
+        keep=False runs the no-grad sampler chain with two ping-pong buffers and only the sdf column.
+        Returns a dict of activation tensors."""
+        lib, S = self.lib, self.stream()
+        e = self.empty
+        a = {'P': P}
+        a['E'] = e(P, 64)
+        a['U4'] = e(P, 256)
+        a['YX'] = e(P, 288) if want_feat else None
+        L.check(lib.nu_sdf_embed(c_p(X), x_ld, P, c_p(addr(a['E'])), c_p(addr(a['U4'])),
+                                 c_p(addr(a['YX'])), S), "nu_sdf_embed")
+        ls = self.sdf
+        if keep:
+            H = [None] + [e(P, 256) for _ in range(3)] + [a['U4']] + [e(P, 256) for _ in range(4)]
+        else:
+            t0, t1 = e(P, 256), e(P, 256)
+            H = [None, t0, t1, t0, a['U4'], t0, t1, t0, t1]
+        a['H'] = H
+        src, lds, K = a['E'], 64, 64
+        for l in range(8):
+            N = ls[l].N
+            self.nt(addr(src), lds, addr(*ls[l].Wp), ls[l].Kp, P, N, K, addr(H[l + 1]), 256, EPI_BIAS_SOFTPLUS,
+                    bias=addr(ls[l].b), zero_to=N)
+            src, lds, K = H[l + 1], 256, 256
+        # last layer: row 0 = sdf (skinny), rows 1..256 = feature (N = 256 GEMM)
+        if want_feat:
+            self.skinny_fwd(addr(H[8]), 256, P, 256, addr(*ls[8].Wp), 256, addr(ls[8].b), 1, addr(a['YX']), 288)
+            self.nt(addr(H[8]), 256, addr(ls[8].Wp[0], 256), 256, P, 256, 256, addr(a['YX'], 1), 288, EPI_BIAS_NONE,
+                    bias=addr(ls[8].b, 1))
+            a['sdf'] = None
+        else:
+            a['sdf'] = e(P)
+            self.skinny_fwd(addr(H[8]), 256, P, 256, addr(*ls[8].Wp), 256, addr(ls[8].b), 1, addr(a['sdf']), 1)
+        return a
+
+    def sdf_normal(self, a):
+        """Reverse sweep: n = d sdf / d x  (field.py:158-170), keeping delta_l for the second-order backward."""
+        lib, S, P, ls, H = self.lib, self.stream(), a['P'], self.sdf, a['H']
+        e = self.empty
+        D = [e(P, 256) for _ in range(8)]
+        a['D'] = D
+        L.check(lib.nu_rowscale_dsp(c_p(addr(H[8])), 256, P, 256, c_p(addr(*ls[8].Wp)), c_p(addr(D[7])), 256, S),
+                "nu_rowscale_dsp")
+        for l in range(7, 0, -1):
+            # G_{u_l} = D_l . Wp_l ; delta_{l-1} = G[:, :N_{l-1}] * sp'(H_l)
+            Kred = rup(ls[l].N, 32)                    # reduction over layer l's outputs (217 -> 224 at l = 3)
+            Nout = ls[l - 1].N                          # columns that carry an activation derivative
+            if l == 4:
+                # columns 217..255 of G_{u_4} are the skip gradient w.r.t. the embedding: written plain
+                self.nt(addr(D[l]), 256, addr(*ls[l].WpT), ls[l].ldT, P, 256, Kred, addr(D[l - 1]), 256, EPI_MUL_DSP,
+                        H=addr(H[l]), ldh=256, act_cols=217)
+            else:
+                self.nt(addr(D[l]), 256, addr(*ls[l].WpT), ls[l].ldT, P, Nout, Kred, addr(D[l - 1]), 256, EPI_MUL_DSP,
+                        H=addr(H[l]), ldh=256, zero_to=256 if l != 4 else 0)
+        G0 = e(P, 64)
+        self.nt(addr(D[0]), 256, addr(*ls[0].WpT), ls[0].ldT, P, 39, 256, addr(G0), 64, EPI_PLAIN, zero_to=64)
+        a['n'] = e(P, 3)
+        L.check(lib.nu_embed_jt(c_p(addr(a['E'])), c_p(addr(G0)), 64, c_p(addr(D[3], 217)), 256, P, c_p(addr(a['n'])), S),
+                "nu_embed_jt")
+        return a['n']
+
+    def sdf_backward(self, a, dYX, nbar, flat):
+        """Backward of (y, n) w.r.t. the SDF parameters given dYX [P,288] (cols 0..256 = d y) and nbar [P,3]
+        (may be None: first-order only).  Writes packed weight grads + bias grads (into `flat`)."""
+        lib, S, P, ls, H, E = self.lib, self.stream(), a['P'], self.sdf, a['H'], a['E']
+        e = self.empty
+        second = nbar is not None
+        Cb = [None] * 8
+        Q = [None] * 9
+        if second:
+            D = a['D']
+            Q[0] = e(P, 64)
+            Q[4] = e(P, 256)
+            L.check(lib.nu_embed_j(c_p(addr(E)), c_p(addr(nbar)), P, c_p(addr(Q[0])), c_p(addr(Q[4])), S), "nu_embed_j")
+            src, lds, K = Q[0], 64, 64
+            for l in range(8):
+                N = ls[l].N
+                Cb[l] = e(P, 256)
+                if l + 1 != 4:
+                    Q[l + 1] = e(P, 256)
+                self.nt(addr(src), lds, addr(*ls[l].Wp), ls[l].Kp, P, N, K, addr(Q[l + 1]), 256, EPI_Q_SP,
+                        C2=addr(Cb[l]), ldc2=256, H=addr(H[l + 1]), ldh=256, D=addr(D[l]), ldd=256,
+                        zero_to=N if l == 3 else 256)
+                src, lds, K = Q[l + 1], 256, 256
+        # B sweep: abar_7 = (dYX . W8) * sp'(H8) + C7 ...
+        A = [None] * 8
+        for l in range(7, -1, -1):
+            if l == 7:
+                srcA, lda, K, WT, ldT = dYX, 288, 288, ls[8].WpT, ls[8].ldT
+            else:
+                srcA, lda, K, WT, ldT = A[l + 1], 256, rup(ls[l + 1].N, 32), ls[l + 1].WpT, ls[l + 1].ldT
+            N = ls[l].N
+            A[l] = Cb[l] if second else e(P, 256)
+            self.nt(addr(srcA), lda, addr(*WT), ldT, P, N, K, addr(A[l]), 256, EPI_B_SP if second else EPI_MUL_DSP,
+                    H=addr(H[l + 1]), ldh=256, Cadd=addr(Cb[l]) if second else 0, ldadd=256, zero_to=256)
+        # weight gradients
+        for l in range(8):
+            u, ldu = (E, 64) if l == 0 else (H[l], 256)
+            if second:
+                self.wgrad(addr(A[l]), 256, addr(u), ldu, P, ls[l].N, ls[l].Kp, addr(*ls[l].dWp), ls[l].ldd,
+                           addr(flat, ls[l].db_off), A1=addr(a['D'][l]), lda1=256, B1=addr(Q[l]), ldb1=64 if l == 0 else 256)
+            else:
+                self.wgrad(addr(A[l]), 256, addr(u), ldu, P, ls[l].N, ls[l].Kp, addr(*ls[l].dWp), ls[l].ldd,
+                           addr(flat, ls[l].db_off))
+        self.wgrad(addr(dYX), 288, addr(H[8]), 256, P, 257, 256, addr(*ls[8].dWp), 256, addr(flat, ls[8].db_off))
+        if second:
+            # d W8[sdf row] += sum_p q_8   (the reverse sweep starts from W8's sdf row)
+            self.colsum(addr(Q[8]), 256, P, 256, addr(*ls[8].dWp), 1)
+
+    # ------------------------------------------------------------------ generic ReLU stacks
+    def relu_stack_fwd(self, layers, X, ldx, rows):
+        """3 hidden ReLU layers (make_predictor, field.py:371-408); returns hidden activations [H1,H2,H3]."""
+        Hs = []
+        src, lds = X, ldx
+        for j in range(3):
+            lay = layers[j]
+            Hn = self.empty(rows, 256)
+            self.nt(addr(src), lds, addr(*lay.Wp), lay.Kp, rows, 256, lay.Kp, addr(Hn), 256, EPI_BIAS_RELU, bias=addr(lay.b))
+            Hs.append(Hn)
+            src, lds = Hn, 256
+        return Hs
+
+    def relu_stack_bwd(self, layers, X, ldx, rows, Hs, dH3, flat, dX=None, lddx=0, dx_cols=0):
+        """dH3 = gradient w.r.t. post-ReLU H3 already masked by relu'(H3) (i.e. d pre-activation of layer 2)."""
+        dA = dH3
+        for j in (2, 1, 0):
+            lay = layers[j]
+            u, ldu = (X, ldx) if j == 0 else (Hs[j - 1], 256)
+            self.wgrad(addr(dA), 256, addr(u), ldu, rows, 256, lay.Kp, addr(*lay.dWp), lay.ldd, addr(flat, lay.db_off))
+            if j > 0:
+                nxt = self.empty(rows, 256)
+                self.nt(addr(dA), 256, addr(*lay.WpT), lay.ldT, rows, 256, 256, addr(nxt), 256, EPI_MUL_DRELU,
+                        H=addr(Hs[j - 1]), ldh=256)
+                dA = nxt
+            elif dX is not None:
+                self.nt(addr(dA), 256, addr(*lay.WpT), lay.ldT, rows, dx_cols, 256, addr(dX), lddx, EPI_PLAIN)
+
+    # ------------------------------------------------------------------ shading stack
+    def shading_forward(self, a, pt, idx, P, color_rm, extra_dirs=None):
+        """Materials -> encodings -> 4 light predictors -> combine (field.py:684-777).
+        a: SDF activations (YX, E, n).  extra_dirs [R,3]: per-ray directions whose mirror query IDE(d,0)
+        rides along the outer_light batch (colour_spec, renderer_zerothick.py:780-781)."""
+        lib, S = self.lib, self.stream()
+        e = self.empty
+        s = {'P': P}
+        YX = a['YX']
+        # materials: layer 0 batched (N=1024), layers 1-2 grouped x4, block-diagonal 6-wide head
+        M1, M2, M3 = e(P, 1024), e(P, 1024), e(P, 1024)
+        self.nt(addr(YX), 288, addr(self.WpM0), 288, P, 1024, 288, addr(M1), 1024, EPI_BIAS_RELU, bias=addr(self.bM0))
+        for j, (src, dst) in ((1, (M1, M2)), (2, (M2, M3))):
+            self.nt(addr(src), 1024, addr(self.WpM[j]), 256, P, 256, 256, addr(dst), 1024, EPI_BIAS_RELU,
+                    bias=addr(self.bM[j]), groups=4, sA=256, sB=65536, sC=256, sBias=256)
+        Mraw = e(P, 8)
+        self.skinny_fwd(addr(M3), 1024, P, 1024, addr(self.Ws6), 1024, addr(self.b6), 6, addr(Mraw), 8)
+        s.update(M1=M1, M2=M2, M3=M3, Mraw=Mraw)
+        # encodings
+        R = 0 if extra_dirs is None else extra_dirs.shape[0]
+        rows_ol = 3 * P + R
+        OLin, ILin, IWin, RLin, SD = e(rows_ol, 96), e(2 * P, 128), e(P, 96), e(P, 96), e(P, 8)
+        L.check(lib.nu_shade_encode_fwd(c_p(addr(a['n'])), c_p(addr(pt)), 8, c_p(addr(a['E'])), c_p(addr(Mraw)), 8, P,
+                                        c_p(addr(OLin)), c_p(addr(ILin)), c_p(addr(IWin)), c_p(addr(RLin)),
+                                        c_p(addr(SD)), S), "nu_shade_encode_fwd")
+        if R:
+            L.check(lib.nu_ide(c_p(addr(extra_dirs)), c_p(0), R, c_p(addr(OLin, 3 * P * 96)), 96, S), "nu_ide")
+        s.update(OLin=OLin, ILin=ILin, IWin=IWin, RLin=RLin, SD=SD, R=R, rows_ol=rows_ol)
+        # light predictors
+        s['OLh'] = self.relu_stack_fwd(self.outer_light, OLin, 96, rows_ol)
+        s['ILh'] = self.relu_stack_fwd(self.inner_light, ILin, 128, 2 * P)
+        s['IWh'] = self.relu_stack_fwd(self.inner_weight, IWin, 96, P)
+        s['RLh'] = self.relu_stack_fwd(self.refrac_light, RLin, 96, P)
+        OLo, ILo, IWo, RLo = e(rows_ol, 4), e(2 * P, 4), e(P), e(P, 4)
+        for lay, Hs, out, rows, no, ldo in ((self.outer_light[3], s['OLh'], OLo, rows_ol, 3, 4),
+                                            (self.inner_light[3], s['ILh'], ILo, 2 * P, 3, 4),
+                                            (self.inner_weight[3], s['IWh'], IWo, P, 1, 1),
+                                            (self.refrac_light[3], s['RLh'], RLo, P, 3, 4)):
+            self.skinny_fwd(addr(Hs[2]), 256, rows, 256, addr(*lay.Wp), 256, addr(lay.b), no, addr(out), ldo)
+        s.update(OLo=OLo, ILo=ILo, IWo=IWo, RLo=RLo)
+        s['aux'] = e(P, 4)
+        L.check(lib.nu_shade_combine_fwd(c_p(addr(Mraw)), 8, c_p(addr(OLo)), c_p(addr(ILo)), c_p(addr(IWo)),
+                                         c_p(addr(RLo)), c_p(addr(SD)), c_p(addr(self.lut)), c_p(addr(idx)), P,
+                                         c_f(self.exp_max), c_p(addr(color_rm)), c_p(addr(s['aux'])), S),
+                "nu_shade_combine_fwd")
+        return s
+
+    def shading_backward(self, a, s, pt, idx, dcolor_rm, flat, d_spec_raw=None, d_occ_raw=None):
+        """Returns (dYX [P,288] with feature/x columns filled, dn_shade [P,3])."""
+        lib, S, P = self.lib, self.stream(), s['P']
+        e = self.empty
+        rows_ol, R = s['rows_ol'], s['R']
+        dMraw, dOLo, dILo, dIWo, dRLo, dNoV = e(P, 8), e(rows_ol, 4), e(2 * P, 4), e(P), e(P, 4), e(P)
+        L.check(lib.nu_shade_combine_bwd(c_p(addr(s['Mraw'])), 8, c_p(addr(s['OLo'])), c_p(addr(s['ILo'])),
+                                         c_p(addr(s['IWo'])), c_p(addr(s['RLo'])), c_p(addr(s['SD'])),
+                                         c_p(addr(self.lut)), c_p(addr(idx)), P, c_f(self.exp_max),
+                                         c_p(addr(dcolor_rm)), c_p(addr(dMraw)), c_p(addr(dOLo)), c_p(addr(dILo)),
+                                         c_p(addr(dIWo)), c_p(addr(dRLo)), c_p(addr(dNoV)), S), "nu_shade_combine_bwd")
+        if R:
+            if d_spec_raw is not None:
+                dOLo[3 * P:, :3] = d_spec_raw
+                dOLo[3 * P:, 3] = 0
+            else:
+                dOLo[3 * P:].zero_()
+        if d_occ_raw is not None:
+            dIWo += d_occ_raw
+        # heads + hidden stacks of the four light predictors
+        dOLin, dILin = e(rows_ol, 96), e(2 * P, 128)
+        for layers, Hs, dy, ldy, rows, no, X, ldx, dX, lddx, dxc in (
+                (self.outer_light, s['OLh'], dOLo, 4, rows_ol, 3, s['OLin'], 96, dOLin, 96, 96),
+                (self.inner_light, s['ILh'], dILo, 4, 2 * P, 3, s['ILin'], 128, dILin, 128, 128),
+                (self.inner_weight, s['IWh'], dIWo, 1, P, 1, s['IWin'], 96, None, 0, 0),
+                (self.refrac_light, s['RLh'], dRLo, 4, P, 3, s['RLin'], 96, None, 0, 0)):
+            head = layers[3]
+            dH3 = e(rows, 256)
+            self.skinny_bwd(addr(dy), ldy, addr(Hs[2]), 256, rows, 256, addr(*head.Wp), 256, no, addr(dH3), 256, 1, 0,
+                            addr(*head.dWp), head.ldd, addr(flat, head.db_off))
+            self.relu_stack_bwd(layers, X, ldx, rows, Hs, dH3, flat, dX, lddx, dxc)
+        dn = e(P, 3)
+        L.check(lib.nu_shade_encode_bwd(c_p(addr(a['n'])), c_p(addr(pt)), 8, c_p(addr(s['SD'])), c_p(addr(dOLin)),
+                                        c_p(addr(dILin)), c_p(addr(dNoV)), P, c_p(addr(dn)), c_p(addr(dMraw)), 8, S),
+                "nu_shade_encode_bwd")
+        # materials backward
+        db0, db12, db6 = self.mat_db
+        dM3 = e(P, 1024)
+        self.skinny_bwd(addr(dMraw), 8, addr(s['M3']), 1024, P, 1024, addr(self.Ws6), 1024, 6, addr(dM3), 1024, 1, 0,
+                        addr(self.dWs6), 1024, addr(flat, db6))
+        dA = dM3
+        for j, Hin in ((2, s['M2']), (1, s['M1'])):
+            self.wgrad(addr(dA), 1024, addr(Hin), 1024, P, 256, 256, addr(self.dWpM[j]), 256, addr(flat, db12[j]),
+                       groups=4, sA0=256, sB0=256, sW=65536, sDb=256)
+            nxt = e(P, 1024)
+            self.nt(addr(dA), 1024, addr(self.WpTM[j]), 256, P, 256, 256, addr(nxt), 1024, EPI_MUL_DRELU,
+                    H=addr(Hin), ldh=1024, groups=4, sA=256, sB=65536, sC=256, sH=256)
+            dA = nxt
+        self.wgrad(addr(dA), 1024, addr(a['YX']), 288, P, 1024, 288, addr(self.dWpM0), 288, addr(flat, db0))
+        dYX = e(P, 288)
+        self.nt(addr(dA), 1024, addr(self.WpTM0), 1024, P, 288, 1024, addr(dYX), 288, EPI_PLAIN)
+        return dYX, dn
+
+    # ------------------------------------------------------------------ NeRF++ background
+    def nerf_forward(self, pt, idx, P, alpha_rm, color_rm):
+        lib, S = self.lib, self.stream()
+        e = self.empty
+        b = {'P': P}
+        E4, U5, V = e(P, 96), e(P, 352), e(P, 288)
+        L.check(lib.nu_nerf_embed(c_p(addr(pt)), 8, P, c_p(addr(E4)), c_p(addr(U5)), c_p(addr(V)), S), "nu_nerf_embed")
+        H = [E4]
+        src, lds = E4, 96
+        for i in range(8):
+            lay = self.nerf[i]
+            dst = U5 if i == 4 else e(P, 256)
+            ldc = 352 if i == 4 else 256
+            self.nt(addr(src), lds, addr(*lay.Wp), lay.Kp, P, 256, lay.Kp, addr(dst), ldc, EPI_BIAS_RELU, bias=addr(lay.b))
+            H.append(dst)
+            src, lds = dst, ldc
+        b['H'] = H  # H[i] = input of layer i (H[5] = U5, ld 352), H[8] = last hidden
+        sig = e(P)
+        self.skinny_fwd(addr(H[8]), 256, P, 256, addr(*self.nerf_alpha.Wp), 256, addr(self.nerf_alpha.b), 1, addr(sig), 1)
+        self.nt(addr(H[8]), 256, addr(*self.nerf_feat.Wp), 256, P, 256, 256, addr(V), 288, EPI_BIAS_NONE,
+                bias=addr(self.nerf_feat.b))
+        HV = e(P, 128)
+        self.nt(addr(V), 288, addr(*self.nerf_view.Wp), 288, P, 128, 288, addr(HV), 128, EPI_BIAS_RELU,
+                bias=addr(self.nerf_view.b))
+        rgb = e(P, 4)
+        self.skinny_fwd(addr(HV), 128, P, 128, addr(*self.nerf_rgb.Wp), 128, addr(self.nerf_rgb.b), 3, addr(rgb), 4)
+        L.check(lib.nu_nerf_act_fwd(c_p(addr(sig)), 1, c_p(addr(rgb)), 4, c_p(addr(pt)), c_p(addr(idx)), P,
+                                    c_p(addr(alpha_rm)), c_p(addr(color_rm)), S), "nu_nerf_act_fwd")
+        b.update(V=V, HV=HV, sig=sig, rgb=rgb)
+        return b
+
+    def nerf_backward(self, b, pt, idx, dalpha_rm, dcolor_rm, flat):
+        lib, S, P = self.lib, self.stream(), b['P']
+        e = self.empty
+        H = b['H']
+        dsig, drgb = e(P), e(P, 4)
+        L.check(lib.nu_nerf_act_bwd(c_p(addr(b['sig'])), 1, c_p(addr(b['rgb'])), 4, c_p(addr(pt)), c_p(addr(idx)), P,
+                                    c_p(addr(dalpha_rm)), c_p(addr(dcolor_rm)), c_p(addr(dsig)), 1, c_p(addr(drgb)), 4, S),
+                "nu_nerf_act_bwd")
+        # rgb head -> view layer
+        dHV = e(P, 128)
+        self.skinny_bwd(addr(drgb), 4, addr(b['HV']), 128, P, 128, addr(*self.nerf_rgb.Wp), 128, 3, addr(dHV), 128, 1, 0,
+                        addr(*self.nerf_rgb.dWp), 128, addr(flat, self.nerf_rgb.db_off))
+        self.wgrad(addr(dHV), 128, addr(b['V']), 288, P, 128, 288, addr(*self.nerf_view.dWp), 288,
+                   addr(flat, self.nerf_view.db_off))
+        dF = e(P, 256)   # gradient w.r.t. the feature_linear output (first 256 columns of V)
+        self.nt(addr(dHV), 128, addr(*self.nerf_view.WpT), self.nerf_view.ldT, P, 256, 128, addr(dF), 256, EPI_PLAIN)
+        self.wgrad(addr(dF), 256, addr(H[8]), 256, P, 256, 256, addr(*self.nerf_feat.dWp), 256,
+                   addr(flat, self.nerf_feat.db_off))
+        # density head: dH8_alpha (masked by relu'(H8)), then add the feature path
+        dH8a = e(P, 256)
+        self.skinny_bwd(addr(dsig), 1, addr(H[8]), 256, P, 256, addr(*self.nerf_alpha.Wp), 256, 1, addr(dH8a), 256, 1, 0,
+                        addr(*self.nerf_alpha.dWp), 256, addr(flat, self.nerf_alpha.db_off))
+        dA = e(P, 256)
+        self.nt(addr(dF), 256, addr(*self.nerf_feat.WpT), self.nerf_feat.ldT, P, 256, 256, addr(dA), 256, EPI_B_RELU,
+                H=addr(H[8]), ldh=256, Cadd=addr(dH8a), ldadd=256)
+        # trunk, layers 7..0 ; dA = d pre-activation of layer i
+        for i in range(7, -1, -1):
+            lay = self.nerf[i]
+            ldu = 96 if i == 0 else (352 if i == 5 else 256)
+            self.wgrad(addr(dA), 256, addr(H[i]), ldu, P, 256, lay.Kp, addr(*lay.dWp), lay.ldd, addr(flat, lay.db_off))
+            if i > 0:
+                nxt = e(P, 256)
+                self.nt(addr(dA), 256, addr(*lay.WpT), lay.ldT, P, 256, 256, addr(nxt), 256, EPI_MUL_DRELU,
+                        H=addr(H[i]), ldh=ldu)
+                dA = nxt
+
+    # ------------------------------------------------------------------ sampler (no grad)
+    def _sampler_consts(self, Nc, Nbg, n_new):
+        key = (Nc, Nbg, n_new)
+        if getattr(self, '_sc_key', None) != key:
+            lin = torch.linspace(0.0, 1.0, Nc)
+            zo = torch.linspace(1e-3, 1.0 - 1.0 / (Nbg + 1.0), Nbg)
+            mids = 0.5 * (zo[1:] + zo[:-1])
+            upper = torch.cat([mids, zo[-1:]], -1)
+            lower = torch.cat([zo[:1], mids], -1)
+            uv = torch.linspace(0.5 / n_new, 1.0 - 0.5 / n_new, steps=n_new)
+            self._sc = tuple(t.to(self.dev).contiguous() for t in (lin, lower, upper, zo, uv))
+            self._sc_key = key
+        return self._sc
+
+    def sample_ray(self, o, d, near, far, perturb, u1=None, u2=None):
+        """Hierarchical sampler (renderer_zerothick.py:572-612).  o, d [R,3]; near, far [R].  When perturb > 0 the
+        two uniform draws are taken from (u1 [R], u2 [R,Nbg]) or drawn with torch.rand on the device."""
+        cfg, lib, S = self.cfg, self.lib, self.stream()
+        Nc, Nbg, Ni, steps = cfg['n_samples'], cfg['n_bg_samples'], cfg['n_importance'], cfg['up_sample_steps']
+        R = o.shape[0]
+        n_new = Ni // steps
+        lin, lower, upper, zo_lin, uv = self._sampler_consts(Nc, Nbg, n_new)
+        if perturb > 0:
+            if u1 is None:
+                u1 = torch.rand(R, 1, device=self.dev)
+                u2 = torch.rand(R, Nbg, device=self.dev)
+            u1, u2 = u1.contiguous(), u2.contiguous()
+        e = self.empty
+        z, zbg, X = e(R, Nc), e(R, Nbg), e(R * Nc, 3)
+        L.check(lib.nu_sample_coarse(c_p(addr(o)), c_p(addr(d)), c_p(addr(near)), c_p(addr(far)), c_p(addr(lin)),
+                                     c_p(addr(lower if perturb > 0 else zo_lin)), c_p(addr(upper)),
+                                     c_p(addr(u1) if perturb > 0 else 0), c_p(addr(u2) if perturb > 0 else 0), R, Nc, Nbg,
+                                     c_p(addr(z)), c_p(addr(zbg)), c_p(addr(X)), S), "nu_sample_coarse")
+        sdf = self.sdf_forward(addr(X), 3, R * Nc, keep=False, want_feat=False)['sdf']
+        sn = Nc
+        var = self.p['deviation_network.variance']
+        for i in range(steps):
+            zn, Xn = e(R, n_new), e(R * n_new, 3)
+            L.check(lib.nu_upsample(c_p(addr(o)), c_p(addr(d)), c_p(addr(z)), c_p(addr(sdf)), R, sn, c_p(addr(var)),
+                                    c_f(64.0 * 2 ** i), 1 if cfg['clip_sample_variance'] else 0, c_p(addr(uv)), n_new,
+                                    c_p(addr(zn)), c_p(addr(Xn)), S), "nu_upsample")
+            last = i + 1 == steps
+            sdf_n = None if last else self.sdf_forward(addr(Xn), 3, R * n_new, keep=False, want_feat=False)['sdf']
+            zo, so = e(R, sn + n_new), (None if last else e(R, sn + n_new))
+            L.check(lib.nu_merge_sorted(c_p(addr(z)), c_p(addr(sdf)), sn, c_p(addr(zn)), c_p(addr(sdf_n)), n_new, R,
+                                        c_p(addr(zo)), c_p(addr(so)), S), "nu_merge_sorted")
+            z, sdf, sn = zo, so, sn + n_new
+        out = e(R, sn + Nbg)
+        L.check(lib.nu_concat_cols(c_p(addr(z)), sn, c_p(addr(zbg)), Nbg, R, c_p(addr(out)), S), "nu_concat_cols")
+        return out
+
+    # ------------------------------------------------------------------ render_core
+    def render_forward(self, o, d, z, anneal, want_weights=False):
+        """Stage-1 render_core forward (renderer_zerothick.py:725-820) on R rays with S samples each.
+        Returns (outputs dict of tensors, ctx) ; one host sync (the inner-point count)."""
+        lib, S_ = self.lib, self.stream()
+        e = self.empty
+        R, S = z.shape
+        o, d, z = o.contiguous(), d.contiguous(), z.contiguous()
+        cnt, off, tot = e(R, dtype=torch.int32), e(R, dtype=torch.int32), e(2, dtype=torch.int32)
+        L.check(lib.nu_partition_count(c_p(addr(o)), c_p(addr(d)), c_p(addr(z)), R, S, c_p(addr(cnt)), c_p(addr(off)),
+                                       c_p(addr(tot)), S_), "nu_partition_count")
+        P_in = int(tot[0].item())
+        P_out = R * S - P_in
+        pt_in, idx_in = e(max(P_in, 1), 8), e(max(P_in, 1), dtype=torch.int32)
+        pt_out, idx_out = e(max(P_out, 1), 8), e(max(P_out, 1), dtype=torch.int32)
+        inner_rm = e(R * S, dtype=torch.uint8)
+        L.check(lib.nu_partition_write(c_p(addr(o)), c_p(addr(d)), c_p(addr(z)), R, S, c_p(addr(off)), c_p(addr(pt_in)),
+                                       c_p(addr(idx_in)), c_p(addr(pt_out)), c_p(addr(idx_out)), c_p(addr(inner_rm)), S_),
+                "nu_partition_write")
+        alpha_rm, color_rm = e(R * S), e(R * S, 3)
+        ctx = dict(R=R, S=S, P_in=P_in, P_out=P_out, pt_in=pt_in, idx_in=idx_in, pt_out=pt_out, idx_out=idx_out,
+                   inner_rm=inner_rm, alpha_rm=alpha_rm, color_rm=color_rm, anneal=float(anneal))
+        if P_out > 0:
+            ctx['nerf'] = self.nerf_forward(pt_out, idx_out, P_out, alpha_rm, color_rm)
+        out = {}
+        # unit ray directions for the per-ray mirror query (dirs[:,0,:] in the reference)
+        du = torch.nn.functional.normalize(d, dim=-1).contiguous()
+        if P_in > 0:
+            a = self.sdf_forward(addr(pt_in), 8, P_in, keep=True)
+            self.sdf_normal(a)
+            gerr = e(P_in)
+            var = self.p['deviation_network.variance']
+            L.check(lib.nu_neus_alpha_fwd(c_p(addr(a['YX'])), 288, c_p(addr(a['n'])), c_p(addr(pt_in)), c_p(addr(idx_in)),
+                                          P_in, c_p(addr(var)), c_f(anneal), c_p(addr(alpha_rm)), c_p(addr(gerr)), S_),
+                    "nu_neus_alpha_fwd")
+            s = self.shading_forward(a, pt_in, idx_in, P_in, color_rm, extra_dirs=du)
+            ctx.update(sdf=a, shade=s)
+            out['gradient_error'] = gerr
+            out['spec_raw'] = s['OLo'][3 * P_in:, :3]
+            out['occ_raw'] = s['IWo']
+            out['sdf_in'] = a['YX'][:, 0]
+            out['aux'] = s['aux']
+            out['normal_raw'] = a['n']
+        weights = e(R, S) if want_weights else None
+        rgb, acc, rgb_bg = e(R, 3), e(R), e(R, 3)
+        L.check(lib.nu_composite_fwd(c_p(addr(alpha_rm)), c_p(addr(color_rm)), c_p(addr(inner_rm)), R, S,
+                                     c_p(addr(weights)), c_p(addr(rgb)), c_p(addr(acc)), c_p(addr(rgb_bg)), S_),
+                "nu_composite_fwd")
+        out.update(rgb=rgb, acc=acc, rgb_bg=rgb_bg, weights=weights)
+        return out, ctx
+
+    def render_backward(self, ctx, d_rgb, d_acc, d_rgb_bg, d_gerr=None, d_spec_raw=None, d_occ_raw=None, d_sdf_in=None,
+                        train_inv_s=False):
+        """Hand-derived backward of render_forward w.r.t. every network parameter.  Returns the flat gradient
+        buffer (layout: self.grad_views)."""
+        lib, S_ = self.lib, self.stream()
+        e = self.empty
+        R, S, P_in, P_out = ctx['R'], ctx['S'], ctx['P_in'], ctx['P_out']
+        flat = self.zeros(self.n_grad)
+        dalpha_rm, dcolor_rm = e(R * S), e(R * S, 3)
+        L.check(lib.nu_composite_bwd(c_p(addr(ctx['alpha_rm'])), c_p(addr(ctx['color_rm'])), c_p(addr(ctx['inner_rm'])),
+                                     R, S, c_p(addr(d_rgb.contiguous())), c_p(addr(d_acc.contiguous()) if d_acc is not None else 0),
+                                     c_p(addr(d_rgb_bg.contiguous()) if d_rgb_bg is not None else 0), c_p(addr(dalpha_rm)),
+                                     c_p(addr(dcolor_rm)), S_), "nu_composite_bwd")
+        if P_out > 0:
+            self.nerf_backward(ctx['nerf'], ctx['pt_out'], ctx['idx_out'], dalpha_rm, dcolor_rm, flat)
+        if P_in > 0:
+            a, s = ctx['sdf'], ctx['shade']
+            dYX, dn = self.shading_backward(a, s, ctx['pt_in'], ctx['idx_in'], dcolor_rm, flat,
+                                            d_spec_raw=d_spec_raw, d_occ_raw=d_occ_raw)
+            nbar = e(P_in, 3)
+            var = self.p['deviation_network.variance']
+            L.check(lib.nu_neus_alpha_bwd(c_p(addr(a['YX'])), 288, c_p(addr(a['n'])), c_p(addr(ctx['pt_in'])),
+                                          c_p(addr(ctx['idx_in'])), P_in, c_p(addr(var)), c_f(ctx['anneal']),
+                                          c_p(addr(dalpha_rm)), c_p(addr(d_gerr.contiguous()) if d_gerr is not None else 0),
+                                          c_p(addr(dn)), c_p(addr(dYX)), 288, c_p(addr(nbar)),
+                                          c_p(addr(flat, self.var_off) if train_inv_s else 0), S_), "nu_neus_alpha_bwd")
+            if d_sdf_in is not None:
+                dYX[:, 0] += d_sdf_in
+            self.sdf_backward(a, dYX, nbar, flat)
+        self.unpack_grads(flat)
+        return flat

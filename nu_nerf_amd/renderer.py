@@ -1,0 +1,382 @@
+"""Drop-in boundary: `name2renderer[cfg['network']](cfg)` -> nn.Module with `forward(data) -> dict`.
+
+Mirrors the reference's renderer protocol (network/renderer_zerothick.py:89-864, registry :2057-2060;
+called from train/trainer_zero.py:58,152): same constructor signature `(cfg, training=True)`, same
+`default_cfg` keys, same `state_dict()` names (legacy weight-norm `weight_g`/`weight_v`), same
+`render(...)` signature and output-dict keys.  The arithmetic runs in the HIP library through
+`Stage1Engine`; modules here only own the parameters.  Device-agnostic (no `cuda:0` literals, no
+default-tensor-type flips) so one process per GPU works.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .engine import Stage1Engine
+from .params import init_stage1_params, predictor_dims
+from . import synthetic
+
+
+# ------------------------------------------------------------------------------------------------
+# parameter containers with the reference's state_dict layout
+# ------------------------------------------------------------------------------------------------
+class WNLinear(nn.Module):
+    """Parameters of `nn.utils.weight_norm(nn.Linear(in, out))`: bias, weight_g [out,1], weight_v [out,in]
+    (registration order of the legacy hook; reference field.py:121-122, :386-393)."""
+
+    def __init__(self, in_dim, out_dim):
+        super().__init__()
+        self.bias = nn.Parameter(torch.zeros(out_dim))
+        self.weight_g = nn.Parameter(torch.ones(out_dim, 1))
+        self.weight_v = nn.Parameter(torch.zeros(out_dim, in_dim))
+
+
+class PlainLinear(nn.Module):
+    def __init__(self, in_dim, out_dim):
+        super().__init__()
+        self.weight = nn.Parameter(torch.zeros(out_dim, in_dim))
+        self.bias = nn.Parameter(torch.zeros(out_dim))
+
+
+class SDFNetwork(nn.Module):
+    """Parameter layout of reference SDFNetwork (field.py:64-124): lin0..lin8, dims 39-256x3-217-256x4-257."""
+
+    def __init__(self):
+        super().__init__()
+        dims = [39] + [256] * 8 + [257]
+        for l in range(9):
+            out_dim = dims[l + 1] - dims[0] if l + 1 == 4 else dims[l + 1]
+            setattr(self, f"lin{l}", WNLinear(dims[l], out_dim))
+
+
+class SingleVarianceNetwork(nn.Module):
+    def __init__(self, init_val):
+        super().__init__()
+        self.variance = nn.Parameter(torch.tensor(float(init_val)))
+
+
+class NeRFNetwork(nn.Module):
+    """Parameter layout of reference NeRFNetwork(D=8, W=256, d_in=4, multires=10, multires_view=4) (field.py:246-261)."""
+
+    def __init__(self):
+        super().__init__()
+        self.pts_linears = nn.ModuleList([PlainLinear(84, 256)] +
+                                         [PlainLinear(256 + 84 if i == 4 else 256, 256) for i in range(7)])
+        self.views_linears = nn.ModuleList([PlainLinear(27 + 256, 128)])
+        self.feature_linear = PlainLinear(256, 256)
+        self.alpha_linear = PlainLinear(256, 1)
+        self.rgb_linear = PlainLinear(128, 3)
+
+
+def _predictor(in_dim, out_dim):
+    """make_predictor layout: Sequential indices 0,2,4,6 hold the weight-normed linears (field.py:386-395)."""
+    return nn.Sequential(WNLinear(in_dim, 256), nn.ReLU(), WNLinear(256, 256), nn.ReLU(), WNLinear(256, 256), nn.ReLU(),
+                         WNLinear(256, out_dim), nn.Identity())
+
+
+class AppShadingNetwork(nn.Module):
+    default_cfg = {'human_light': False, 'sphere_direction': False, 'light_pos_freq': 6, 'inner_init': -0.95,
+                   'roughness_init': 0.0, 'metallic_init': 0.0, 'light_exp_max': 3.0, 'refrac_freq': 6}
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = {**self.default_cfg, **cfg}
+        if self.cfg['human_light']:
+            raise NotImplementedError("human_light=True is outside the stage-1 hot path of the supported configs")
+        for name, k, n_out, _ in predictor_dims(self.cfg['sphere_direction']):
+            setattr(self, name, _predictor(k, n_out))
+        self.register_buffer('FG_LUT', torch.zeros(1, 256, 256, 2))
+
+
+class InfOutNetwork(nn.Module):
+    """Constructed by the reference but never evaluated (field.py:1020-1042); kept for state_dict compatibility."""
+
+    def __init__(self):
+        super().__init__()
+        self.module0 = nn.Sequential(WNLinear(63, 256), nn.ReLU(), WNLinear(256, 256), nn.ReLU(), WNLinear(256, 256),
+                                     nn.ReLU(), WNLinear(256, 256), nn.ReLU(), WNLinear(256, 3), nn.ReLU())
+
+
+# ------------------------------------------------------------------------------------------------
+# autograd wrappers around the engine
+# ------------------------------------------------------------------------------------------------
+class _RenderCoreFn(torch.autograd.Function):
+    """render_core as ONE differentiable op: forward + hand-derived backward, both sequences of HIP kernels."""
+
+    @staticmethod
+    def forward(ctx, engine, o, d, z, anneal, train_inv_s, names, *params):
+        out, c = engine.render_forward(o, d, z, anneal)
+        ctx.engine, ctx.c, ctx.names, ctx.train_inv_s = engine, c, names, train_inv_s
+        ctx.set_materialize_grads(False)
+        dev = o.device
+        P_in = c['P_in']
+        if P_in > 0:
+            gerr, spec, occ, sdf_in = out['gradient_error'], out['spec_raw'].clone(), out['occ_raw'].clone(), out['sdf_in'].clone()
+        else:
+            gerr = torch.zeros(0, device=dev)
+            spec, occ, sdf_in = torch.zeros(o.shape[0], 3, device=dev), torch.zeros(0, device=dev), torch.zeros(0, device=dev)
+        return out['rgb'], out['acc'], out['rgb_bg'], gerr, spec, occ, sdf_in
+
+    @staticmethod
+    def backward(ctx, d_rgb, d_acc, d_rgb_bg, d_gerr, d_spec, d_occ, d_sdf):
+        eng, c = ctx.engine, ctx.c
+        R = c['R']
+        dev = c['alpha_rm'].device
+        if d_rgb is None:
+            d_rgb = torch.zeros(R, 3, device=dev)
+        flat = eng.render_backward(c, d_rgb, d_acc, d_rgb_bg, d_gerr, d_spec, d_occ, d_sdf, train_inv_s=ctx.train_inv_s)
+        grads = []
+        for n in ctx.names:
+            off, shape = eng.grad_views[n]
+            if n == 'deviation_network.variance' and not ctx.train_inv_s:
+                grads.append(None)
+                continue
+            numel = int(np.prod(shape)) if len(shape) else 1
+            grads.append(flat[off:off + numel].view(shape))
+        ctx.c = None
+        return (None,) * 7 + tuple(grads)
+
+
+class _SdfValueFn(torch.autograd.Function):
+    """sdf(x) for a set of points with gradients to the SDF parameters only (init-SDF regulariser on the shell
+    1 < |x| < 1.2; renderer_zerothick.py:804-807)."""
+
+    @staticmethod
+    def forward(ctx, engine, pts, names, *params):
+        from .engine import addr
+        P = pts.shape[0]
+        a = engine.sdf_forward(addr(pts), 3, P, keep=True, want_feat=True)
+        ctx.engine, ctx.a, ctx.names = engine, a, names
+        return a['YX'][:, 0].clone()
+
+    @staticmethod
+    def backward(ctx, d_sdf):
+        eng, a = ctx.engine, ctx.a
+        P = a['P']
+        flat = eng.zeros(eng.n_grad)
+        dYX = eng.zeros(P, 288)
+        dYX[:, 0] = d_sdf
+        eng.sdf_backward(a, dYX, None, flat)
+        eng.unpack_grads(flat)
+        grads = []
+        for n in ctx.names:
+            off, shape = eng.grad_views[n]
+            numel = int(np.prod(shape)) if len(shape) else 1
+            grads.append(flat[off:off + numel].view(shape))
+        ctx.a = None
+        return (None, None, None) + tuple(grads)
+
+
+def linear_to_srgb(x):
+    """utils/raw_utils.py:5-11 (used here only on [R,3]-sized per-ray tensors)."""
+    eps = torch.finfo(torch.float32).eps
+    return torch.where(x <= 0.0031308, 323 / 25 * x, (211 * torch.clamp(x, min=eps) ** (5 / 12) - 11) / 200)
+
+
+# ------------------------------------------------------------------------------------------------
+# the renderer module
+# ------------------------------------------------------------------------------------------------
+class NeROShapeRenderer(nn.Module):
+    default_cfg = {
+        'std_net': 'default', 'std_act': 'exp', 'inv_s_init': 0.3, 'freeze_inv_s_step': None,
+        'sdf_net': 'default', 'sdf_activation': 'none', 'sdf_bias': 0.5, 'sdf_n_layers': 8, 'sdf_freq': 6,
+        'sdf_d_out': 257, 'geometry_init': True,
+        'shader_config': {},
+        'n_samples': 64, 'n_bg_samples': 32, 'inf_far': 1000.0, 'n_importance': 64, 'up_sample_steps': 4,
+        'perturb': 1.0, 'anneal_end': 50000, 'train_ray_num': 512, 'test_ray_num': 1024,
+        'clip_sample_variance': True, 'is_nerf': False,
+        'database_name': 'nerf_synthetic/lego/black_800',
+        'test_downsample_ratio': True, 'downsample_ratio': 0.5, 'val_geometry': False,
+        'rgb_loss': 'charbonier', 'apply_occ_loss': True, 'occ_loss_step': 20000, 'occ_loss_max_pn': 2048,
+        'occ_sdf_thresh': 0.01,
+        'fixed_camera': False,
+    }
+
+    def __init__(self, cfg, training=True):
+        super().__init__()
+        self.cfg = {**self.default_cfg, **cfg}
+        c = self.cfg
+        if (c['sdf_n_layers'], c['sdf_freq'], c['sdf_d_out'], c['std_act'], c['sdf_activation']) != (8, 6, 257, 'exp', 'none'):
+            raise NotImplementedError("only the default SDF/variance architecture is built (every shipped config uses it)")
+        self.is_nerf = c['is_nerf']
+        self.sdf_network = SDFNetwork()
+        self.deviation_network = SingleVarianceNetwork(c['inv_s_init'])
+        self.outer_nerf = NeRFNetwork()
+        self.color_network = AppShadingNetwork(c['shader_config'])
+        self.infinity_far_bkgr = InfOutNetwork()
+        self._engine = None
+        self._init_parameters()
+        if training:
+            self._init_dataset()
+
+    # ---- parameters -------------------------------------------------------------------------
+    def _init_parameters(self):
+        """Reference initial distributions (geometric SDF init etc., see params.py), seeded from torch's RNG so
+        `torch.manual_seed` (train/trainer_zero.py:96) makes construction reproducible."""
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+        init = init_stage1_params(seed, sphere_direction=self.color_network.cfg['sphere_direction'],
+                                  sdf_bias=self.cfg['sdf_bias'], inv_s_init=self.cfg['inv_s_init'])
+        self.load_param_dict(init)
+
+    def load_param_dict(self, arrays):
+        sd = self.state_dict()
+        with torch.no_grad():
+            for k, v in arrays.items():
+                sd[k].copy_(torch.as_tensor(np.asarray(v)).reshape(sd[k].shape))
+
+    def _named(self):
+        d = dict(self.named_parameters())
+        d['color_network.FG_LUT'] = self.color_network.FG_LUT
+        return d
+
+    def engine(self):
+        dev = self.deviation_network.variance.device
+        if self._engine is None or self._engine.dev != dev:
+            ecfg = dict(self.cfg)
+            ecfg.update(self.color_network.cfg)
+            self._engine = Stage1Engine(self._named(), dev, ecfg)
+            self._grad_names = [n for n in self._engine.grad_views.keys()]
+            named = self._named()
+            self._grad_params = [named[n] for n in self._grad_names]
+            self._sdf_names = [n for n in self._grad_names if n.startswith('sdf_network')]
+            self._sdf_params = [named[n] for n in self._sdf_names]
+        return self._engine
+
+    def _apply(self, fn, *a, **k):
+        self._engine = None  # parameters may move: rebuild the packed tables lazily
+        return super()._apply(fn, *a, **k)
+
+    # ---- data ----------------------------------------------------------------------------------
+    def _init_dataset(self):
+        """Ray-batch store.  Only the synthetic source exists offline (`database_name: synthetic/<n_rays>`);
+        the reference's image databases (dataset/database.py) are out of scope."""
+        name = self.cfg['database_name']
+        if not name.startswith('synthetic'):
+            raise NotImplementedError(
+                f"database '{name}': image databases are outside this build's scope; use 'synthetic/<n_rays>' "
+                "or construct with training=False and call render()/train_step_rays() with your own rays")
+        parts = name.split('/')
+        n = int(parts[1]) if len(parts) > 1 else 1 << 20
+        rays = synthetic.make_rays(n, seed=int(self.cfg.get('ray_seed', 6033)))
+        self.train_batch = {k: torch.from_numpy(v) for k, v in rays.items()}
+        self.tbn = n
+        self.train_batch_i = 0
+        self._batch_dev = None
+
+    def _shuffle_train_batch(self):
+        self.train_batch_i = 0
+        dev = self._batch_dev
+        idx = torch.randperm(self.tbn, device=dev)
+        for k, v in self.train_batch.items():
+            self.train_batch[k] = v[idx]
+
+    # ---- reference helpers ------------------------------------------------------------------------
+    def get_anneal_val(self, step):
+        if self.cfg['anneal_end'] < 0:
+            return 1.0
+        return float(np.min([1.0, step / self.cfg['anneal_end']]))
+
+    @staticmethod
+    def near_far_from_sphere(rays_o, rays_d):
+        a = torch.sum(rays_d ** 2, dim=-1, keepdim=True)
+        b = 2.0 * torch.sum(rays_o * rays_d, dim=-1, keepdim=True)
+        mid = 0.5 * (-b) / a
+        return torch.clamp(mid - 1.0, min=1e-3), mid + 1.0
+
+    def _process_nerf_ray_batch(self, ray_batch, poses=None):
+        rays_d = F.normalize(ray_batch['rays_d'], dim=-1)
+        rays_o = ray_batch['rays_o']
+        n = rays_o.shape[0]
+        near = torch.full((n, 1), 0.8, device=rays_o.device)
+        far = torch.full((n, 1), 4.5, device=rays_o.device)
+        return rays_o, rays_d, near, far, None
+
+    def compute_rgb_loss(self, rgb_pr, rgb_gt):
+        kind = self.cfg['rgb_loss']
+        if kind == 'l2':
+            return torch.sum((rgb_pr - rgb_gt) ** 2, -1)
+        if kind == 'l1':
+            return torch.sum(F.l1_loss(rgb_pr, rgb_gt, reduction='none'), -1)
+        if kind == 'smooth_l1':
+            return torch.sum(F.smooth_l1_loss(rgb_pr, rgb_gt, reduction='none', beta=0.25), -1)
+        if kind == 'charbonier':
+            return torch.sqrt(torch.sum((rgb_gt - rgb_pr) ** 2, dim=-1) + 0.001)
+        raise NotImplementedError
+
+    # ---- hot path -----------------------------------------------------------------------------------
+    def sample_ray(self, rays_o, rays_d, near, far, perturb, rand=None):
+        eng = self.engine()
+        u1, u2 = rand if rand is not None else (None, None)
+        return eng.sample_ray(rays_o.contiguous(), rays_d.contiguous(), near.reshape(-1).contiguous(),
+                              far.reshape(-1).contiguous(), perturb, u1, u2)
+
+    def render(self, rays_o, rays_d, near, far, human_poses=None, perturb_overwrite=-1, cos_anneal_ratio=0.0,
+               is_train=True, step=None, is_nerf=False, rand=None):
+        """Same contract as the reference `render` (renderer_zerothick.py:614-634).  `rand` optionally injects the
+        sampler's two uniform draws (parity tests)."""
+        perturb = self.cfg['perturb']
+        if perturb_overwrite >= 0:
+            perturb = perturb_overwrite
+        eng = self.engine()
+        eng.pack()
+        with torch.no_grad():
+            z_vals = self.sample_ray(rays_o, rays_d, near, far, perturb, rand)
+        return self.render_core(rays_o, rays_d, z_vals, human_poses, cos_anneal_ratio=cos_anneal_ratio, step=step,
+                                is_train=is_train, is_nerf=is_nerf, _packed=True)
+
+    def render_core(self, rays_o, rays_d, z_vals, human_poses=None, cos_anneal_ratio=0.0, step=None, is_train=True,
+                    is_nerf=False, _packed=False):
+        eng = self.engine()
+        if not _packed:
+            eng.pack()
+        cfg = self.cfg
+        frozen = cfg['freeze_inv_s_step'] is not None and step < cfg['freeze_inv_s_step']
+        rgb, acc, rgb_bg, gerr, spec_raw, occ_raw, sdf_in = _RenderCoreFn.apply(
+            eng, rays_o, rays_d, z_vals, float(cos_anneal_ratio), not frozen, self._grad_names, *self._grad_params)
+        color = rgb + (1. - acc[..., None]) if is_nerf else rgb
+        exp_max = eng.exp_max
+        outputs = {
+            'ray_rgb': torch.clamp(color, min=0.0, max=1.0),
+            'gradient_error': gerr if gerr.numel() else torch.zeros(1, device=rgb.device),
+            'acc': acc,
+            'color_bkgr': rgb_bg,
+            'color_spec': linear_to_srgb(torch.exp(torch.clamp(spec_raw, max=exp_max))),
+        }
+        var = self.deviation_network.variance
+        inv_s = torch.exp(var * 10.0).clip(1e-6, 1e6)
+        outputs['std'] = (1.0 / inv_s).detach() if gerr.numel() else torch.zeros(1, device=rgb.device)
+        self._last = dict(occ_raw=occ_raw, sdf_in=sdf_in)
+        return outputs
+
+    def forward(self, data):
+        is_train = 'eval' not in data
+        step = data['step']
+        if not is_train:
+            raise NotImplementedError("validation rendering (test_step) needs an image database: out of scope")
+        return self.train_step(step)
+
+    def train_step(self, step):
+        rn = self.cfg['train_ray_num']
+        dev = self.deviation_network.variance.device
+        if self._batch_dev != dev:
+            self.train_batch = {k: v.to(dev) for k, v in self.train_batch.items()}
+            self._batch_dev = dev
+            self._shuffle_train_batch()
+        batch = {k: v[self.train_batch_i:self.train_batch_i + rn] for k, v in self.train_batch.items()}
+        self.train_batch_i += rn
+        if self.train_batch_i + rn >= self.tbn:
+            self._shuffle_train_batch()
+        return self.train_step_rays(batch, step)
+
+    def train_step_rays(self, batch, step, rand=None):
+        """One training forward on an explicit ray batch {'rays_o','rays_d','rgbs'} (renderer_zerothick.py:447-466)."""
+        rays_o, rays_d, near, far, poses = self._process_nerf_ray_batch(batch)
+        outputs = self.render(rays_o, rays_d, near, far, poses, -1, self.get_anneal_val(step), is_train=True, step=step,
+                              is_nerf=self.is_nerf, rand=rand)
+        outputs['loss_rgb'] = self.compute_rgb_loss(outputs['ray_rgb'], batch['rgbs'])
+        return outputs
+
+
+name2renderer = {'shape': NeROShapeRenderer}
