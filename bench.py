@@ -1,0 +1,200 @@
+"""bench.py -- headline benchmark: stage-1 training throughput (train rays/s, ms/iter) on a Spherepot-shaped
+synthetic workload (BASELINE.json configs[1]: 4096 rays/batch, 64 coarse + 64 importance + 32 background
+samples, fp32), one process per GPU, ray batches sharded data-parallel with an RCCL all-reduce of the
+parameter gradients.
+
+    python bench.py --gpus N --steps K --warmup W            (N>1: launched by torch.distributed.run)
+
+A step = ray fetch (device-resident pool) -> sampler -> render_core forward -> loss -> backward -> [all-reduce]
+-> Adam.  Rank 0 prints ONE JSON line.  Extra objects:
+  roofline     : the fp32-MFMA GEMM kernels (gemm_nt_kernel*, the dominant kernel): algorithmic FLOPs of every
+                 launch in the timed region / summed launch durations (HIP events on the launch stream) vs the
+                 157.3 TFLOP/s fp32-MFMA peak of MI355X_MICROARCH.md.
+  cpu_baseline : the CPU oracle (oracle/stage1_oracle.py, a port of the reference's PyTorch path) timed on this
+                 box's host cores on a bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+
+
+def build_cfg(rays):
+    return {'name': 'bench', 'network': 'shape', 'database_name': 'synthetic/0', 'is_nerf': True, 'apply_occ_loss': True,
+            'occ_loss_step': 15000, 'freeze_inv_s_step': 15000, 'eikonal_weight': 0.1, 'train_ray_num': rays,
+            'n_samples': 64, 'n_importance': 64, 'n_bg_samples': 32, 'up_sample_steps': 4}
+
+
+def warmup_cos_lr(step, end_warm=5000, end_iter=300000, lr=5e-4, alpha=0.05):
+    if step < end_warm:
+        return lr * step / end_warm
+    prog = (step - end_warm) / (end_iter - end_warm)
+    return lr * ((np.cos(np.pi * prog) + 1.0) * 0.5 * (1 - alpha) + alpha)
+
+
+def cpu_baseline(rays_cpu, step0, budget_s=20.0):
+    """Oracle (port of the reference PyTorch path) on host cores: full iterations incl. backward + Adam."""
+    from oracle import stage1_oracle as O
+    from nu_nerf_amd.params import init_stage1_params
+    R = 128
+    cfg = dict(O.DEFAULT_CFG)
+    params = {}
+    for k, v in init_stage1_params(6033).items():
+        t = torch.from_numpy(np.ascontiguousarray(v))
+        if not k.endswith('FG_LUT') and not k.startswith('infinity') and '.iors.' not in k:
+            t.requires_grad_(True)
+        params[k] = t
+    opt = torch.optim.Adam([p for p in params.values() if p.requires_grad], lr=1e-3)
+    o, d, rgb = (torch.from_numpy(rays_cpu[k][:R]) for k in ('rays_o', 'rays_d', 'rgbs'))
+    times = []
+    t_start = time.time()
+    it = 0
+    while True:
+        t0 = time.time()
+        opt.zero_grad()
+        total, _, _ = O.train_step(params, cfg, o, d, rgb, step0 + it)
+        total.backward()
+        opt.step()
+        dt = time.time() - t0
+        if it > 0:
+            times.append(dt)
+        it += 1
+        if (time.time() - t_start > budget_s and len(times) >= 1) or len(times) >= 8:
+            break
+    ms = 1e3 * float(np.mean(times))
+    return {"value": R / (ms / 1e3), "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{len(times)} full iterations (fwd+bwd+Adam) of {R} rays x 160 samples after 1 warm-up, "
+                      f"{ms:.0f} ms/iter, torch CPU fp32, os.cpu_count()={os.cpu_count()}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--rays', type=int, default=4096, help='rays per GPU per step')
+    ap.add_argument('--start-step', type=int, default=20000, help='training-step index of the first iteration')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-timing', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=dev)
+    assert world == args.gpus or world == 1, (world, args.gpus)
+
+    from nu_nerf_amd.renderer import NeROShapeRenderer
+    from nu_nerf_amd.params import init_stage1_params
+    from nu_nerf_amd.synthetic import make_rays
+    from nu_nerf_amd.loss import name2loss, SPHEREPOT_LOSSES, total_loss
+    from nu_nerf_amd.parallel import GradAllReducer
+
+    R = args.rays
+    cfg = build_cfg(R)
+    torch.manual_seed(6033)
+    net = NeROShapeRenderer(cfg, training=False)
+    net.load_param_dict(init_stage1_params(6033))       # identical replica on every rank
+    net = net.to(dev)
+    losses = [name2loss[n](cfg) for n in SPHEREPOT_LOSSES]
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    reducer = GradAllReducer(net, world) if world > 1 else None
+
+    # device-resident ray pool; every rank draws a disjoint slice of the same seeded permutation
+    n_iter = args.steps + args.warmup
+    pool = make_rays(R * world * min(n_iter, 16), seed=6033)
+    pool_dev = {k: torch.from_numpy(v).to(dev) for k, v in pool.items() if k != 'idxs'}
+
+    def batch_for(it):
+        b = (it % min(n_iter, 16)) * world + rank
+        return {k: v[b * R:(b + 1) * R] for k, v in pool_dev.items()}
+
+    eng = net.engine()
+    stats = {'P_in': 0, 'P_out': 0}
+
+    def one_step(it):
+        step = args.start_step + it
+        lr = warmup_cos_lr(step)
+        for g in opt.param_groups:
+            g['lr'] = lr
+        opt.zero_grad(set_to_none=True)
+        out = net.train_step_rays(batch_for(it), step)
+        total, _ = total_loss(out, losses, step)
+        total.backward()
+        if reducer is not None:
+            reducer.all_reduce()
+        opt.step()
+        stats['P_in'] += eng.last_ctx['P_in']
+        stats['P_out'] += eng.last_ctx['P_out']
+        return total
+
+    for it in range(args.warmup):
+        one_step(it)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    stats['P_in'] = stats['P_out'] = 0
+    if not args.no_kernel_timing:
+        eng.begin_kernel_timing()
+    t0 = time.perf_counter()
+    last = None
+    for it in range(args.warmup, args.warmup + args.steps):
+        last = one_step(it)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ktime = eng.end_kernel_timing() if not args.no_kernel_timing else None
+
+    if rank == 0:
+        ms = 1e3 * elapsed / args.steps
+        value = R * world * args.steps / elapsed
+        res = {
+            "metric": "train rays/sec", "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "Spherepot-shaped stage-1 train step, %d rays/GPU x (64 coarse + 64 importance + 32 bg) "
+                                   "samples, fp32, synthetic cameras (BASELINE.json configs[1])" % R,
+                       "rays_per_gpu": R, "global_rays": R * world, "samples_per_ray": 160, "start_step": args.start_step,
+                       "parallelism": "dp%d" % world,
+                       "mean_inner_points": stats['P_in'] / args.steps, "mean_outer_points": stats['P_out'] / args.steps,
+                       "final_loss": float(last.detach())},
+        }
+        if ktime is not None:
+            tf = ktime['flops'] / max(ktime['seconds'], 1e-12) / 1e12
+            res["roofline"] = {"bound": "mfma", "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                               "frac": tf / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                               "kernel": "gemm_nt_kernel<*> (fp32 v_mfma_f32_32x32x2_f32)",
+                               "launches": ktime['launches'], "avg_launch_us": 1e6 * ktime['seconds'] / max(ktime['launches'], 1),
+                               "gemm_time_share": ktime['seconds'] / elapsed,
+                               "wgrad": {"achieved": ktime['tn_flops'] / max(ktime['tn_seconds'], 1e-12) / 1e12,
+                                         "launches": ktime['tn_launches'], "time_share": ktime['tn_seconds'] / elapsed}}
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(pool, args.start_step)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -50,11 +50,16 @@ extern "C" int nu_sample_coarse(const float* o, const float* d, const float* nea
 
 // One up-sampling round.  inv_s = min(exp(10*variance), inv_s_cap) (clip_sample_variance) or the cap itself.
 // Outputs z_new[R, n_new] (ascending) and the new sample positions Xn[R*n_new, 3].
+// MODE 0: NeuS `upsample` (cos = min(prev_cos, cos) clipped to [-1e3, 0], zeroed outside the unit sphere).
+// MODE 1: `get_weights` of the occlusion probe (field.py:501-521): cos = min(cos, 0), alpha masked by cos < 0,
+//         inv_s = exp(10*variance) uncapped; optionally writes wsum[r] = sum of the weights (the hit probability).
+template <int MODE>
 __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__ o, const float* __restrict__ d,
                                                        const float* __restrict__ z, const float* __restrict__ sdf, int R,
                                                        int sn, const float* __restrict__ variance, float inv_s_cap,
                                                        int use_variance, const float* __restrict__ uvals, int n_new,
-                                                       float* __restrict__ z_new, float* __restrict__ Xn) {
+                                                       float* __restrict__ z_new, float* __restrict__ Xn,
+                                                       float* __restrict__ wsum) {
     __shared__ float s_z[4][NU_SMAX], s_s[4][NU_SMAX], s_r[4][NU_SMAX], s_c[4][NU_SMAX + 1];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int r = blockIdx.x * 4 + w;
@@ -76,6 +81,7 @@ __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__
     // non-live waves run the arithmetic on zeros (no global access) so that every wave reaches the barrier below
     float inv_s = inv_s_cap;
     if (use_variance) inv_s = fminf(expf(variance[0] * 10.0f), inv_s_cap);
+    if (MODE == 1) inv_s = expf(variance[0] * 10.0f);
     const int ni = sn - 1;                 // intervals
     const int CH = (ni + 63) / 64;         // contiguous intervals per lane (<= 4)
     float al[4], wl[4];
@@ -87,16 +93,22 @@ __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__
             const float s0 = s_s[w][m], s1 = s_s[w][m + 1], z0 = s_z[w][m], z1 = s_z[w][m + 1];
             const float mid = (s0 + s1) * 0.5f;
             float cosv = (s1 - s0) / (z1 - z0 + 1e-5f);
-            float prev = 0.f;
-            if (m > 0) prev = (s0 - s_s[w][m - 1]) / (z0 - s_z[w][m - 1] + 1e-5f);
-            cosv = fminf(prev, cosv);
-            cosv = fminf(fmaxf(cosv, -1e3f), 0.f);
-            const bool inside = (s_r[w][m] < 1.0f) || (s_r[w][m + 1] < 1.0f);
-            cosv = inside ? cosv : 0.f;
+            bool surf = true;
+            if (MODE == 0) {
+                float prev = 0.f;
+                if (m > 0) prev = (s0 - s_s[w][m - 1]) / (z0 - s_z[w][m - 1] + 1e-5f);
+                cosv = fminf(prev, cosv);
+                cosv = fminf(fmaxf(cosv, -1e3f), 0.f);
+                const bool inside = (s_r[w][m] < 1.0f) || (s_r[w][m + 1] < 1.0f);
+                cosv = inside ? cosv : 0.f;
+            } else {
+                surf = cosv < 0.f;
+                cosv = fminf(cosv, 0.f);
+            }
             const float dz = z1 - z0;
             const float pe = mid - cosv * dz * 0.5f, ne = mid + cosv * dz * 0.5f;
             const float pc = nu_sigmoid(pe * inv_s), nc = nu_sigmoid(ne * inv_s);
-            al[i] = (pc - nc + 1e-5f) / (pc + 1e-5f);
+            al[i] = surf ? (pc - nc + 1e-5f) / (pc + 1e-5f) : 0.f;
             pl *= (1.0f - al[i] + 1e-7f);
         }
     }
@@ -104,17 +116,22 @@ __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__
     float inc = nu_wave_incl_prod(pl, lane);
     float T = __shfl_up(inc, 1, 64);
     if (lane == 0) T = 1.f;
-    float lsum = 0.f;
+    float lsum = 0.f, lraw = 0.f;
     for (int i = 0; i < CH; ++i) {
         const int m = lane * CH + i;
         wl[i] = 0.f;
         if (m < ni) {
+            lraw += al[i] * T;
             wl[i] = al[i] * T + 1e-5f;  // sample_pdf adds 1e-5 to every weight
             lsum += wl[i];
             T *= (1.0f - al[i] + 1e-7f);
         }
     }
     const float total = nu_wave_sum(lsum);
+    if (wsum) {
+        const float raw = nu_wave_sum(lraw);
+        if (live && lane == 0) wsum[r] = raw;
+    }
     // cdf: cdf[0] = 0, cdf[m+1] = sum_{i<=m} w_i/total
     float lp = 0.f;
     for (int i = 0; i < CH; ++i) {
@@ -154,8 +171,17 @@ extern "C" int nu_upsample(const float* o, const float* d, const float* z, const
                            const float* variance, float inv_s_cap, int use_variance, const float* uvals, int n_new,
                            float* z_new, float* Xn, hipStream_t stream) {
     if (R <= 0 || sn < 2 || sn > NU_SMAX) return NU_ERR_ARG;
-    hipLaunchKernelGGL(upsample_kernel, dim3(nu_cdiv(R, 4)), dim3(256), 0, stream, o, d, z, sdf, R, sn, variance, inv_s_cap,
-                       use_variance, uvals, n_new, z_new, Xn);
+    hipLaunchKernelGGL(upsample_kernel<0>, dim3(nu_cdiv(R, 4)), dim3(256), 0, stream, o, d, z, sdf, R, sn, variance,
+                       inv_s_cap, use_variance, uvals, n_new, z_new, Xn, (float*)nullptr);
+    return nu_launch_status();
+}
+// Occlusion-probe weights along secondary rays (get_weights + optional deterministic resampling)
+extern "C" int nu_probe_weights(const float* o, const float* d, const float* z, const float* sdf, int R, int sn,
+                                const float* variance, const float* uvals, int n_new, float* z_new, float* Xn,
+                                float* wsum, hipStream_t stream) {
+    if (R <= 0 || sn < 2 || sn > NU_SMAX) return NU_ERR_ARG;
+    hipLaunchKernelGGL(upsample_kernel<1>, dim3(nu_cdiv(R, 4)), dim3(256), 0, stream, o, d, z, sdf, R, sn, variance, 0.f, 0,
+                       uvals, n_new, z_new, Xn, wsum);
     return nu_launch_status();
 }
 

@@ -95,6 +95,8 @@ class Stage1Engine:
         assert lib.nu_pack_desc_size() == ctypes.sizeof(PackDesc), "PackDesc ABI mismatch"
         self._ws = None
         self._ptr_sig = None
+        self._ktime = None
+        self.last_ctx = None
         self._build_layers()
 
     # ------------------------------------------------------------------ buffers
@@ -289,15 +291,49 @@ class Stage1Engine:
 
     # ------------------------------------------------------------------ raw launches
     def nt(self, A, lda, B, ldb, M, N, K, C, ldc, epi, *, C2=0, ldc2=0, bias=0, H=0, ldh=0, D=0, ldd=0, Cadd=0,
-           ldadd=0, zero_to=0, act_cols=0, alpha=1.0, groups=1, sA=0, sB=0, sC=0, sC2=0, sBias=0, sH=0, sD=0, sCadd=0):
+           ldadd=0, zero_to=0, act_cols=0, alpha=1.0, groups=1, sA=0, sB=0, sC=0, sC2=0, sBias=0, sH=0, sD=0, sCadd=0,
+           ktrue=None, ntrue=None):
+        """C = epi(A . B^T) on the fp32-MFMA kernel.  ktrue/ntrue: unpadded extents, used only for the algorithmic
+        FLOP count of the roofline report."""
         if M <= 0:
             return
         g = GemmNT(A, lda, B, ldb, M, N, K, C, ldc, C2, ldc2, bias, H, ldh, D, ldd, Cadd, ldadd, zero_to, act_cols,
                    alpha, groups, sA, sB, sC, sC2, sBias, sH, sD, sCadd, epi)
+        kt = self._ktime
+        if kt is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         L.check(self.lib.nu_gemm_nt_ex(ctypes.byref(g), self.stream()), "nu_gemm_nt_ex")
+        if kt is not None:
+            e1.record()
+            kt['nt'].append((e0, e1, 2.0 * M * (ntrue or N) * (ktrue or K) * groups))
+
+    def begin_kernel_timing(self):
+        """Bracket every GEMM launch with HIP events on the launch stream (bench.py's roofline leg)."""
+        self._ktime = {'nt': [], 'tn': []}
+
+    def end_kernel_timing(self):
+        kt, self._ktime = self._ktime, None
+        torch.cuda.synchronize(self.dev)
+        out = {}
+        for key, pre in (('nt', ''), ('tn', 'tn_')):
+            out[pre + 'seconds'] = sum(a.elapsed_time(b) for a, b, _ in kt[key]) * 1e-3
+            out[pre + 'flops'] = sum(f for _, _, f in kt[key])
+            out[pre + 'launches'] = len(kt[key])
+        return out
 
     def wgrad(self, A0, lda0, B0, ldb0, P, N1, N2, dW, ldw, db, *, A1=0, lda1=0, B1=0, ldb1=0, groups=1, sA0=0, sB0=0,
-              sA1=0, sB1=0, sW=0, sDb=0):
+              sA1=0, sB1=0, sW=0, sDb=0, n2true=None):
+        kt = self._ktime
+        if kt is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        self._wgrad(A0, lda0, B0, ldb0, P, N1, N2, dW, ldw, db, A1, lda1, B1, ldb1, groups, sA0, sB0, sA1, sB1, sW, sDb)
+        if kt is not None:
+            e1.record()
+            kt['tn'].append((e0, e1, 2.0 * P * N1 * (n2true or N2) * groups * (2 if A1 else 1)))
+
+    def _wgrad(self, A0, lda0, B0, ldb0, P, N1, N2, dW, ldw, db, A1, lda1, B1, ldb1, groups, sA0, sB0, sA1, sB1, sW, sDb):
         tiles = ((N1 + 127) // 128) * ((N2 + 127) // 128) * groups
         S = max(1, min((P + 255) // 256, max(1, 1024 // tiles)))
         nbytes = self.lib.nu_wgrad_workspace_bytes(N1, N2, S, groups)
@@ -346,7 +382,7 @@ class Stage1Engine:
         for l in range(8):
             N = ls[l].N
             self.nt(addr(src), lds, addr(*ls[l].Wp), ls[l].Kp, P, N, K, addr(H[l + 1]), 256, EPI_BIAS_SOFTPLUS,
-                    bias=addr(ls[l].b), zero_to=N)
+                    bias=addr(ls[l].b), zero_to=N, ktrue=ls[l].K)
             src, lds, K = H[l + 1], 256, 256
         # last layer: row 0 = sdf (skinny), rows 1..256 = feature (N = 256 GEMM)
         if want_feat:
@@ -728,6 +764,7 @@ class Stage1Engine:
                                      c_p(addr(weights)), c_p(addr(rgb)), c_p(addr(acc)), c_p(addr(rgb_bg)), S_),
                 "nu_composite_fwd")
         out.update(rgb=rgb, acc=acc, rgb_bg=rgb_bg, weights=weights)
+        self.last_ctx = ctx
         return out, ctx
 
     def render_backward(self, ctx, d_rgb, d_acc, d_rgb_bg, d_gerr=None, d_spec_raw=None, d_occ_raw=None, d_sdf_in=None,
@@ -745,6 +782,11 @@ class Stage1Engine:
                                      c_p(addr(dcolor_rm)), S_), "nu_composite_bwd")
         if P_out > 0:
             self.nerf_backward(ctx['nerf'], ctx['pt_out'], ctx['idx_out'], dalpha_rm, dcolor_rm, flat)
+        else:
+            self.zero_stale_wgrads(self.nerf + [self.nerf_feat, self.nerf_alpha, self.nerf_view, self.nerf_rgb])
+        if P_in == 0:
+            self.zero_stale_wgrads(self.sdf + self.mat_layers + self.outer_light + self.inner_light +
+                                   self.inner_weight + self.refrac_light)
         if P_in > 0:
             a, s = ctx['sdf'], ctx['shade']
             dYX, dn = self.shading_backward(a, s, ctx['pt_in'], ctx['idx_in'], dcolor_rm, flat,
@@ -761,3 +803,45 @@ class Stage1Engine:
             self.sdf_backward(a, dYX, nbar, flat)
         self.unpack_grads(flat)
         return flat
+
+    # ------------------------------------------------------------------ occlusion probe (no grad)
+    def occ_probe(self, pts, dirs, sn0=64, sn1=16):
+        """Hit probability of secondary rays inside the unit sphere: get_intersection + get_weights + sample_pdf
+        (field.py:501-554) for points already known to satisfy |x| < 0.999.  Returns occ_prob_gt [M]."""
+        lib, S = self.lib, self.stream()
+        e = self.empty
+        M = pts.shape[0]
+        pts, dirs = pts.contiguous(), dirs.contiguous()
+        dtx = torch.sum(pts * dirs, dim=-1)
+        xtx = torch.sum(pts ** 2, dim=-1)
+        max_dist = (-dtx + torch.sqrt(dtx ** 2 - xtx + 1 + 1e-6)).contiguous()
+        key = ('probe', sn0, sn1)
+        if getattr(self, '_pc_key', None) != key:
+            self._pc = (torch.linspace(0, 1, sn0).to(self.dev),
+                        torch.linspace(0.5 / sn1, 1.0 - 0.5 / sn1, steps=sn1).to(self.dev))
+            self._pc_key = key
+        lin, uv = self._pc
+        zero = self.zeros(M)
+        z, X = e(M, sn0), e(M * sn0, 3)
+        L.check(lib.nu_sample_coarse(c_p(addr(pts)), c_p(addr(dirs)), c_p(addr(zero)), c_p(addr(max_dist)), c_p(addr(lin)),
+                                     c_p(0), c_p(0), c_p(0), c_p(0), M, sn0, 0, c_p(addr(z)), c_p(0), c_p(addr(X)), S),
+                "nu_sample_coarse")
+        sdf = self.sdf_forward(addr(X), 3, M * sn0, keep=False, want_feat=False)['sdf']
+        var = self.p['deviation_network.variance']
+        zn, Xn = e(M, sn1), e(M * sn1, 3)
+        L.check(lib.nu_probe_weights(c_p(addr(pts)), c_p(addr(dirs)), c_p(addr(z)), c_p(addr(sdf)), M, sn0, c_p(addr(var)),
+                                     c_p(addr(uv)), sn1, c_p(addr(zn)), c_p(addr(Xn)), c_p(0), S), "nu_probe_weights")
+        sdf2 = self.sdf_forward(addr(Xn), 3, M * sn1, keep=False, want_feat=False)['sdf']
+        wsum = e(M)
+        L.check(lib.nu_probe_weights(c_p(addr(pts)), c_p(addr(dirs)), c_p(addr(zn)), c_p(addr(sdf2)), M, sn1,
+                                     c_p(addr(var)), c_p(0), 0, c_p(0), c_p(0), c_p(addr(wsum)), S), "nu_probe_weights")
+        return wsum
+
+    def zero_stale_wgrads(self, which):
+        """When a point set is empty its weight-gradient GEMMs do not run: clear their packed outputs."""
+        seen = set()
+        for lay in which:
+            t = lay.dWp[0]
+            if id(t) not in seen:
+                t.zero_()
+                seen.add(id(t))

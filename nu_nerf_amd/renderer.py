@@ -347,8 +347,66 @@ class NeROShapeRenderer(nn.Module):
         var = self.deviation_network.variance
         inv_s = torch.exp(var * 10.0).clip(1e-6, 1e6)
         outputs['std'] = (1.0 / inv_s).detach() if gerr.numel() else torch.zeros(1, device=rgb.device)
-        self._last = dict(occ_raw=occ_raw, sdf_in=sdf_in)
+        c = eng.last_ctx
+        P_in = c['P_in']
+        if P_in > 0:
+            aux = c['shade']['aux']
+            outputs['transmission'] = aux[:, 1:2]   # logged only by the shipped configs (no gradient path here)
+            outputs['metallic'] = aux[:, 2:3]
+        if step < 1000:
+            outputs['sdf_pts'], outputs['sdf_vals'] = self._init_reg_points(eng, c, sdf_in)
+        if cfg['apply_occ_loss']:
+            if P_in > 0:
+                outputs['loss_occ'] = self.compute_occ_loss(eng, c, occ_raw, step)
+            else:
+                outputs['loss_occ'] = torch.zeros(1, device=rgb.device)
         return outputs
+
+    def _init_reg_points(self, eng, c, sdf_in):
+        """Points with |x| < 1.2 and their SDF (renderer_zerothick.py:804-807): the inner set reuses the main pass;
+        the shell 1 < |x| < 1.2 of the outer set is evaluated separately (gradients to the SDF parameters)."""
+        P_in, P_out = c['P_in'], c['P_out']
+        dev = c['alpha_rm'].device
+        pts = [c['pt_in'][:P_in, :3]] if P_in > 0 else []
+        vals = [sdf_in] if P_in > 0 else []
+        if P_out > 0:
+            xo = c['pt_out'][:P_out, :3]
+            sel = torch.nonzero(torch.norm(xo, dim=-1) < 1.2)[:, 0]
+            if sel.numel() > 0:
+                shell = xo[sel].contiguous()
+                pts.append(shell)
+                vals.append(_SdfValueFn.apply(eng, shell, self._sdf_names, *self._sdf_params))
+        if not pts:
+            return torch.zeros(0, 3, device=dev), torch.zeros(0, device=dev)
+        return torch.cat(pts, 0), torch.cat(vals, 0)
+
+    def compute_occ_loss(self, eng, c, occ_raw, step, perm=None):
+        """Occlusion loss (renderer_zerothick.py:695-723): L1 between the predicted occlusion probability and the hit
+        probability of the reflected ray traced through the SDF (no grad)."""
+        cfg = self.cfg
+        dev = occ_raw.device
+        if step < cfg['occ_loss_step']:
+            return torch.zeros(1, device=dev)
+        P_in = c['P_in']
+        with torch.no_grad():
+            pt = c['pt_in'][:P_in]
+            x, dirs = pt[:, :3], pt[:, 4:7]
+            a, SD = c['sdf'], c['shade']['SD']
+            sdf, n = a['YX'][:, 0], a['n']
+            mask = (torch.norm(x, dim=-1) < 0.999) & (torch.sum(n * dirs, -1) < 0) & (torch.abs(sdf) < cfg['occ_sdf_thresh'])
+            idx = torch.nonzero(mask)[:, 0]
+            if idx.numel() > cfg['occ_loss_max_pn']:
+                if perm is None:
+                    perm = torch.randperm(idx.numel(), device=dev)
+                idx = torch.sort(idx[perm[:cfg['occ_loss_max_pn']]])[0]
+            if idx.numel() == 0:
+                return torch.zeros(1, device=dev)
+            nh, nov = SD[idx, :3], SD[idx, 3:4]
+            vh = F.normalize(-dirs[idx], dim=-1)
+            refl = nov * nh * 2 - vh
+            occ_gt = eng.occ_probe(x[idx], refl)
+        occ_prob = occ_raw[idx] * 0.5 + 0.5
+        return F.l1_loss(occ_prob[:, None], occ_gt[:, None])
 
     def forward(self, data):
         is_train = 'eval' not in data
