@@ -1,0 +1,195 @@
+/* nu_nerf.h -- C ABI of libnunerf.so: the MI355X (gfx950) hot path of NU-NeRF's stage-1 training step.
+ *
+ * The reference (jjjkkyz/NU-NeRF) has no FFI: its hot path is eager PyTorch inside
+ * network/renderer_zerothick.py and network/field.py.  This header is the boundary a maintainer binds instead
+ * (ctypes stub: INTEGRATION.md); each entry names the reference code it replaces (paths relative to the
+ * reference repository root).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer borrowed from the caller (fp32 unless stated; indices int32; masks uint8),
+ *     row-major, contiguous unless a leading dimension (ld*) is given; nothing is allocated or freed inside;
+ *     scratch memory comes in through (workspace, workspace_bytes) with a *_workspace_bytes() size query;
+ *   - all work is enqueued on `stream` (the caller's current HIP stream); no call synchronises the device;
+ *   - return value: 0 on success, negative NU_ERR_* otherwise (never throws);
+ *   - "P" counts points, "R" rays, "S" samples per ray.  Activation buffers use padded leading dimensions whose pad
+ *     columns are zero (see DESIGN.md "Data layout").
+ */
+#ifndef NU_NERF_H
+#define NU_NERF_H
+
+/* the HIP runtime's own definition, repeated so that plain-C consumers need no HIP headers
+ * (an identical typedef redeclaration is legal in C11 and C++) */
+typedef struct ihipStream_t* hipStream_t;
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NU_OK 0
+#define NU_ERR_ARG (-1)
+#define NU_ERR_LAUNCH (-2)
+#define NU_ERR_WORKSPACE (-3)
+
+/* ---------------------------------------------------------------------------------------------------------
+ * fp32-MFMA GEMMs: the contractions of every `lin(x)` / autograd matmul in field.py:133-150 (SDFNetwork.forward),
+ * :158-170 (SDFNetwork.gradient and its double backward), :265-289 (NeRFNetwork.forward), :371-408 (make_predictor).
+ * --------------------------------------------------------------------------------------------------------- */
+enum NuEpi {                   /* epilogue applied to v = alpha * (A . B^T)[row, col] */
+    NU_EPI_BIAS_NONE = 0,      /* C = v + bias[col]                                         (last linear layers) */
+    NU_EPI_BIAS_RELU = 1,      /* C = relu(v + bias[col])                                   (field.py:274, :387-391) */
+    NU_EPI_BIAS_SOFTPLUS = 2,  /* C = softplus_beta100(v + bias[col])                       (field.py:126-127, :147-148) */
+    NU_EPI_MUL_DRELU = 3,      /* C = v * (H > 0)                                           (ReLU backward) */
+    NU_EPI_MUL_DSP = 4,        /* C = v * sp'(H),  sp' = 1 - exp(-100 H)                    (Softplus backward) */
+    NU_EPI_Q_SP = 5,           /* C = v * sp'(H);  C2 = v * D * 100 * (1 - sp'(H))          (second-order sweep) */
+    NU_EPI_B_SP = 6,           /* C = v * sp'(H) + Cadd */
+    NU_EPI_PLAIN = 7,          /* C = v */
+    NU_EPI_B_RELU = 8,         /* C = v * (H > 0) + Cadd */
+    NU_EPI_COUNT = 9
+};
+
+typedef struct NuGemmNT {      /* C[M,N] = epi(A[M,K] . B[N,K]^T);  K % 32 == 0, lda/ldb % 4 == 0, A/B 16-byte aligned */
+    const float* A; int lda;
+    const float* B; int ldb;   /* packed weights: >= ceil128(N) rows, zero padded */
+    int M, N, K;
+    float* C; int ldc;
+    float* C2; int ldc2;
+    const float* bias;
+    const float* H; int ldh;
+    const float* D; int ldd;
+    const float* Cadd; int ldadd;
+    int zero_to;               /* columns [N, zero_to) of C/C2 are written as 0 */
+    int act_cols;              /* derivative epilogues: columns >= act_cols are written as plain v (0: all columns) */
+    float alpha;
+    int groups;                /* grouped launch; element strides per group follow */
+    long long sA, sB, sC, sC2, sBias, sH, sD, sCadd;
+    int epi;                   /* enum NuEpi */
+} NuGemmNT;
+
+typedef struct NuGemmTN {      /* dW[N1,N2] = A0^T B0 (+ A1^T B1), reduced over P rows in S deterministic splits */
+    const float* A0; int lda0; const float* B0; int ldb0;
+    const float* A1; int lda1; const float* B1; int ldb1;   /* A1 == NULL: single pair */
+    int P, N1, N2;
+    float* slab; float* bias_slab;                           /* filled by nu_wgrad from the workspace */
+    int S, groups;
+    long long sA0, sB0, sA1, sB1, sSlab, sBiasSlab;
+} NuGemmTN;
+
+int nu_gemm_nt_ex(const NuGemmNT* g, hipStream_t stream);
+long long nu_wgrad_workspace_bytes(int N1, int N2, int S, int groups);
+/* dW (ld = ldw, group stride sW) and optionally db[N1] = column sums of A0 (group stride sDb) */
+int nu_wgrad(const NuGemmTN* g, float* dW, int ldw, long long sW, float* db, long long sDb, void* workspace,
+             long long workspace_bytes, hipStream_t stream);
+/* flat-argument variants (tests / stand-alone use) */
+int nu_gemm_nt(const float* A, int lda, const float* B, int ldb, int M, int N, int K, float* C, int ldc, float* C2,
+               int ldc2, const float* bias, const float* H, int ldh, const float* D, int ldd, const float* Cadd,
+               int ldadd, int zero_to, float alpha, int epi, hipStream_t stream);
+long long nu_gemm_tn_workspace_bytes(int N1, int N2, int S);
+int nu_gemm_tn(const float* A0, int lda0, const float* B0, int ldb0, const float* A1, int lda1, const float* B1,
+               int ldb1, int P, int N1, int N2, float* C, int ldc, float* bias_out, int S, void* workspace,
+               long long workspace_bytes, hipStream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Weight packing: nn.utils.weight_norm (W = v * g / ||v||_row, field.py:121-122, :386-393) folded into padded,
+ * optionally column-permuted and transposed operand buffers; and its chain rule back to (weight_v, weight_g).
+ * --------------------------------------------------------------------------------------------------------- */
+typedef struct NuPackDesc {
+    const float* v; const float* g; const int* colmap;
+    float* Wp; float* WpT; const float* dWp;
+    long long dv_off, dg_off;                 /* offsets (floats) into the flat gradient buffer */
+    const float* bias; float* bias_p;
+    float scale;
+    int N, K, Kp, ldT, ldd, row_begin, col_off;
+} NuPackDesc;
+int nu_pack_desc_size(void);
+int nu_pack_layers(const void* descs_dev, int ndesc, int total_rows, hipStream_t stream);
+int nu_unpack_grads(const void* descs_dev, int ndesc, int total_rows, float* flat_grads, hipStream_t stream);
+
+/* 1..6-wide output heads (field.py:393 final Linear of make_predictor; :260-261 alpha_linear / rgb_linear) */
+int nu_skinny_fwd(const float* H, int ldh, int P, int K, const float* Ws, int ldw, const float* b, int NO, float* out,
+                  int ldo, hipStream_t stream);
+long long nu_skinny_bwd_workspace_bytes(int K, int NO);
+int nu_skinny_bwd(const float* dy, int ldy, const float* H, int ldh, int P, int K, const float* Ws, int ldw, int NO,
+                  float* dH, int lddh, int relu_mask, int accumulate, float* dWs, int lddw, float* db, void* workspace,
+                  long long workspace_bytes, hipStream_t stream);
+long long nu_colsum_workspace_bytes(int ncols);
+int nu_colsum(const float* A, int lda, int P, int ncols, float* out, int accumulate, void* workspace,
+              long long workspace_bytes, hipStream_t stream);
+/* D = w[col] * softplus'(H): seed of the reverse sweep of SDFNetwork.gradient (field.py:158-170) */
+int nu_rowscale_dsp(const float* H, int ldh, int P, int K, const float* w, float* D, int ldd, hipStream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Encodings
+ * --------------------------------------------------------------------------------------------------------- */
+/* get_embedder(6,3) of the SDF input (field.py:14-61, :133-136): E[P,64], skip-concat slot of U4[P,256], x-slot of YX */
+int nu_sdf_embed(const float* pt, int pt_ld, int P, float* E, float* U4, float* YX, hipStream_t stream);
+/* n = J_emb^T (G0 + Gs): last step of d sdf / d x (field.py:163-170);  q0 = J_emb nbar: first step of its adjoint */
+int nu_embed_jt(const float* E, const float* G0, int ldg0, const float* Gs, int ldgs, int P, float* n, hipStream_t stream);
+int nu_embed_j(const float* E, const float* nbar, int P, float* Q0, float* Q4, hipStream_t stream);
+/* integrated directional encoding, 72-d (utils/ref_utils.py:84-114) and its gradient */
+int nu_ide(const float* dirs, const float* kappa_inv, int P, float* out, int ldo, hipStream_t stream);
+int nu_ide_bwd(const float* dirs, const float* kappa_inv, const float* gout, int ldg, int P, float* ddirs,
+               float* dkappa, hipStream_t stream);
+/* inputs of the four light predictors (field.py:636-682, :686-689, :717) and the backward to normals / roughness */
+int nu_shade_encode_fwd(const float* nrm, const float* pt, int pt_ld, const float* E, const float* Mraw, int ldm, int P,
+                        float* OLin, float* ILin, float* IWin, float* RLin, float* SD, hipStream_t stream);
+int nu_shade_encode_bwd(const float* nrm, const float* pt, int pt_ld, const float* SD, const float* dOLin,
+                        const float* dILin, const float* dNoV, int P, float* dn, float* dMraw, int ldm,
+                        hipStream_t stream);
+/* NeRF++ inputs (x/|x|, 1/|x|) L=10 and view -d L=4 (renderer_zerothick.py:687-690; field.py:266-269) */
+int nu_nerf_embed(const float* pt, int pt_ld, int P, float* E4, float* U5, float* V, hipStream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * render_core (renderer_zerothick.py:725-820)
+ * --------------------------------------------------------------------------------------------------------- */
+/* mid-points, section lengths, inner mask |x| <= 1 and its compaction (:730-736, boolean-mask gathers :748-767) */
+int nu_partition_count(const float* o, const float* d, const float* z, int R, int S, int* cnt_in, int* off_in,
+                       int* totals, hipStream_t stream);
+int nu_partition_write(const float* o, const float* d, const float* z, int R, int S, const int* off_in, float* pt_in,
+                       int* idx_in, float* pt_out, int* idx_out, unsigned char* inner_rm, hipStream_t stream);
+/* compute_sdf_alpha (:657-685) + eikonal term (:769) */
+int nu_neus_alpha_fwd(const float* YX, int ldy, const float* nrm, const float* pt, const int* idx, int P,
+                      const float* variance, float anneal, float* alpha_rm, float* gerr, hipStream_t stream);
+int nu_neus_alpha_bwd(const float* YX, int ldy, const float* nrm, const float* pt, const int* idx, int P,
+                      const float* variance, float anneal, const float* dalpha_rm, const float* dgerr,
+                      const float* dn_shade, float* dYX, int lddy, float* nbar, float* dvar, hipStream_t stream);
+/* density_activation + colour activation of compute_density_alpha (:515-516, :691-692) */
+int nu_nerf_act_fwd(const float* sigma, int lds, const float* rgb, int ldr, const float* pt, const int* idx, int P,
+                    float* alpha_rm, float* color_rm, hipStream_t stream);
+int nu_nerf_act_bwd(const float* sigma, int lds, const float* rgb, int ldr, const float* pt, const int* idx, int P,
+                    const float* dalpha_rm, const float* dcolor_rm, float* dsigma, int ldds, float* drgb, int lddr,
+                    hipStream_t stream);
+/* BRDF mix, split-sum LUT lookup (nvdiffrast dr.texture, field.py:719-722), Fresnel, sRGB (field.py:698-740) */
+int nu_shade_combine_fwd(const float* Mraw, int ldm, const float* OLo, const float* ILo, const float* IWo,
+                         const float* RLo, const float* SD, const float* lut, const int* idx, int P, float exp_max,
+                         float* color_rm, float* aux, hipStream_t stream);
+int nu_shade_combine_bwd(const float* Mraw, int ldm, const float* OLo, const float* ILo, const float* IWo,
+                         const float* RLo, const float* SD, const float* lut, const int* idx, int P, float exp_max,
+                         const float* dcolor_rm, float* dMraw, float* dOLo, float* dILo, float* dIWo, float* dRLo,
+                         float* dNoV, hipStream_t stream);
+/* front-to-back composite incl. the background-only composite (:773-779) */
+int nu_composite_fwd(const float* alpha, const float* color, const unsigned char* inner, int R, int S, float* weights,
+                     float* rgb, float* acc, float* rgb_bg, hipStream_t stream);
+int nu_composite_bwd(const float* alpha, const float* color, const unsigned char* inner, int R, int S,
+                     const float* drgb, const float* dacc, const float* drgb_bg, float* dalpha, float* dcolor,
+                     hipStream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Hierarchical sampler (renderer_zerothick.py:572-612, :525-570; field.py:468-498, :501-554)
+ * --------------------------------------------------------------------------------------------------------- */
+int nu_sample_coarse(const float* o, const float* d, const float* near, const float* far, const float* lin,
+                     const float* lower, const float* upper, const float* u1, const float* u2, int R, int Nc, int Nbg,
+                     float* zc, float* zbg, float* X, hipStream_t stream);
+int nu_upsample(const float* o, const float* d, const float* z, const float* sdf, int R, int sn, const float* variance,
+                float inv_s_cap, int use_variance, const float* uvals, int n_new, float* z_new, float* Xn,
+                hipStream_t stream);
+int nu_probe_weights(const float* o, const float* d, const float* z, const float* sdf, int R, int sn,
+                     const float* variance, const float* uvals, int n_new, float* z_new, float* Xn, float* wsum,
+                     hipStream_t stream);
+int nu_merge_sorted(const float* z, const float* sdf, int sn, const float* zn, const float* sdfn, int nn, int R,
+                    float* zo, float* sdfo, hipStream_t stream);
+int nu_concat_cols(const float* A, int a, const float* B, int b, int R, float* out, hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NU_NERF_H */

@@ -9,22 +9,7 @@
 // ------------------------------------------------------------------------------------------------
 // pack / unpack
 // ------------------------------------------------------------------------------------------------
-struct NuPackDesc {
-    const float* v;      // [N, K] weight_v (or plain weight)
-    const float* g;      // [N] weight_g, or null for a plain Linear
-    const int* colmap;   // [K] original column -> packed column, or null (identity)
-    float* Wp;           // packed [>=N][Kp] (row stride Kp), forward operand
-    float* WpT;          // packed transpose [>=Kp][ldT]: WpT[kp*ldT + n], or null
-    const float* dWp;    // gradient in packed layout [N][ldd]
-    long long dv_off;    // offsets (floats) into the flat gradient buffer
-    long long dg_off;    // (-1: none)
-    const float* bias;   // [N] bias parameter (or null)
-    float* bias_p;       // packed bias destination (or null): bias_p[n] = bias[n]
-    float scale;         // extra factor folded into the packed weight (1/sqrt(2) at the SDF skip)
-    int N, K, Kp, ldT, ldd;
-    int row_begin;       // first global row of this descriptor in the batched launch
-    int col_off;         // added to every packed column index (block-diagonal heads)
-};
+// NuPackDesc: see include/nu_nerf.h
 
 static __device__ inline int nu_find_desc(const NuPackDesc* __restrict__ d, int nd, int row) {
     int lo = 0, hi = nd - 1;

@@ -6,10 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define NU_OK 0
-#define NU_ERR_ARG (-1)
-#define NU_ERR_LAUNCH (-2)
-#define NU_ERR_WORKSPACE (-3)
+#include "nu_nerf.h"  // public C ABI: error codes, NuGemmNT / NuGemmTN / NuPackDesc
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
