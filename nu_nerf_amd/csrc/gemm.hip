@@ -4,6 +4,7 @@
 //   network/field.py:133-150 (SDFNetwork.forward), :158-170 (.gradient), :265-289 (NeRFNetwork),
 //   :371-408 (make_predictor stacks) and their autograd backward / double backward.
 #include "gemm.h"
+#include <stdlib.h>
 
 #define TBM 128
 #define TBN 128
@@ -11,11 +12,34 @@
 #define NT_LDS 36   // padded row stride (floats): 36*r mod 64 hits every 16-B slot once per 16 rows
 
 // ------------------------------------------------------------------------------------------------
-// NT kernel
+// NT kernel: persistent workgroups walk the output tiles; the first k-tile of the NEXT output tile is
+// prefetched into registers under the last MFMAs of the current one, so only the very first tile of a
+// workgroup exposes global-load latency.  Epilogue goes through a wave-private LDS transpose so that
+// global stores (and the aux loads of the derivative epilogues) are 16 B per lane, 256 B per row.
 // ------------------------------------------------------------------------------------------------
+#define EPI_LDS 68  // row stride (floats) of the per-wave 64x64 epilogue scratch
+
+template <int EPI>
+static __device__ inline float nu_epi_apply(float v, float bv, float h, float d, float ca, float& out2) {
+    out2 = 0.f;
+    if (EPI == NU_EPI_BIAS_NONE) return v + bv;
+    if (EPI == NU_EPI_BIAS_RELU) return fmaxf(v + bv, 0.0f);
+    if (EPI == NU_EPI_BIAS_SOFTPLUS) return nu_softplus100_fast(v + bv);
+    if (EPI == NU_EPI_MUL_DRELU) return h > 0.0f ? v : 0.0f;
+    if (EPI == NU_EPI_MUL_DSP) return v * (1.0f - nu_exp_m100(h));
+    if (EPI == NU_EPI_Q_SP) {
+        const float e = nu_exp_m100(h);   // sp' = 1 - e ; sp''/sp' = 100 e
+        out2 = v * d * 100.0f * e;
+        return v * (1.0f - e);
+    }
+    if (EPI == NU_EPI_B_SP) return v * (1.0f - nu_exp_m100(h)) + ca;
+    if (EPI == NU_EPI_B_RELU) return (h > 0.0f ? v : 0.0f) + ca;
+    return v;
+}
+
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NuGemmNT g) {
-    __shared__ __attribute__((aligned(16))) float smem[2][2][TBM * NT_LDS];
+    __shared__ __attribute__((aligned(16))) float smem[2][2][TBM * NT_LDS];   // 73728 B; epilogue scratch aliases it
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -23,87 +47,68 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NuGemmNT g) {
     const int wr = wid >> 1, wc = wid & 1;
     const int z = blockIdx.z;
     const int ntn = (g.N + TBN - 1) / TBN;
-    const int mt = blockIdx.x / ntn, nt = blockIdx.x - mt * ntn;
-    const int m0 = mt * TBM, n0 = nt * TBN;
+    const int mtiles = (g.M + TBM - 1) / TBM;
+    // slot space grouped so that the ntn column tiles of one row tile sit 8 slots apart (same XCD under
+    // round-robin placement: the second reader of an A tile hits that XCD's L2 -- speed only)
+    const int nslots = ((mtiles + 7) / 8) * 8 * ntn;
 
     const float* __restrict__ A = g.A + (long long)z * g.sA;
     const float* __restrict__ B = g.B + (long long)z * g.sB;
-
-    // global->register staging: 4 float4 of A and 4 of B per thread per k-tile
     const int c4 = tid & 7;
     const int r0 = tid >> 3;
-    const float* ap[4];
-    const float* bp[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int ra = m0 + r0 + 32 * i;
-        ra = ra < g.M ? ra : g.M - 1;
-        ap[i] = A + (long long)ra * g.lda + 4 * c4;
-        bp[i] = B + (long long)(n0 + r0 + 32 * i) * g.ldb + 4 * c4;
-    }
-    f32x4 ra4[4], rb4[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        ra4[i] = *reinterpret_cast<const f32x4*>(ap[i]);
-        rb4[i] = *reinterpret_cast<const f32x4*>(bp[i]);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        *reinterpret_cast<f32x4*>(&smem[0][0][(r0 + 32 * i) * NT_LDS + 4 * c4]) = ra4[i];
-        *reinterpret_cast<f32x4*>(&smem[0][1][(r0 + 32 * i) * NT_LDS + 4 * c4]) = rb4[i];
-    }
-    __syncthreads();
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
     const int nk = g.K / TBK;
     const int li = lane & 31, lh = lane >> 5;
     const int a_off = (wr * 64 + li) * NT_LDS + 4 * lh;
     const int b_off = (wc * 64 + li) * NT_LDS + 4 * lh;
 
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                ra4[i] = *reinterpret_cast<const f32x4*>(ap[i] + (kt + 1) * TBK);
-                rb4[i] = *reinterpret_cast<const f32x4*>(bp[i] + (kt + 1) * TBK);
-            }
-        }
-        const float* As = smem[cur][0];
-        const float* Bs = smem[cur][1];
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            f32x4 a0 = *reinterpret_cast<const f32x4*>(&As[a_off + kk * 8]);
-            f32x4 a1 = *reinterpret_cast<const f32x4*>(&As[a_off + 32 * NT_LDS + kk * 8]);
-            f32x4 b0 = *reinterpret_cast<const f32x4*>(&Bs[b_off + kk * 8]);
-            f32x4 b1 = *reinterpret_cast<const f32x4*>(&Bs[b_off + 32 * NT_LDS + kk * 8]);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b0[e], acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b1[e], acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b0[e], acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b1[e], acc[1][1], 0, 0, 0);
-            }
-        }
-        if (kt + 1 < nk) {
-            const int nxt = cur ^ 1;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                *reinterpret_cast<f32x4*>(&smem[nxt][0][(r0 + 32 * i) * NT_LDS + 4 * c4]) = ra4[i];
-                *reinterpret_cast<f32x4*>(&smem[nxt][1][(r0 + 32 * i) * NT_LDS + 4 * c4]) = rb4[i];
-            }
-        }
-        __syncthreads();
-    }
+    auto slot_tile = [&](int j, int& mt, int& nt) -> bool {
+        const int grp = j / (8 * ntn);
+        const int rem = j - grp * 8 * ntn;
+        nt = rem >> 3;
+        mt = grp * 8 + (rem & 7);
+        return mt < mtiles;
+    };
+    auto next_valid = [&](int j, int& mt, int& nt) -> int {
+        while (j < nslots && !slot_tile(j, mt, nt)) j += gridDim.x;
+        return j;
+    };
 
-    // ---- epilogue ----
+    int mt = 0, nt = 0;
+    int j = next_valid(blockIdx.x, mt, nt);
+    if (j >= nslots) return;
+
+    const float* ap[4];
+    const float* bp[4];
+    f32x4 ra4[4], rb4[4];
+    auto set_ptrs = [&](int mt_, int nt_) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int ra = mt_ * TBM + r0 + 32 * i;
+            ra = ra < g.M ? ra : g.M - 1;
+            ap[i] = A + (long long)ra * g.lda + 4 * c4;
+            bp[i] = B + (long long)(nt_ * TBN + r0 + 32 * i) * g.ldb + 4 * c4;
+        }
+    };
+    auto load_regs = [&](int koff) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ra4[i] = *reinterpret_cast<const f32x4*>(ap[i] + koff);
+            rb4[i] = *reinterpret_cast<const f32x4*>(bp[i] + koff);
+        }
+    };
+    auto store_regs = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<f32x4*>(&smem[buf][0][(r0 + 32 * i) * NT_LDS + 4 * c4]) = ra4[i];
+            *reinterpret_cast<f32x4*>(&smem[buf][1][(r0 + 32 * i) * NT_LDS + 4 * c4]) = rb4[i];
+        }
+    };
+
+    set_ptrs(mt, nt);
+    load_regs(0);
+    store_regs(0);
+    __syncthreads();
+
     float* __restrict__ C = g.C + (long long)z * g.sC;
     float* __restrict__ C2 = g.C2 ? g.C2 + (long long)z * g.sC2 : nullptr;
     const float* __restrict__ bias = g.bias ? g.bias + (long long)z * g.sBias : nullptr;
@@ -112,57 +117,126 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NuGemmNT g) {
     const float* __restrict__ Cadd = g.Cadd ? g.Cadd + (long long)z * g.sCadd : nullptr;
     const int zero_to = g.zero_to > g.N ? g.zero_to : g.N;
     const int act_cols = g.act_cols > 0 ? g.act_cols : 0x7fffffff;
+    constexpr bool kNeedH = (EPI == NU_EPI_MUL_DRELU || EPI == NU_EPI_MUL_DSP || EPI == NU_EPI_Q_SP ||
+                             EPI == NU_EPI_B_SP || EPI == NU_EPI_B_RELU);
+    constexpr bool kNeedD = (EPI == NU_EPI_Q_SP);
+    constexpr bool kNeedAdd = (EPI == NU_EPI_B_SP || EPI == NU_EPI_B_RELU);
+    constexpr bool kBias = (EPI <= NU_EPI_BIAS_SOFTPLUS);
+    // 16-byte vector path needs every touched matrix 16-B aligned with ld % 4 == 0 (wave-uniform test)
+    bool vec_ok = (((uintptr_t)C & 15) == 0) && ((g.ldc & 3) == 0);
+    if (kNeedH) vec_ok = vec_ok && (((uintptr_t)H & 15) == 0) && ((g.ldh & 3) == 0);
+    if (kNeedD) vec_ok = vec_ok && (((uintptr_t)D & 15) == 0) && ((g.ldd & 3) == 0) && (((uintptr_t)C2 & 15) == 0) && ((g.ldc2 & 3) == 0);
+    if (kNeedAdd) vec_ok = vec_ok && (((uintptr_t)Cadd & 15) == 0) && ((g.ldadd & 3) == 0);
 
+    while (true) {
+        int mtn = 0, ntnx = 0;
+        const int jn = next_valid(j + gridDim.x, mtn, ntnx);
+        const bool has_next = jn < nslots;
+        const int m0 = mt * TBM, n0 = nt * TBN;
+
+        f32x16 acc[2][2];
 #pragma unroll
-    for (int tn = 0; tn < 2; ++tn) {
-        const int col = n0 + wc * 64 + tn * 32 + li;
-        if (col >= zero_to) continue;
-        const bool live = col < g.N;
-        float bv = 0.0f;
-        if (EPI <= NU_EPI_BIAS_SOFTPLUS) bv = (live && bias) ? bias[col] : 0.0f;
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int tm = 0; tm < 2; ++tm) {
+            for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wr * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.0f;
+
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            if (kt + 1 < nk) {
+                load_regs((kt + 1) * TBK);
+            } else if (has_next) {
+                set_ptrs(mtn, ntnx);
+                load_regs(0);
+            }
+            const float* As = smem[cur][0];
+            const float* Bs = smem[cur][1];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                f32x4 a0 = *reinterpret_cast<const f32x4*>(&As[a_off + kk * 8]);
+                f32x4 a1 = *reinterpret_cast<const f32x4*>(&As[a_off + 32 * NT_LDS + kk * 8]);
+                f32x4 b0 = *reinterpret_cast<const f32x4*>(&Bs[b_off + kk * 8]);
+                f32x4 b1 = *reinterpret_cast<const f32x4*>(&Bs[b_off + 32 * NT_LDS + kk * 8]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b0[e], acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b1[e], acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b0[e], acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b1[e], acc[1][1], 0, 0, 0);
+                }
+            }
+            if (kt + 1 < nk) store_regs(cur ^ 1);
+            __syncthreads();
+        }
+
+        // ---- epilogue: accumulators -> wave-private LDS scratch -> row-contiguous float4 ----
+        float* scr = &smem[0][0][0] + wid * (64 * EPI_LDS);
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    scr[(tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * EPI_LDS + tn * 32 + li] = acc[tm][tn][r];
+        const int colq = (lane & 15) * 4;
+        const int gcol = n0 + wc * 64 + colq;
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (kBias && bias) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bv[e] = (gcol + e < g.N) ? bias[gcol + e] : 0.f;
+        }
+        if (gcol < zero_to) {
+            const bool full = vec_ok && (gcol + 3 < g.N) && (gcol + 3 < act_cols || gcol >= act_cols);
+#pragma unroll 4
+            for (int i = 0; i < 16; ++i) {
+                const int rl = i * 4 + (lane >> 4);
+                const int row = m0 + wr * 64 + rl;
+                const f32x4 v4 = *reinterpret_cast<const f32x4*>(&scr[rl * EPI_LDS + colq]);
                 if (row >= g.M) continue;
-                float v = g.alpha * acc[tm][tn][r];
-                float out = 0.0f, out2 = 0.0f;
-                if (live && EPI >= NU_EPI_MUL_DRELU && EPI != NU_EPI_PLAIN && col >= act_cols) {
-                    out = v;
-                } else if (live) {
-                    if (EPI == NU_EPI_BIAS_NONE) {
-                        out = v + bv;
-                    } else if (EPI == NU_EPI_BIAS_RELU) {
-                        out = fmaxf(v + bv, 0.0f);
-                    } else if (EPI == NU_EPI_BIAS_SOFTPLUS) {
-                        out = nu_softplus100(v + bv);
-                    } else if (EPI == NU_EPI_MUL_DRELU) {
-                        float h = H[(long long)row * g.ldh + col];
-                        out = h > 0.0f ? v : 0.0f;
-                    } else if (EPI == NU_EPI_MUL_DSP) {
-                        float h = H[(long long)row * g.ldh + col];
-                        out = v * nu_softplus100_grad_from_h(h);
-                    } else if (EPI == NU_EPI_Q_SP) {
-                        float h = H[(long long)row * g.ldh + col];
-                        float sp = nu_softplus100_grad_from_h(h);
-                        float d = D[(long long)row * g.ldd + col];  // delta = gbar * sp'
-                        out = v * sp;
-                        out2 = v * d * 100.0f * expf(-100.0f * h);  // sp''/sp' = beta * (1 - sp')
-                    } else if (EPI == NU_EPI_B_SP) {
-                        float h = H[(long long)row * g.ldh + col];
-                        out = v * nu_softplus100_grad_from_h(h) + Cadd[(long long)row * g.ldadd + col];
-                    } else if (EPI == NU_EPI_B_RELU) {
-                        float h = H[(long long)row * g.ldh + col];
-                        out = (h > 0.0f ? v : 0.0f) + Cadd[(long long)row * g.ldadd + col];
-                    } else {
-                        out = v;
+                if (full) {
+                    f32x4 h4 = {0.f, 0.f, 0.f, 0.f}, d4 = h4, c4v = h4, o4, o24;
+                    const bool plain = gcol >= act_cols;
+                    if (kNeedH && !plain) h4 = *reinterpret_cast<const f32x4*>(H + (long long)row * g.ldh + gcol);
+                    if (kNeedD && !plain) d4 = *reinterpret_cast<const f32x4*>(D + (long long)row * g.ldd + gcol);
+                    if (kNeedAdd && !plain) c4v = *reinterpret_cast<const f32x4*>(Cadd + (long long)row * g.ldadd + gcol);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float o2;
+                        const float v = g.alpha * v4[e];
+                        o4[e] = (kNeedH && plain) ? v : nu_epi_apply<EPI>(v, bv[e], h4[e], d4[e], c4v[e], o2);
+                        o24[e] = (kNeedH && plain) ? 0.f : o2;
+                    }
+                    *reinterpret_cast<f32x4*>(C + (long long)row * g.ldc + gcol) = o4;
+                    if (kNeedD) *reinterpret_cast<f32x4*>(C2 + (long long)row * g.ldc2 + gcol) = o24;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int col = gcol + e;
+                        if (col >= zero_to) continue;
+                        float out = 0.f, out2 = 0.f;
+                        if (col < g.N) {
+                            const float v = g.alpha * v4[e];
+                            if (kNeedH && col >= act_cols) {
+                                out = v;
+                            } else {
+                                const float h = kNeedH ? H[(long long)row * g.ldh + col] : 0.f;
+                                const float d = kNeedD ? D[(long long)row * g.ldd + col] : 0.f;
+                                const float ca = kNeedAdd ? Cadd[(long long)row * g.ldadd + col] : 0.f;
+                                out = nu_epi_apply<EPI>(v, bv[e], h, d, ca, out2);
+                            }
+                        }
+                        C[(long long)row * g.ldc + col] = out;
+                        if (kNeedD) C2[(long long)row * g.ldc2 + col] = out2;
                     }
                 }
-                C[(long long)row * g.ldc + col] = out;
-                if (EPI == NU_EPI_Q_SP) C2[(long long)row * g.ldc2 + col] = out2;
             }
         }
+        if (!has_next) break;
+        __syncthreads();   // every wave is done with the scratch
+        store_regs(0);
+        __syncthreads();
+        j = jn; mt = mtn; nt = ntnx;
     }
 }
 
@@ -172,9 +246,14 @@ int nu_gemm_nt_launch(const NuGemmNT& g, hipStream_t stream) {
     if ((g.lda & 3) || (g.ldb & 3)) return NU_ERR_ARG;
     if (((uintptr_t)g.A & 15) || ((uintptr_t)g.B & 15)) return NU_ERR_ARG;
     const int ntn = nu_cdiv(g.N, TBN);
-    const long long nblk = (long long)nu_cdiv(g.M, TBM) * ntn;
-    if (nblk > 0x7fffffffLL) return NU_ERR_ARG;
-    dim3 grid((unsigned)nblk, 1, g.groups > 0 ? g.groups : 1), block(256);
+    const long long nslots = (long long)nu_rup(nu_cdiv(g.M, TBM), 8) * ntn;
+    if (nslots > 0x7fffffffLL) return NU_ERR_ARG;
+    const int groups = g.groups > 0 ? g.groups : 1;
+    // persistent: 2 workgroups per CU (256 CUs) shared over the groups, a multiple of 8 so the XCD grouping holds
+    static const int grid_target = getenv("NU_NT_GRID") ? atoi(getenv("NU_NT_GRID")) : 512;
+    long long per = nu_rup(nu_cdiv(grid_target, groups), 8);
+    if (per > nslots) per = nslots;
+    dim3 grid((unsigned)per, 1, groups), block(256);
     switch (g.epi) {
 #define NU_CASE(E) case E: hipLaunchKernelGGL(gemm_nt_kernel<E>, grid, block, 0, stream, g); break;
         NU_CASE(NU_EPI_BIAS_NONE)

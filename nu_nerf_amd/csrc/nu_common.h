@@ -30,6 +30,18 @@ static __device__ inline float nu_softplus100_grad_from_h(float h) { return -exp
 
 static __device__ inline float nu_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// Hardware-transcendental variants for the GEMM epilogues (v_exp_f32 / v_log_f32, ~1e-6 relative):
+// the epilogue touches every hidden activation, so libm-precise expf/log1pf there costs as much as the MFMAs.
+static __device__ inline float nu_softplus100_fast(float x) {
+    const float bx = 100.0f * x;
+    const float t = __expf(fminf(bx, 20.0f));
+    // log1p(t): series below 1e-3 (|err| < t^4/4), hardware log above
+    const float small = t * (1.0f - t * (0.5f - t * (1.0f / 3.0f)));
+    const float l = t < 1e-3f ? small : __logf(1.0f + t);
+    return bx > 20.0f ? x : l * 0.01f;
+}
+static __device__ inline float nu_exp_m100(float h) { return __expf(-100.0f * h); }   // = 1 - softplus'(a) given h
+
 // sRGB transfer (reference: utils/raw_utils.py:5-17). eps = FLT_EPSILON.
 static __device__ inline float nu_linear_to_srgb(float x) {
     const float eps = 1.1920928955078125e-07f;
