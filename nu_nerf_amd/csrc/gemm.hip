@@ -37,7 +37,7 @@ static __device__ inline float nu_epi_apply(float v, float bv, float h, float d,
     return v;
 }
 
-template <int EPI>
+template <int EPI, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NuGemmNT g) {
     __shared__ __attribute__((aligned(16))) float smem[2][2][TBM * NT_LDS];   // 73728 B; epilogue scratch aliases it
 
@@ -144,11 +144,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NuGemmNT g) {
 
         for (int kt = 0; kt < nk; ++kt) {
             const int cur = kt & 1;
-            if (kt + 1 < nk) {
-                load_regs((kt + 1) * TBK);
-            } else if (has_next) {
-                set_ptrs(mtn, ntnx);
-                load_regs(0);
+            if (ABL != 1) {   // ABL 1: no global loads after the first tile (timing-only build)
+                if (kt + 1 < nk) {
+                    load_regs((kt + 1) * TBK);
+                } else if (has_next) {
+                    set_ptrs(mtn, ntnx);
+                    load_regs(0);
+                }
             }
             const float* As = smem[cur][0];
             const float* Bs = smem[cur][1];
@@ -158,6 +160,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NuGemmNT g) {
                 f32x4 a1 = *reinterpret_cast<const f32x4*>(&As[a_off + 32 * NT_LDS + kk * 8]);
                 f32x4 b0 = *reinterpret_cast<const f32x4*>(&Bs[b_off + kk * 8]);
                 f32x4 b1 = *reinterpret_cast<const f32x4*>(&Bs[b_off + 32 * NT_LDS + kk * 8]);
+                if (ABL == 2) {   // ABL 2: no MFMA (operands kept live) -- data-path-only timing build
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        acc[0][0][e] += a0[e] * b0[e]; acc[0][1][e] += a0[e] * b1[e];
+                        acc[1][0][e] += a1[e] * b0[e]; acc[1][1][e] += a1[e] * b1[e];
+                    }
+                } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b0[e], acc[0][0], 0, 0, 0);
@@ -165,11 +174,18 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NuGemmNT g) {
                     acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b0[e], acc[1][0], 0, 0, 0);
                     acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b1[e], acc[1][1], 0, 0, 0);
                 }
+                }
             }
             if (kt + 1 < nk) store_regs(cur ^ 1);
             __syncthreads();
         }
 
+        if (ABL == 3) {   // ABL 3: no epilogue (accumulators kept live through one store)
+            if (!has_next) { if (acc[0][0][0] + acc[0][1][1] + acc[1][0][2] + acc[1][1][3] == 123.456f) g.C[0] = 1.f; break; }
+            __syncthreads(); store_regs(0); __syncthreads();
+            j = jn; mt = mtn; nt = ntnx;
+            continue;
+        }
         // ---- epilogue: accumulators -> wave-private LDS scratch -> row-contiguous float4 ----
         float* scr = &smem[0][0][0] + wid * (64 * EPI_LDS);
 #pragma unroll
@@ -254,6 +270,13 @@ int nu_gemm_nt_launch(const NuGemmNT& g, hipStream_t stream) {
     long long per = nu_rup(nu_cdiv(grid_target, groups), 8);
     if (per > nslots) per = nslots;
     dim3 grid((unsigned)per, 1, groups), block(256);
+    static const int abl = getenv("NU_NT_ABL") ? atoi(getenv("NU_NT_ABL")) : 0;
+    if (abl && g.epi == NU_EPI_PLAIN) {
+        if (abl == 1) hipLaunchKernelGGL((gemm_nt_kernel<NU_EPI_PLAIN, 1>), grid, block, 0, stream, g);
+        if (abl == 2) hipLaunchKernelGGL((gemm_nt_kernel<NU_EPI_PLAIN, 2>), grid, block, 0, stream, g);
+        if (abl == 3) hipLaunchKernelGGL((gemm_nt_kernel<NU_EPI_PLAIN, 3>), grid, block, 0, stream, g);
+        return nu_launch_status();
+    }
     switch (g.epi) {
 #define NU_CASE(E) case E: hipLaunchKernelGGL(gemm_nt_kernel<E>, grid, block, 0, stream, g); break;
         NU_CASE(NU_EPI_BIAS_NONE)
@@ -513,4 +536,31 @@ extern "C" int nu_wgrad(const NuGemmTN* gin, float* dW, int ldw, long long sW, f
         if (rc == NU_OK && db) rc = nu_bias_slab_reduce_launch(g.bias_slab + z * bias_per, g.S, g.N1, db + z * sDb, 0, stream);
     }
     return rc;
+}
+
+// development aid: occupancy query for the two GEMM kernels (blocks per CU)
+extern "C" int nu_debug_occupancy(int which) {
+    int n = -1;
+    if (which == 0) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_nt_kernel<NU_EPI_BIAS_SOFTPLUS>, 256, 0);
+    else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_tn_kernel, 256, 0);
+    return n;
+}
+
+// development aid: bare fp32-MFMA issue loop (no memory) -- what the matrix pipe delivers at the clock it holds
+__global__ __launch_bounds__(256) void mfma_peak_kernel(float* out, int iters) {
+    f32x16 a0 = {}, a1 = {}, a2 = {}, a3 = {};
+    float x = (float)threadIdx.x * 1e-3f, y = 1.0f + (float)blockIdx.x * 1e-6f;
+    for (int i = 0; i < iters; ++i) {
+        a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(y, x, a1, 0, 0, 0);
+        a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, x, a2, 0, 0, 0);
+        a3 = __builtin_amdgcn_mfma_f32_32x32x2f32(y, y, a3, 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int r = 0; r < 16; ++r) s += a0[r] + a1[r] + a2[r] + a3[r];
+    if (s == 123.456f) out[0] = s;
+}
+extern "C" int nu_debug_mfma_peak(float* out, int blocks, int iters, hipStream_t stream) {
+    hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, stream, out, iters);
+    return nu_launch_status();
 }

@@ -335,7 +335,7 @@ class Stage1Engine:
 
     def _wgrad(self, A0, lda0, B0, ldb0, P, N1, N2, dW, ldw, db, A1, lda1, B1, ldb1, groups, sA0, sB0, sA1, sB1, sW, sDb):
         tiles = ((N1 + 127) // 128) * ((N2 + 127) // 128) * groups
-        S = max(1, min((P + 255) // 256, max(1, 1024 // tiles)))
+        S = max(1, min((P + 255) // 256, max(1, 512 // tiles)))   # 2 workgroups per CU; fewer, larger slabs
         nbytes = self.lib.nu_wgrad_workspace_bytes(N1, N2, S, groups)
         ws = self.workspace(nbytes)
         g = GemmTN(A0, lda0, B0, ldb0, A1, lda1, B1, ldb1, P, N1, N2, 0, 0, S, groups, sA0, sB0, sA1, sB1, 0, 0)
