@@ -189,6 +189,21 @@ int nu_merge_sorted(const float* z, const float* sdf, int sn, const float* zn, c
                     float* zo, float* sdfo, hipStream_t stream);
 int nu_concat_cols(const float* A, int a, const float* B, int b, int R, float* out, hipStream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * Mesh closest-hit tracing (stage 2): replaces the OptiX GAS build (network/tracing_optix.py:20-23, :142-146), the
+ * launch/IO wrapper (:74-117, :154-158) and the device programs of cuda/triangle.cu:48-99.
+ *   rays [N,6] = (origin, direction); hit[N] = 1.0/0.0; idx[N] = face id of the closest hit with tmin < t < tmax, or
+ *   10000000 on a miss; ties in t -> lowest face id.  `bvh` is a caller-owned buffer of nu_lbvh_bytes(n_faces) bytes.
+ * --------------------------------------------------------------------------------------------------------- */
+long long nu_lbvh_bytes(int n_faces);
+int nu_lbvh_build(const float* V, int n_verts, const int* F, int n_faces, void* bvh, long long bvh_bytes,
+                  hipStream_t stream);
+int nu_lbvh_trace(const void* bvh, int n_faces, const float* rays, int N, float tmin, float tmax, float* hit, int* idx,
+                  float* t_out, hipStream_t stream);
+/* O(N*F) sweep with the same ray/triangle test (cross-check, tiny meshes) */
+int nu_brute_trace(const float* V, const int* F, int n_faces, const float* rays, int N, float tmin, float tmax,
+                   float* hit, int* idx, float* t_out, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

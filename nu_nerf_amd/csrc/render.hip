@@ -20,17 +20,23 @@
 // gives the reference) for both the inner and the outer set.
 // ------------------------------------------------------------------------------------------------
 static __device__ inline float nu_norm3(const float* x) {
-    return sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(x[0], x[0]), __fmul_rn(x[1], x[1])), __fmul_rn(x[2], x[2])));
+#pragma clang fp contract(off)
+    return sqrtf((x[0] * x[0] + x[1] * x[1]) + x[2] * x[2]);
 }
 static __device__ inline void nu_sample_point(const float* __restrict__ zrow, int S, int j, const float* o, const float* d,
                                               float* x, float& dist) {
+    // contraction off + plain operators (HIP's __fmul_rn/__fadd_rn would still fuse): the inner/outer decision
+    // |x| <= 1 should round like the reference's eager ops
+#pragma clang fp contract(off)
     const float z0 = zrow[j];
     if (j + 1 < S) dist = zrow[j + 1] - z0;
     else dist = S >= 2 ? zrow[S - 1] - zrow[S - 2] : 0.f;
-    // explicit (non-FMA) arithmetic: the inner/outer decision |x| <= 1 should round like the reference's eager ops
-    const float mid = __fadd_rn(z0, __fmul_rn(dist, 0.5f));
+    const float mid = z0 + dist * 0.5f;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) x[c] = __fadd_rn(o[c], __fmul_rn(d[c], mid));
+    for (int c = 0; c < 3; ++c) {
+        const float m = d[c] * mid;
+        x[c] = o[c] + m;
+    }
 }
 
 __global__ __launch_bounds__(256) void partition_count_kernel(const float* __restrict__ o, const float* __restrict__ d,

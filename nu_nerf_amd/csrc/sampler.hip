@@ -7,6 +7,9 @@
 //   cat_z_vals   network/renderer_zerothick.py:556-570   (merge by sort + SDF gather)
 #include "nu_common.h"
 
+// sample placement should round like the reference's eager mul/add chains: no FMA contraction in this file
+#pragma clang fp contract(off)
+
 #define NU_SMAX 256  // max samples per ray held in LDS
 
 // coarse z:  z[r,j] = near + (far-near)*lin[j] + (u1[r]-0.5)*2/Nc   (u1 == null => no jitter)
@@ -25,17 +28,29 @@ __global__ __launch_bounds__(256) void sample_coarse_kernel(const float* __restr
     const int r = (int)(i / tot), j = (int)(i - (long long)r * tot);
     const float nr = near[r], fr = far[r];
     if (j < Nc) {
-        float z = __fadd_rn(nr, __fmul_rn(__fsub_rn(fr, nr), lin[j]));
-        if (u1) z = __fadd_rn(z, __fdiv_rn(__fmul_rn(__fsub_rn(u1[r], 0.5f), 2.0f), (float)Nc));
+        const float span = fr - nr;
+        const float sc = span * lin[j];
+        float z = nr + sc;
+        if (u1) {
+            const float tr = (u1[r] - 0.5f) * 2.0f;
+            const float jit = tr / (float)Nc;
+            z = z + jit;
+        }
         zc[(long long)r * Nc + j] = z;
 #pragma unroll
-        for (int c = 0; c < 3; ++c)
-            X[((long long)r * Nc + j) * 3 + c] = __fadd_rn(o[r * 3LL + c], __fmul_rn(d[r * 3LL + c], z));
+        for (int c = 0; c < 3; ++c) {
+            const float m = d[r * 3LL + c] * z;
+            X[((long long)r * Nc + j) * 3 + c] = o[r * 3LL + c] + m;
+        }
     } else {
         const int k = j - Nc;
         float zo = lower[k];
-        if (u2) zo = __fadd_rn(lower[k], __fmul_rn(__fsub_rn(upper[k], lower[k]), u2[(long long)r * Nbg + k]));
-        zbg[(long long)r * Nbg + (Nbg - 1 - k)] = __fadd_rn(__fdiv_rn(fr, zo), __fdiv_rn(1.0f, (float)Nbg));
+        if (u2) {
+            const float w = (upper[k] - lower[k]) * u2[(long long)r * Nbg + k];
+            zo = lower[k] + w;
+        }
+        const float q = fr / zo;
+        zbg[(long long)r * Nbg + (Nbg - 1 - k)] = q + 1.0f / (float)Nbg;
     }
 }
 extern "C" int nu_sample_coarse(const float* o, const float* d, const float* near, const float* far, const float* lin,
@@ -72,9 +87,8 @@ __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__
             const float zz = z[(long long)r * sn + j];
             s_z[w][j] = zz;
             s_s[w][j] = sdf[(long long)r * sn + j];
-            const float x0 = __fadd_rn(oo[0], __fmul_rn(dd[0], zz)), x1 = __fadd_rn(oo[1], __fmul_rn(dd[1], zz)),
-                        x2 = __fadd_rn(oo[2], __fmul_rn(dd[2], zz));
-            s_r[w][j] = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(x0, x0), __fmul_rn(x1, x1)), __fmul_rn(x2, x2)));
+            const float x0 = oo[0] + dd[0] * zz, x1 = oo[1] + dd[1] * zz, x2 = oo[2] + dd[2] * zz;
+            s_r[w][j] = sqrtf((x0 * x0 + x1 * x1) + x2 * x2);
         }
     }
     __syncthreads();
@@ -164,7 +178,7 @@ __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__
         z_new[(long long)r * n_new + k] = zz;
 #pragma unroll
         for (int c = 0; c < 3; ++c)
-            Xn[((long long)r * n_new + k) * 3 + c] = __fadd_rn(oo[c], __fmul_rn(dd[c], zz));
+            Xn[((long long)r * n_new + k) * 3 + c] = oo[c] + dd[c] * zz;
     }
 }
 extern "C" int nu_upsample(const float* o, const float* d, const float* z, const float* sdf, int R, int sn,
