@@ -91,10 +91,17 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    # NU_BENCH_DEVICE / NU_BENCH_BACKEND exist only to rehearse the multi-process path on a one-GPU box (gloo, all ranks on
+    # cuda:0); the driver's runs use one GPU per rank and RCCL ("nccl").
+    dev_index = int(os.environ.get('NU_BENCH_DEVICE', local_rank))
+    torch.cuda.set_device(dev_index)
+    dev = torch.device('cuda', dev_index)
     if world > 1:
-        dist.init_process_group('nccl', device_id=dev)
+        backend = os.environ.get('NU_BENCH_BACKEND', 'nccl')
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus or world == 1, (world, args.gpus)
 
     from nu_nerf_amd.renderer import NeROShapeRenderer
