@@ -188,8 +188,17 @@ def main():
         }
         if ktime is not None:
             tf = ktime['flops'] / max(ktime['seconds'], 1e-12) / 1e12
+            # HBM traffic per launch comes from the committed rocprofv3 PMC passes of this same workload (FETCH_SIZE / WRITE_SIZE
+            # in separate --pmc runs, gfx950 corrections applied by scripts/summarize_pmc.py); null if absent or other workload
+            traffic = None
+            tj = os.path.join(ROOT, 'profiles', 'r01', 'traffic_pmc.json')
+            if os.path.exists(tj) and R == 4096 and world == 1:
+                traffic = json.load(open(tj)).get('gemm_nt_kernel', {}).get('hbm_bytes_per_launch')
             res["roofline"] = {"bound": "mfma", "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                               "frac": tf / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                               "frac": tf / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
+                               "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/r01/traffic_pmc.json)",
+                               "algorithmic_bytes_per_launch": ktime['bytes'] / max(ktime['launches'], 1),
+                               "algorithmic_flops_per_launch": ktime['flops'] / max(ktime['launches'], 1),
                                "kernel": "gemm_nt_kernel<*> (fp32 v_mfma_f32_32x32x2_f32)",
                                "launches": ktime['launches'], "avg_launch_us": 1e6 * ktime['seconds'] / max(ktime['launches'], 1),
                                "gemm_time_share": ktime['seconds'] / elapsed,

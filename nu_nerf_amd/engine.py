@@ -306,7 +306,9 @@ class Stage1Engine:
         L.check(self.lib.nu_gemm_nt_ex(ctypes.byref(g), self.stream()), "nu_gemm_nt_ex")
         if kt is not None:
             e1.record()
-            kt['nt'].append((e0, e1, 2.0 * M * (ntrue or N) * (ktrue or K) * groups))
+            nmat = 1 + (1 if C2 else 0) + (1 if H else 0) + (1 if D else 0) + (1 if Cadd else 0)
+            abytes = 4.0 * groups * (M * (ktrue or K) + M * (ntrue or N) * nmat + N * (ktrue or K))
+            kt['nt'].append((e0, e1, 2.0 * M * (ntrue or N) * (ktrue or K) * groups, abytes))
 
     def begin_kernel_timing(self):
         """Bracket every GEMM launch with HIP events on the launch stream (bench.py's roofline leg)."""
@@ -317,8 +319,9 @@ class Stage1Engine:
         torch.cuda.synchronize(self.dev)
         out = {}
         for key, pre in (('nt', ''), ('tn', 'tn_')):
-            out[pre + 'seconds'] = sum(a.elapsed_time(b) for a, b, _ in kt[key]) * 1e-3
-            out[pre + 'flops'] = sum(f for _, _, f in kt[key])
+            out[pre + 'seconds'] = sum(a.elapsed_time(b) for a, b, _, _ in kt[key]) * 1e-3
+            out[pre + 'flops'] = sum(f for _, _, f, _ in kt[key])
+            out[pre + 'bytes'] = sum(b for _, _, _, b in kt[key])
             out[pre + 'launches'] = len(kt[key])
         return out
 
@@ -331,7 +334,9 @@ class Stage1Engine:
         self._wgrad(A0, lda0, B0, ldb0, P, N1, N2, dW, ldw, db, A1, lda1, B1, ldb1, groups, sA0, sB0, sA1, sB1, sW, sDb)
         if kt is not None:
             e1.record()
-            kt['tn'].append((e0, e1, 2.0 * P * N1 * (n2true or N2) * groups * (2 if A1 else 1)))
+            npair = 2 if A1 else 1
+            kt['tn'].append((e0, e1, 2.0 * P * N1 * (n2true or N2) * groups * npair,
+                             4.0 * groups * (npair * P * (N1 + (n2true or N2)) + N1 * N2)))
 
     def _wgrad(self, A0, lda0, B0, ldb0, P, N1, N2, dW, ldw, db, A1, lda1, B1, ldb1, groups, sA0, sB0, sA1, sB1, sW, sDb):
         tiles = ((N1 + 127) // 128) * ((N2 + 127) // 128) * groups

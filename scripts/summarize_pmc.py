@@ -1,0 +1,26 @@
+"""Summarise rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE collected in separate runs, as MI355X_MICROARCH.md's HBM
+section prescribes) into HBM bytes per launch for the GEMM kernels.  gfx950 correction: FETCH_SIZE counts 128-B
+requests as 64 B for wide coalesced streams -> doubled; units are KiB."""
+import collections, csv, json, sys
+
+def agg(path, name):
+    out = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(path)):
+        if r['Counter_Name'] != name:
+            continue
+        k = 'gemm_nt_kernel' if 'gemm_nt_kernel' in r['Kernel_Name'] else ('gemm_tn_kernel' if 'gemm_tn_kernel' in r['Kernel_Name'] else None)
+        if k:
+            out[k][0] += 1
+            out[k][1] += float(r['Counter_Value'])
+    return out
+
+fetch_csv, write_csv, out_json = sys.argv[1:4]
+f, w = agg(fetch_csv, 'FETCH_SIZE'), agg(write_csv, 'WRITE_SIZE')
+res = {}
+for k in f:
+    n = f[k][0]
+    res[k] = {"launches": n, "fetch_bytes_per_launch": 2.0 * 1024 * f[k][1] / n, "write_bytes_per_launch": 1024 * w[k][1] / max(w[k][0], 1),
+              "note": "FETCH_SIZE x2 (gfx950 128-B request correction), KiB units; separate --pmc passes"}
+    res[k]["hbm_bytes_per_launch"] = res[k]["fetch_bytes_per_launch"] + res[k]["write_bytes_per_launch"]
+json.dump(res, open(out_json, 'w'), indent=1)
+print(json.dumps(res, indent=1))
