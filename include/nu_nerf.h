@@ -130,11 +130,16 @@ int nu_ide(const float* dirs, const float* kappa_inv, int P, float* out, int ldo
 int nu_ide_bwd(const float* dirs, const float* kappa_inv, const float* gout, int ldg, int P, float* ddirs,
                float* dkappa, hipStream_t stream);
 /* inputs of the four light predictors (field.py:636-682, :686-689, :717) and the backward to normals / roughness */
+/* sphere = shader_config.sphere_direction (144-d outer_light input, field.py:641-646, :675-679);
+ * refrac_dim = 3 + 6 * refrac_freq (field.py:590-591) */
 int nu_shade_encode_fwd(const float* nrm, const float* pt, int pt_ld, const float* E, const float* Mraw, int ldm, int P,
-                        float* OLin, float* ILin, float* IWin, float* RLin, float* SD, hipStream_t stream);
-int nu_shade_encode_bwd(const float* nrm, const float* pt, int pt_ld, const float* SD, const float* dOLin,
-                        const float* dILin, const float* dNoV, int P, float* dn, float* dMraw, int ldm,
+                        int sphere, int ld_ol, int refrac_dim, int ld_rl, float* OLin, float* ILin, float* IWin,
+                        float* RLin, float* SD, hipStream_t stream);
+int nu_shade_encode_bwd(const float* nrm, const float* pt, int pt_ld, const float* SD, const float* dOLin, int ld_ol,
+                        int sphere, const float* dILin, const float* dNoV, int P, float* dn, float* dMraw, int ldm,
                         hipStream_t stream);
+/* per-ray mirror query of colour_spec (renderer_zerothick.py:780-781; network/renderer.py:710-725) */
+int nu_spec_encode(const float* dirs, const float* x, int R, int sphere, float* out, int ldo, hipStream_t stream);
 /* NeRF++ inputs (x/|x|, 1/|x|) L=10 and view -d L=4 (renderer_zerothick.py:687-690; field.py:266-269) */
 int nu_nerf_embed(const float* pt, int pt_ld, int P, float* E4, float* U5, float* V, hipStream_t stream);
 
@@ -147,11 +152,14 @@ int nu_partition_count(const float* o, const float* d, const float* z, int R, in
 int nu_partition_write(const float* o, const float* d, const float* z, int R, int S, const int* off_in, float* pt_in,
                        int* idx_in, float* pt_out, int* idx_out, unsigned char* inner_rm, hipStream_t stream);
 /* compute_sdf_alpha (:657-685) + eikonal term (:769) */
+/* also writes max(n.d, 0) into colour channel 3 (the loss_normal integrand of network/renderer.py:693-705) */
 int nu_neus_alpha_fwd(const float* YX, int ldy, const float* nrm, const float* pt, const int* idx, int P,
-                      const float* variance, float anneal, float* alpha_rm, float* gerr, hipStream_t stream);
+                      const float* variance, float anneal, float* alpha_rm, float* gerr, float* color_rm,
+                      hipStream_t stream);
 int nu_neus_alpha_bwd(const float* YX, int ldy, const float* nrm, const float* pt, const int* idx, int P,
                       const float* variance, float anneal, const float* dalpha_rm, const float* dgerr,
-                      const float* dn_shade, float* dYX, int lddy, float* nbar, float* dvar, hipStream_t stream);
+                      const float* dn_shade, const float* dcolor_rm, float* dYX, int lddy, float* nbar, float* dvar,
+                      hipStream_t stream);
 /* density_activation + colour activation of compute_density_alpha (:515-516, :691-692) */
 int nu_nerf_act_fwd(const float* sigma, int lds, const float* rgb, int ldr, const float* pt, const int* idx, int P,
                     float* alpha_rm, float* color_rm, hipStream_t stream);
@@ -166,12 +174,13 @@ int nu_shade_combine_bwd(const float* Mraw, int ldm, const float* OLo, const flo
                          const float* RLo, const float* SD, const float* lut, const int* idx, int P, float exp_max,
                          const float* dcolor_rm, float* dMraw, float* dOLo, float* dILo, float* dIWo, float* dRLo,
                          float* dNoV, hipStream_t stream);
-/* front-to-back composite incl. the background-only composite (:773-779) */
+/* front-to-back composite incl. the background-only composite (:773-779); colour is [R*S,4] = rgb + one auxiliary
+ * channel whose composite goes to aux_sum[R] (normal-orientation loss, network/renderer.py:705) */
 int nu_composite_fwd(const float* alpha, const float* color, const unsigned char* inner, int R, int S, float* weights,
-                     float* rgb, float* acc, float* rgb_bg, hipStream_t stream);
+                     float* rgb, float* acc, float* rgb_bg, float* aux_sum, hipStream_t stream);
 int nu_composite_bwd(const float* alpha, const float* color, const unsigned char* inner, int R, int S,
-                     const float* drgb, const float* dacc, const float* drgb_bg, float* dalpha, float* dcolor,
-                     hipStream_t stream);
+                     const float* drgb, const float* dacc, const float* drgb_bg, const float* daux, float* dalpha,
+                     float* dcolor, hipStream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Hierarchical sampler (renderer_zerothick.py:572-612, :525-570; field.py:468-498, :501-554)

@@ -264,9 +264,52 @@ static __device__ inline void nu_shade_dirs(const float* n, const float* d, floa
     for (int c = 0; c < 3; ++c) r[c] = nov * nh[c] * 2.0f - vh[c];
 }
 
+// Point on the unit sphere seen from p (inside, moved to radius 0.999 when outside) along `dir`
+// (offset_points_to_sphere + get_sphere_intersection + normalize; field.py:447-464, :642-643, :676-677)
+struct NuSph {
+    float s[3];       // unit point on the sphere
+    float pp[3];      // offset origin p'
+    float t, root, snorm;
+};
+static __device__ inline NuSph nu_sph_point(const float* x, const float* dir) {
+    NuSph o;
+    const float xn = sqrtf(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+    const float sc = xn > 0.999f ? 0.999f / xn : 1.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) o.pp[c] = xn > 0.999f ? x[c] / xn * 0.999f : x[c];
+    (void)sc;
+    const float b = o.pp[0] * dir[0] + o.pp[1] * dir[1] + o.pp[2] * dir[2];
+    const float cc = o.pp[0] * o.pp[0] + o.pp[1] * o.pp[1] + o.pp[2] * o.pp[2];
+    o.root = sqrtf(b * b - cc + 1.0f + 1e-6f);
+    o.t = -b + o.root;
+    float sv[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) sv[c] = o.pp[c] + dir[c] * o.t;
+    o.snorm = fmaxf(sqrtf(sv[0] * sv[0] + sv[1] * sv[1] + sv[2] * sv[2]), 1e-12f);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) o.s[c] = sv[c] / o.snorm;
+    return o;
+}
+// cotangent of the unit sphere point -> cotangent of dir
+static __device__ inline void nu_sph_point_bwd(const NuSph& o, const float* dir, const float* ds_unit, float* ddir) {
+    const float dotp = ds_unit[0] * o.s[0] + ds_unit[1] * o.s[1] + ds_unit[2] * o.s[2];
+    float ds[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) ds[c] = (ds_unit[c] - o.s[c] * dotp) / o.snorm;
+    const float b = o.pp[0] * dir[0] + o.pp[1] * dir[1] + o.pp[2] * dir[2];
+    const float dt_db = -1.0f + b / o.root;
+    const float dsd = ds[0] * dir[0] + ds[1] * dir[1] + ds[2] * dir[2];   // d L / d t
+#pragma unroll
+    for (int c = 0; c < 3; ++c) ddir[c] += o.t * ds[c] + dsd * dt_db * o.pp[c];
+}
+
+// sphere = 0: OLin rows are [IDE(dir, k) | 0] (ld 96).  sphere = 1 (shader_config.sphere_direction): rows are
+// [IDE(dir, k) | IDE(sph(x, dir), k2) | 0] (ld 160) with k2 = 1 for the diffuse row and rho for both specular rows.
+// rdim = 3 + 6 * refrac_freq columns per half of RLin (prefix of the L=6 embedding), ld_rl = padded row length.
 __global__ __launch_bounds__(256) void shade_encode_fwd_kernel(const float* __restrict__ nrm, const float* __restrict__ pt,
                                                                int pt_ld, const float* __restrict__ E,
-                                                               const float* __restrict__ Mraw, int ldm, int P,
+                                                               const float* __restrict__ Mraw, int ldm, int P, int sphere,
+                                                               int ld_ol, int rdim, int ld_rl,
                                                                float* __restrict__ OLin, float* __restrict__ ILin,
                                                                float* __restrict__ IWin, float* __restrict__ RLin,
                                                                float* __restrict__ SD) {
@@ -274,16 +317,29 @@ __global__ __launch_bounds__(256) void shade_encode_fwd_kernel(const float* __re
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwave = (gridDim.x * blockDim.x) >> 6;
     for (int p = wave; p < P; p += nwave) {
-        float n[3], d[3], nh[3], vh[3], r[3], nov, inorm;
+        float n[3], d[3], x[3], nh[3], vh[3], r[3], nov, inorm;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { n[c] = nrm[p * 3LL + c]; d[c] = pt[(long long)p * pt_ld + 4 + c]; }
+        for (int c = 0; c < 3; ++c) { n[c] = nrm[p * 3LL + c]; d[c] = pt[(long long)p * pt_ld + 4 + c]; x[c] = pt[(long long)p * pt_ld + c]; }
         nu_shade_dirs(n, d, nh, vh, r, nov, inorm);
         const float rho = nu_sigmoid(Mraw[(long long)p * ldm + 1]);
         const float e = lane < 39 ? E[(long long)p * 64 + lane] : 0.f;
 
-        nu_ide_write(OLin + (long long)p * 96, lane, nh[0], nh[1], nh[2], 1.0f, 96);
-        nu_ide_write(OLin + (long long)(P + p) * 96, lane, r[0], r[1], r[2], rho, 96);
-        nu_ide_write(OLin + (long long)(2LL * P + p) * 96, lane, r[0], r[1], r[2], 0.0f, 96);
+        float* ol0 = OLin + (long long)p * ld_ol;
+        float* ol1 = OLin + (long long)(P + p) * ld_ol;
+        float* ol2 = OLin + (long long)(2LL * P + p) * ld_ol;
+        if (sphere) {
+            const NuSph sn = nu_sph_point(x, nh), sr = nu_sph_point(x, r);
+            nu_ide_write(ol0, lane, nh[0], nh[1], nh[2], 1.0f, 72);
+            nu_ide_write(ol0 + 72, lane, sn.s[0], sn.s[1], sn.s[2], 1.0f, ld_ol - 72);
+            nu_ide_write(ol1, lane, r[0], r[1], r[2], rho, 72);
+            nu_ide_write(ol1 + 72, lane, sr.s[0], sr.s[1], sr.s[2], rho, ld_ol - 72);
+            nu_ide_write(ol2, lane, r[0], r[1], r[2], 0.0f, 72);
+            nu_ide_write(ol2 + 72, lane, sr.s[0], sr.s[1], sr.s[2], rho, ld_ol - 72);
+        } else {
+            nu_ide_write(ol0, lane, nh[0], nh[1], nh[2], 1.0f, ld_ol);
+            nu_ide_write(ol1, lane, r[0], r[1], r[2], rho, ld_ol);
+            nu_ide_write(ol2, lane, r[0], r[1], r[2], 0.0f, ld_ol);
+        }
 
         float* il0 = ILin + (long long)p * 128;
         float* il1 = ILin + (long long)(P + p) * 128;
@@ -292,16 +348,18 @@ __global__ __launch_bounds__(256) void shade_encode_fwd_kernel(const float* __re
         nu_ide_write(il1 + 39, lane, r[0], r[1], r[2], 0.0f, 128 - 39);
 
         float* iw = IWin + (long long)p * 96;
-        float* rl = RLin + (long long)p * 96;
+        float* rl = RLin + (long long)p * ld_rl;
         if (lane < 39) {
             iw[lane] = e;
-            rl[lane] = e;
             iw[39 + lane] = nu_embed_col(r, 3, lane);
-            rl[39 + lane] = nu_embed_col(vh, 3, lane);
         } else if (lane < 39 + 18) {
             iw[78 + lane - 39] = 0.f;
-            rl[78 + lane - 39] = 0.f;
         }
+        if (lane < rdim) {
+            rl[lane] = e;                                   // L=rf embedding is a prefix of the L=6 one
+            rl[rdim + lane] = nu_embed_col(vh, 3, lane);
+        }
+        for (int c = 2 * rdim + lane; c < ld_rl; c += 64) rl[c] = 0.f;
         if (lane < 8) {
             float v = 0.f;
             if (lane < 3) v = nh[lane];
@@ -313,13 +371,14 @@ __global__ __launch_bounds__(256) void shade_encode_fwd_kernel(const float* __re
     }
 }
 extern "C" int nu_shade_encode_fwd(const float* nrm, const float* pt, int pt_ld, const float* E, const float* Mraw,
-                                   int ldm, int P, float* OLin, float* ILin, float* IWin, float* RLin, float* SD,
-                                   hipStream_t stream) {
+                                   int ldm, int P, int sphere, int ld_ol, int refrac_dim, int ld_rl, float* OLin,
+                                   float* ILin, float* IWin, float* RLin, float* SD, hipStream_t stream) {
     if (P <= 0) return NU_OK;
+    if (ld_ol < (sphere ? 144 : 72) || refrac_dim > 39 || ld_rl < 2 * refrac_dim) return NU_ERR_ARG;
     int blocks = nu_cdiv(P, 4);
     blocks = blocks < 8192 ? blocks : 8192;
-    hipLaunchKernelGGL(shade_encode_fwd_kernel, dim3(blocks), dim3(256), 0, stream, nrm, pt, pt_ld, E, Mraw, ldm, P, OLin,
-                       ILin, IWin, RLin, SD);
+    hipLaunchKernelGGL(shade_encode_fwd_kernel, dim3(blocks), dim3(256), 0, stream, nrm, pt, pt_ld, E, Mraw, ldm, P, sphere,
+                       ld_ol, refrac_dim, ld_rl, OLin, ILin, IWin, RLin, SD);
     return nu_launch_status();
 }
 
@@ -327,7 +386,7 @@ extern "C" int nu_shade_encode_fwd(const float* nrm, const float* pt, int pt_ld,
 //   -> dn_shade[P,3] (w.r.t. the RAW sdf gradient n), and dMraw[p,1] += d rho * rho (1 - rho)
 __global__ __launch_bounds__(256) void shade_encode_bwd_kernel(const float* __restrict__ nrm, const float* __restrict__ pt,
                                                                int pt_ld, const float* __restrict__ SD,
-                                                               const float* __restrict__ dOLin,
+                                                               const float* __restrict__ dOLin, int ld_ol, int sphere,
                                                                const float* __restrict__ dILin,
                                                                const float* __restrict__ dNoV, int P,
                                                                float* __restrict__ dn, float* __restrict__ dMraw, int ldm) {
@@ -335,19 +394,36 @@ __global__ __launch_bounds__(256) void shade_encode_bwd_kernel(const float* __re
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwave = (gridDim.x * blockDim.x) >> 6;
     for (int p = wave; p < P; p += nwave) {
-        float n[3], d[3], nh[3], vh[3], r[3], nov, inorm;
+        float n[3], d[3], x[3], nh[3], vh[3], r[3], nov, inorm;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { n[c] = nrm[p * 3LL + c]; d[c] = pt[(long long)p * pt_ld + 4 + c]; }
+        for (int c = 0; c < 3; ++c) { n[c] = nrm[p * 3LL + c]; d[c] = pt[(long long)p * pt_ld + 4 + c]; x[c] = pt[(long long)p * pt_ld + c]; }
         nu_shade_dirs(n, d, nh, vh, r, nov, inorm);
         const float rho = SD[(long long)p * 8 + 5];
         float gx, gy, gz, gk;
         float dnh[3], dr[3] = {0.f, 0.f, 0.f}, drho = 0.f;
-        nu_ide_grad(dOLin + (long long)p * 96, lane, nh[0], nh[1], nh[2], 1.0f, gx, gy, gz, gk);
+        const float* g0 = dOLin + (long long)p * ld_ol;
+        const float* g1 = dOLin + (long long)(P + p) * ld_ol;
+        const float* g2 = dOLin + (long long)(2LL * P + p) * ld_ol;
+        nu_ide_grad(g0, lane, nh[0], nh[1], nh[2], 1.0f, gx, gy, gz, gk);
         dnh[0] = gx; dnh[1] = gy; dnh[2] = gz;
-        nu_ide_grad(dOLin + (long long)(P + p) * 96, lane, r[0], r[1], r[2], rho, gx, gy, gz, gk);
+        nu_ide_grad(g1, lane, r[0], r[1], r[2], rho, gx, gy, gz, gk);
         dr[0] += gx; dr[1] += gy; dr[2] += gz; drho += gk;
-        nu_ide_grad(dOLin + (long long)(2LL * P + p) * 96, lane, r[0], r[1], r[2], 0.0f, gx, gy, gz, gk);
+        nu_ide_grad(g2, lane, r[0], r[1], r[2], 0.0f, gx, gy, gz, gk);
         dr[0] += gx; dr[1] += gy; dr[2] += gz;
+        if (sphere) {
+            const NuSph sn = nu_sph_point(x, nh), sr = nu_sph_point(x, r);
+            float ds[3];
+            nu_ide_grad(g0 + 72, lane, sn.s[0], sn.s[1], sn.s[2], 1.0f, ds[0], ds[1], ds[2], gk);
+            nu_sph_point_bwd(sn, nh, ds, dnh);
+            float dsr[3], t1[3];
+            nu_ide_grad(g1 + 72, lane, sr.s[0], sr.s[1], sr.s[2], rho, dsr[0], dsr[1], dsr[2], gk);
+            drho += gk;
+            nu_ide_grad(g2 + 72, lane, sr.s[0], sr.s[1], sr.s[2], rho, t1[0], t1[1], t1[2], gk);
+            drho += gk;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) dsr[c] += t1[c];
+            nu_sph_point_bwd(sr, r, dsr, dr);
+        }
         nu_ide_grad(dILin + (long long)p * 128 + 39, lane, r[0], r[1], r[2], rho, gx, gy, gz, gk);
         dr[0] += gx; dr[1] += gy; dr[2] += gz; drho += gk;
         nu_ide_grad(dILin + (long long)(P + p) * 128 + 39, lane, r[0], r[1], r[2], 0.0f, gx, gy, gz, gk);
@@ -367,13 +443,43 @@ __global__ __launch_bounds__(256) void shade_encode_bwd_kernel(const float* __re
     }
 }
 extern "C" int nu_shade_encode_bwd(const float* nrm, const float* pt, int pt_ld, const float* SD, const float* dOLin,
-                                   const float* dILin, const float* dNoV, int P, float* dn, float* dMraw, int ldm,
-                                   hipStream_t stream) {
+                                   int ld_ol, int sphere, const float* dILin, const float* dNoV, int P, float* dn,
+                                   float* dMraw, int ldm, hipStream_t stream) {
     if (P <= 0) return NU_OK;
     int blocks = nu_cdiv(P, 4);
     blocks = blocks < 8192 ? blocks : 8192;
-    hipLaunchKernelGGL(shade_encode_bwd_kernel, dim3(blocks), dim3(256), 0, stream, nrm, pt, pt_ld, SD, dOLin, dILin, dNoV,
-                       P, dn, dMraw, ldm);
+    hipLaunchKernelGGL(shade_encode_bwd_kernel, dim3(blocks), dim3(256), 0, stream, nrm, pt, pt_ld, SD, dOLin, ld_ol, sphere,
+                       dILin, dNoV, P, dn, dMraw, ldm);
+    return nu_launch_status();
+}
+
+// Per-ray mirror query for colour_spec: row = [IDE(d, 0) | IDE(sph(x, d), 0) if sphere | 0]
+//   zero-thickness renderer: x unused (renderer_zerothick.py:780-781); standard renderer: x = the ray's candidate point
+//   (sample 64, network/renderer.py:710-725)
+__global__ __launch_bounds__(256) void spec_encode_kernel(const float* __restrict__ dirs, const float* __restrict__ x, int R,
+                                                          int sphere, float* __restrict__ out, int ldo) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwave = (gridDim.x * blockDim.x) >> 6;
+    for (int r = wave; r < R; r += nwave) {
+        const float d[3] = {dirs[r * 3LL], dirs[r * 3LL + 1], dirs[r * 3LL + 2]};
+        float* row = out + (long long)r * ldo;
+        if (sphere) {
+            const float xx[3] = {x[r * 3LL], x[r * 3LL + 1], x[r * 3LL + 2]};
+            const NuSph s = nu_sph_point(xx, d);
+            nu_ide_write(row, lane, d[0], d[1], d[2], 0.0f, 72);
+            nu_ide_write(row + 72, lane, s.s[0], s.s[1], s.s[2], 0.0f, ldo - 72);
+        } else {
+            nu_ide_write(row, lane, d[0], d[1], d[2], 0.0f, ldo);
+        }
+    }
+}
+extern "C" int nu_spec_encode(const float* dirs, const float* x, int R, int sphere, float* out, int ldo, hipStream_t stream) {
+    if (R <= 0) return NU_OK;
+    if (ldo < (sphere ? 144 : 72) || (sphere && !x)) return NU_ERR_ARG;
+    int blocks = nu_cdiv(R, 4);
+    blocks = blocks < 8192 ? blocks : 8192;
+    hipLaunchKernelGGL(spec_encode_kernel, dim3(blocks), dim3(256), 0, stream, dirs, x, R, sphere, out, ldo);
     return nu_launch_status();
 }
 

@@ -205,7 +205,8 @@ __global__ __launch_bounds__(256) void neus_alpha_fwd_kernel(const float* __rest
                                                              const float* __restrict__ nrm, const float* __restrict__ pt,
                                                              const int* __restrict__ idx, int P,
                                                              const float* __restrict__ variance, float anneal,
-                                                             float* __restrict__ alpha_rm, float* __restrict__ gerr) {
+                                                             float* __restrict__ alpha_rm, float* __restrict__ gerr,
+                                                             float* __restrict__ color_rm) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P) return;
     const float inv_s = nu_inv_s(variance);
@@ -214,14 +215,19 @@ __global__ __launch_bounds__(256) void neus_alpha_fwd_kernel(const float* __rest
     const f32x4 b = *reinterpret_cast<const f32x4*>(pt + (long long)p * NU_PT + 4);
     const float d[3] = {b[0], b[1], b[2]};
     NuAlphaVals v = nu_neus_alpha(YX[(long long)p * ldy], n, d, a[3], inv_s, anneal);
-    alpha_rm[idx[p]] = v.alpha;
+    const int k = idx[p];
+    alpha_rm[k] = v.alpha;
     gerr[p] = v.gerr;
+    // 4th colour channel: max(n . d, 0), composited into loss_normal by the non-zero-thickness renderer
+    // (network/renderer.py:693-705); ignored (zero cotangent) by the zero-thickness one
+    if (color_rm) color_rm[k * 4LL + 3] = fmaxf(d[0] * n[0] + d[1] * n[1] + d[2] * n[2], 0.f);
 }
 extern "C" int nu_neus_alpha_fwd(const float* YX, int ldy, const float* nrm, const float* pt, const int* idx, int P,
-                                 const float* variance, float anneal, float* alpha_rm, float* gerr, hipStream_t stream) {
+                                 const float* variance, float anneal, float* alpha_rm, float* gerr, float* color_rm,
+                                 hipStream_t stream) {
     if (P <= 0) return NU_OK;
     hipLaunchKernelGGL(neus_alpha_fwd_kernel, dim3(nu_cdiv(P, 256)), dim3(256), 0, stream, YX, ldy, nrm, pt, idx, P,
-                       variance, anneal, alpha_rm, gerr);
+                       variance, anneal, alpha_rm, gerr, color_rm);
     return nu_launch_status();
 }
 
@@ -234,6 +240,7 @@ __global__ __launch_bounds__(256) void neus_alpha_bwd_kernel(const float* __rest
                                                              const float* __restrict__ dalpha_rm,
                                                              const float* __restrict__ dgerr,
                                                              const float* __restrict__ dn_shade,
+                                                             const float* __restrict__ dcolor_rm,
                                                              float* __restrict__ dYX, int lddy, float* __restrict__ nbar,
                                                              float* __restrict__ dvar) {
     __shared__ float red[4];
@@ -248,14 +255,17 @@ __global__ __launch_bounds__(256) void neus_alpha_bwd_kernel(const float* __rest
         const f32x4 b = *reinterpret_cast<const f32x4*>(pt + (long long)p * NU_PT + 4);
         const float d[3] = {b[0], b[1], b[2]};
         NuAlphaVals v = nu_neus_alpha(YX[(long long)p * ldy], n, d, a[3], inv_s, anneal);
-        const float ga = dalpha_rm[idx[p]];
+        const int kk = idx[p];
+        const float ga = dalpha_rm[kk];
         dYX[(long long)p * lddy] = ga * v.dalpha_dsdf;
+        const float ndot = d[0] * n[0] + d[1] * n[1] + d[2] * n[2];
+        const float gno = (dcolor_rm && ndot > 0.f) ? dcolor_rm[kk * 4LL + 3] : 0.f;   // d max(n.d, 0) / d n = d
         const float ge = dgerr ? dgerr[p] : 0.f;
         // d gerr / d n = 2 (|n| - 1) n / |n|
         const float ke = v.norm > 0.f ? ge * 2.0f * (v.norm - 1.0f) / v.norm : 0.f;
 #pragma unroll
         for (int c = 0; c < 3; ++c)
-            nbar[p * 3LL + c] = ga * v.dalpha_dcos * d[c] + ke * n[c] + (dn_shade ? dn_shade[p * 3LL + c] : 0.f);
+            nbar[p * 3LL + c] = (ga * v.dalpha_dcos + gno) * d[c] + ke * n[c] + (dn_shade ? dn_shade[p * 3LL + c] : 0.f);
         dinv = ga * v.dalpha_dinvs;
     }
     if (dvar) {
@@ -271,11 +281,11 @@ __global__ __launch_bounds__(256) void neus_alpha_bwd_kernel(const float* __rest
 }
 extern "C" int nu_neus_alpha_bwd(const float* YX, int ldy, const float* nrm, const float* pt, const int* idx, int P,
                                  const float* variance, float anneal, const float* dalpha_rm, const float* dgerr,
-                                 const float* dn_shade, float* dYX, int lddy, float* nbar, float* dvar,
-                                 hipStream_t stream) {
+                                 const float* dn_shade, const float* dcolor_rm, float* dYX, int lddy, float* nbar,
+                                 float* dvar, hipStream_t stream) {
     if (P <= 0) return NU_OK;
     hipLaunchKernelGGL(neus_alpha_bwd_kernel, dim3(nu_cdiv(P, 256)), dim3(256), 0, stream, YX, ldy, nrm, pt, idx, P,
-                       variance, anneal, dalpha_rm, dgerr, dn_shade, dYX, lddy, nbar, dvar);
+                       variance, anneal, dalpha_rm, dgerr, dn_shade, dcolor_rm, dYX, lddy, nbar, dvar);
     return nu_launch_status();
 }
 
@@ -295,7 +305,8 @@ __global__ __launch_bounds__(256) void nerf_act_fwd_kernel(const float* __restri
     alpha_rm[k] = 1.0f - expf(-nu_softplus1(sigma[(long long)p * lds]) * dist);
 #pragma unroll
     for (int c = 0; c < 3; ++c)
-        color_rm[k * 3LL + c] = nu_linear_to_srgb(expf(fminf(rgb[(long long)p * ldr + c], 5.0f)));
+        color_rm[k * 4LL + c] = nu_linear_to_srgb(expf(fminf(rgb[(long long)p * ldr + c], 5.0f)));
+    color_rm[k * 4LL + 3] = 0.f;
 }
 extern "C" int nu_nerf_act_fwd(const float* sigma, int lds, const float* rgb, int ldr, const float* pt, const int* idx,
                                int P, float* alpha_rm, float* color_rm, hipStream_t stream) {
@@ -324,7 +335,7 @@ __global__ __launch_bounds__(256) void nerf_act_bwd_kernel(const float* __restri
     for (int c = 0; c < 3; ++c) {
         const float r = rgb[(long long)p * ldr + c];
         const float e = expf(fminf(r, 5.0f));
-        drgb[(long long)p * lddr + c] = r <= 5.0f ? dcolor_rm[k * 3LL + c] * nu_linear_to_srgb_grad(e) * e : 0.f;
+        drgb[(long long)p * lddr + c] = r <= 5.0f ? dcolor_rm[k * 4LL + c] * nu_linear_to_srgb_grad(e) * e : 0.f;
     }
 }
 extern "C" int nu_nerf_act_bwd(const float* sigma, int lds, const float* rgb, int ldr, const float* pt, const int* idx,
@@ -426,7 +437,7 @@ __global__ __launch_bounds__(256) void shade_combine_kernel(
     const int k = idx[p];
     if (!BWD) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) color_rm[k * 3LL + c] = nu_linear_to_srgb(lin[c]);
+        for (int c = 0; c < 3; ++c) color_rm[k * 4LL + c] = nu_linear_to_srgb(lin[c]);
         if (aux) {
             f32x4 a = {occ, T, met, rho};
             *reinterpret_cast<f32x4*>(aux + (long long)p * 4) = a;
@@ -442,7 +453,7 @@ __global__ __launch_bounds__(256) void shade_combine_kernel(
     float* gRL = dRLo + (long long)p * 4;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        const float g = dcolor_rm[k * 3LL + c] * nu_linear_to_srgb_grad(lin[c]);
+        const float g = dcolor_rm[k * 4LL + c] * nu_linear_to_srgb_grad(lin[c]);
         const float diffuse = (1.0f - met) * alb[c] * Ld[c];
         const float specw = sa[c] * L.A + L.B;
         const float spec = specw * light[c];
@@ -547,7 +558,8 @@ template <int CH>
 __global__ __launch_bounds__(256) void composite_fwd_kernel(const float* __restrict__ alpha, const float* __restrict__ color,
                                                             const unsigned char* __restrict__ inner, int R, int S,
                                                             float* __restrict__ weights, float* __restrict__ rgb,
-                                                            float* __restrict__ acc, float* __restrict__ rgb_bg) {
+                                                            float* __restrict__ acc, float* __restrict__ rgb_bg,
+                                                            float* __restrict__ aux_sum) {
     const int lane = threadIdx.x & 63;
     const int r = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (r >= R) return;
@@ -562,28 +574,31 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(const float* __restr
         if (j < S) { pl *= (1.0f - a[i] + 1e-7f); plb *= (1.0f - abg[i] + 1e-7f); }
     }
     float T = nu_wave_excl_prod(pl, lane), Tb = nu_wave_excl_prod(plb, lane);
-    float s[3] = {0.f, 0.f, 0.f}, sb[3] = {0.f, 0.f, 0.f}, sacc = 0.f;
+    float s[4] = {0.f, 0.f, 0.f, 0.f}, sb[3] = {0.f, 0.f, 0.f}, sacc = 0.f;
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
         const int j = lane * CH + i;
         if (j < S) {
             const float w = a[i] * T, wb = abg[i] * Tb;
             if (weights) weights[base + j] = w;
-            const float c0 = color[(base + j) * 3], c1 = color[(base + j) * 3 + 1], c2 = color[(base + j) * 3 + 2];
-            s[0] += w * c0; s[1] += w * c1; s[2] += w * c2;
-            sb[0] += wb * c0; sb[1] += wb * c1; sb[2] += wb * c2;
+            const f32x4 c = *reinterpret_cast<const f32x4*>(color + (base + j) * 4);   // rgb + normal-orientation term
+            s[0] += w * c[0]; s[1] += w * c[1]; s[2] += w * c[2]; s[3] += w * c[3];
+            sb[0] += wb * c[0]; sb[1] += wb * c[1]; sb[2] += wb * c[2];
             sacc += w;
             T *= (1.0f - a[i] + 1e-7f);
             Tb *= (1.0f - abg[i] + 1e-7f);
         }
     }
 #pragma unroll
-    for (int c = 0; c < 3; ++c) { s[c] = nu_wave_sum(s[c]); sb[c] = nu_wave_sum(sb[c]); }
+    for (int c = 0; c < 4; ++c) s[c] = nu_wave_sum(s[c]);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) sb[c] = nu_wave_sum(sb[c]);
     sacc = nu_wave_sum(sacc);
     if (lane == 0) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) { rgb[r * 3LL + c] = s[c]; rgb_bg[r * 3LL + c] = sb[c]; }
         acc[r] = sacc;
+        if (aux_sum) aux_sum[r] = s[3];
     }
 }
 
@@ -591,13 +606,13 @@ template <int CH>
 __global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restrict__ alpha, const float* __restrict__ color,
                                                             const unsigned char* __restrict__ inner, int R, int S,
                                                             const float* __restrict__ drgb, const float* __restrict__ dacc,
-                                                            const float* __restrict__ drgb_bg,
+                                                            const float* __restrict__ drgb_bg, const float* __restrict__ daux,
                                                             float* __restrict__ dalpha, float* __restrict__ dcolor) {
     const int lane = threadIdx.x & 63;
     const int r = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (r >= R) return;
     const long long base = (long long)r * S;
-    const float g[3] = {drgb[r * 3LL], drgb[r * 3LL + 1], drgb[r * 3LL + 2]};
+    const float g[4] = {drgb[r * 3LL], drgb[r * 3LL + 1], drgb[r * 3LL + 2], daux ? daux[r] : 0.f};
     const float gb[3] = {drgb_bg ? drgb_bg[r * 3LL] : 0.f, drgb_bg ? drgb_bg[r * 3LL + 1] : 0.f,
                          drgb_bg ? drgb_bg[r * 3LL + 2] : 0.f};
     const float ga = dacc ? dacc[r] : 0.f;
@@ -621,13 +636,12 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restr
         Tj[i] = T; Tbj[i] = Tb;
         gw[i] = 0.f; gwb[i] = 0.f;
         if (j < S) {
-            const float c0 = color[(base + j) * 3], c1 = color[(base + j) * 3 + 1], c2 = color[(base + j) * 3 + 2];
-            gw[i] = g[0] * c0 + g[1] * c1 + g[2] * c2 + ga;
-            gwb[i] = gb[0] * c0 + gb[1] * c1 + gb[2] * c2;
+            const f32x4 c = *reinterpret_cast<const f32x4*>(color + (base + j) * 4);
+            gw[i] = g[0] * c[0] + g[1] * c[1] + g[2] * c[2] + g[3] * c[3] + ga;
+            gwb[i] = gb[0] * c[0] + gb[1] * c[1] + gb[2] * c[2];
             const float w = a[i] * T, wb = abg[i] * Tb;
-            dcolor[(base + j) * 3] = w * g[0] + wb * gb[0];
-            dcolor[(base + j) * 3 + 1] = w * g[1] + wb * gb[1];
-            dcolor[(base + j) * 3 + 2] = w * g[2] + wb * gb[2];
+            f32x4 dc = {w * g[0] + wb * gb[0], w * g[1] + wb * gb[1], w * g[2] + wb * gb[2], w * g[3]};
+            *reinterpret_cast<f32x4*>(dcolor + (base + j) * 4) = dc;
             ls += gw[i] * w;
             lsb += gwb[i] * wb;
             T *= (1.0f - a[i] + 1e-7f);
@@ -649,23 +663,24 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restr
     }
 }
 
+// colour is [R*S, 4]: rgb + one auxiliary channel composited into aux_sum (loss_normal of network/renderer.py:705)
 extern "C" int nu_composite_fwd(const float* alpha, const float* color, const unsigned char* inner, int R, int S,
-                                float* weights, float* rgb, float* acc, float* rgb_bg, hipStream_t stream) {
+                                float* weights, float* rgb, float* acc, float* rgb_bg, float* aux_sum, hipStream_t stream) {
     if (R <= 0 || S <= 0 || S > 64 * NU_MAXCHUNK) return NU_ERR_ARG;
     dim3 grid(nu_cdiv(R, 4)), block(256);
     const int ch = nu_cdiv(S, 64);
-#define NU_CASE(c) case c: hipLaunchKernelGGL(composite_fwd_kernel<c>, grid, block, 0, stream, alpha, color, inner, R, S, weights, rgb, acc, rgb_bg); break;
+#define NU_CASE(c) case c: hipLaunchKernelGGL(composite_fwd_kernel<c>, grid, block, 0, stream, alpha, color, inner, R, S, weights, rgb, acc, rgb_bg, aux_sum); break;
     switch (ch) { NU_CASE(1) NU_CASE(2) NU_CASE(3) NU_CASE(4) default: return NU_ERR_ARG; }
 #undef NU_CASE
     return nu_launch_status();
 }
 extern "C" int nu_composite_bwd(const float* alpha, const float* color, const unsigned char* inner, int R, int S,
-                                const float* drgb, const float* dacc, const float* drgb_bg, float* dalpha, float* dcolor,
-                                hipStream_t stream) {
+                                const float* drgb, const float* dacc, const float* drgb_bg, const float* daux,
+                                float* dalpha, float* dcolor, hipStream_t stream) {
     if (R <= 0 || S <= 0 || S > 64 * NU_MAXCHUNK) return NU_ERR_ARG;
     dim3 grid(nu_cdiv(R, 4)), block(256);
     const int ch = nu_cdiv(S, 64);
-#define NU_CASE(c) case c: hipLaunchKernelGGL(composite_bwd_kernel<c>, grid, block, 0, stream, alpha, color, inner, R, S, drgb, dacc, drgb_bg, dalpha, dcolor); break;
+#define NU_CASE(c) case c: hipLaunchKernelGGL(composite_bwd_kernel<c>, grid, block, 0, stream, alpha, color, inner, R, S, drgb, dacc, drgb_bg, daux, dalpha, dcolor); break;
     switch (ch) { NU_CASE(1) NU_CASE(2) NU_CASE(3) NU_CASE(4) default: return NU_ERR_ARG; }
 #undef NU_CASE
     return nu_launch_status();

@@ -86,8 +86,11 @@ class Stage1Engine:
         self.p = params  # dict name -> Parameter/Tensor on device
         self.exp_max = float(cfg.get('light_exp_max', 3.0))
         self.sphere_direction = bool(cfg.get('sphere_direction', False))
-        if self.sphere_direction:
-            raise NotImplementedError("sphere_direction=True (144-d outer_light) is a later-round row")
+        if int(cfg.get('light_pos_freq', 6)) != 6:
+            raise NotImplementedError("light_pos_freq != 6 (no shipped config changes it)")
+        self.refrac_dim = 3 + 6 * int(cfg.get('refrac_freq', 6))       # field.py:590-591 (real_bottle uses refrac_freq 3)
+        self.ld_ol = 160 if self.sphere_direction else 96               # outer_light input 144 / 72 (field.py:594-597)
+        self.ld_rl = rup(2 * self.refrac_dim, 32)
         lib = self.lib
         for fn in ("nu_wgrad_workspace_bytes", "nu_skinny_bwd_workspace_bytes", "nu_colsum_workspace_bytes",
                    "nu_gemm_tn_workspace_bytes"):
@@ -242,10 +245,10 @@ class Stage1Engine:
                 reg(q + '.weight_v', lay.dv_off); reg(q + '.weight_g', lay.dg_off); reg(q + '.bias', lay.db_off)
                 out.append(lay)
             return out
-        self.outer_light = predictor('outer_light', 96)
+        self.outer_light = predictor('outer_light', self.ld_ol)
         self.inner_light = predictor('inner_light', 128)
         self.inner_weight = predictor('inner_weight', 96)
-        self.refrac_light = predictor('refrac_light', 96)
+        self.refrac_light = predictor('refrac_light', self.ld_rl)
         layers += self.outer_light + self.inner_light + self.inner_weight + self.refrac_light
         self.layers = layers
         self.n_grad = self._goff
@@ -503,7 +506,7 @@ class Stage1Engine:
                 self.nt(addr(dA), 256, addr(*lay.WpT), lay.ldT, rows, dx_cols, 256, addr(dX), lddx, EPI_PLAIN)
 
     # ------------------------------------------------------------------ shading stack
-    def shading_forward(self, a, pt, idx, P, color_rm, extra_dirs=None):
+    def shading_forward(self, a, pt, idx, P, color_rm, extra_dirs=None, extra_pts=None):
         """Materials -> encodings -> 4 light predictors -> combine (field.py:684-777).
         a: SDF activations (YX, E, n).  extra_dirs [R,3]: per-ray directions whose mirror query IDE(d,0)
         rides along the outer_light batch (colour_spec, renderer_zerothick.py:780-781)."""
@@ -523,18 +526,20 @@ class Stage1Engine:
         # encodings
         R = 0 if extra_dirs is None else extra_dirs.shape[0]
         rows_ol = 3 * P + R
-        OLin, ILin, IWin, RLin, SD = e(rows_ol, 96), e(2 * P, 128), e(P, 96), e(P, 96), e(P, 8)
-        L.check(lib.nu_shade_encode_fwd(c_p(addr(a['n'])), c_p(addr(pt)), 8, c_p(addr(a['E'])), c_p(addr(Mraw)), 8, P,
-                                        c_p(addr(OLin)), c_p(addr(ILin)), c_p(addr(IWin)), c_p(addr(RLin)),
-                                        c_p(addr(SD)), S), "nu_shade_encode_fwd")
+        ld_ol, ld_rl, sph = self.ld_ol, self.ld_rl, 1 if self.sphere_direction else 0
+        OLin, ILin, IWin, RLin, SD = e(rows_ol, ld_ol), e(2 * P, 128), e(P, 96), e(P, ld_rl), e(P, 8)
+        L.check(lib.nu_shade_encode_fwd(c_p(addr(a['n'])), c_p(addr(pt)), 8, c_p(addr(a['E'])), c_p(addr(Mraw)), 8, P, sph,
+                                        ld_ol, self.refrac_dim, ld_rl, c_p(addr(OLin)), c_p(addr(ILin)), c_p(addr(IWin)),
+                                        c_p(addr(RLin)), c_p(addr(SD)), S), "nu_shade_encode_fwd")
         if R:
-            L.check(lib.nu_ide(c_p(addr(extra_dirs)), c_p(0), R, c_p(addr(OLin, 3 * P * 96)), 96, S), "nu_ide")
+            L.check(lib.nu_spec_encode(c_p(addr(extra_dirs)), c_p(addr(extra_pts)), R, sph if extra_pts is not None else 0,
+                                       c_p(addr(OLin, 3 * P * ld_ol)), ld_ol, S), "nu_spec_encode")
         s.update(OLin=OLin, ILin=ILin, IWin=IWin, RLin=RLin, SD=SD, R=R, rows_ol=rows_ol)
         # light predictors
-        s['OLh'] = self.relu_stack_fwd(self.outer_light, OLin, 96, rows_ol)
+        s['OLh'] = self.relu_stack_fwd(self.outer_light, OLin, ld_ol, rows_ol)
         s['ILh'] = self.relu_stack_fwd(self.inner_light, ILin, 128, 2 * P)
         s['IWh'] = self.relu_stack_fwd(self.inner_weight, IWin, 96, P)
-        s['RLh'] = self.relu_stack_fwd(self.refrac_light, RLin, 96, P)
+        s['RLh'] = self.relu_stack_fwd(self.refrac_light, RLin, ld_rl, P)
         OLo, ILo, IWo, RLo = e(rows_ol, 4), e(2 * P, 4), e(P), e(P, 4)
         for lay, Hs, out, rows, no, ldo in ((self.outer_light[3], s['OLh'], OLo, rows_ol, 3, 4),
                                             (self.inner_light[3], s['ILh'], ILo, 2 * P, 3, 4),
@@ -569,21 +574,22 @@ class Stage1Engine:
         if d_occ_raw is not None:
             dIWo += d_occ_raw
         # heads + hidden stacks of the four light predictors
-        dOLin, dILin = e(rows_ol, 96), e(2 * P, 128)
+        ld_ol, ld_rl = self.ld_ol, self.ld_rl
+        dOLin, dILin = e(rows_ol, ld_ol), e(2 * P, 128)
         for layers, Hs, dy, ldy, rows, no, X, ldx, dX, lddx, dxc in (
-                (self.outer_light, s['OLh'], dOLo, 4, rows_ol, 3, s['OLin'], 96, dOLin, 96, 96),
+                (self.outer_light, s['OLh'], dOLo, 4, rows_ol, 3, s['OLin'], ld_ol, dOLin, ld_ol, ld_ol),
                 (self.inner_light, s['ILh'], dILo, 4, 2 * P, 3, s['ILin'], 128, dILin, 128, 128),
                 (self.inner_weight, s['IWh'], dIWo, 1, P, 1, s['IWin'], 96, None, 0, 0),
-                (self.refrac_light, s['RLh'], dRLo, 4, P, 3, s['RLin'], 96, None, 0, 0)):
+                (self.refrac_light, s['RLh'], dRLo, 4, P, 3, s['RLin'], ld_rl, None, 0, 0)):
             head = layers[3]
             dH3 = e(rows, 256)
             self.skinny_bwd(addr(dy), ldy, addr(Hs[2]), 256, rows, 256, addr(*head.Wp), 256, no, addr(dH3), 256, 1, 0,
                             addr(*head.dWp), head.ldd, addr(flat, head.db_off))
             self.relu_stack_bwd(layers, X, ldx, rows, Hs, dH3, flat, dX, lddx, dxc)
         dn = e(P, 3)
-        L.check(lib.nu_shade_encode_bwd(c_p(addr(a['n'])), c_p(addr(pt)), 8, c_p(addr(s['SD'])), c_p(addr(dOLin)),
-                                        c_p(addr(dILin)), c_p(addr(dNoV)), P, c_p(addr(dn)), c_p(addr(dMraw)), 8, S),
-                "nu_shade_encode_bwd")
+        L.check(lib.nu_shade_encode_bwd(c_p(addr(a['n'])), c_p(addr(pt)), 8, c_p(addr(s['SD'])), c_p(addr(dOLin)), ld_ol,
+                                        1 if self.sphere_direction else 0, c_p(addr(dILin)), c_p(addr(dNoV)), P,
+                                        c_p(addr(dn)), c_p(addr(dMraw)), 8, S), "nu_shade_encode_bwd")
         # materials backward
         db0, db12, db6 = self.mat_db
         dM3 = e(P, 1024)
@@ -721,7 +727,7 @@ class Stage1Engine:
         return out
 
     # ------------------------------------------------------------------ render_core
-    def render_forward(self, o, d, z, anneal, want_weights=False):
+    def render_forward(self, o, d, z, anneal, want_weights=False, spec_pts=None):
         """Stage-1 render_core forward (renderer_zerothick.py:725-820) on R rays with S samples each.
         Returns (outputs dict of tensors, ctx) ; one host sync (the inner-point count)."""
         lib, S_ = self.lib, self.stream()
@@ -739,7 +745,7 @@ class Stage1Engine:
         L.check(lib.nu_partition_write(c_p(addr(o)), c_p(addr(d)), c_p(addr(z)), R, S, c_p(addr(off)), c_p(addr(pt_in)),
                                        c_p(addr(idx_in)), c_p(addr(pt_out)), c_p(addr(idx_out)), c_p(addr(inner_rm)), S_),
                 "nu_partition_write")
-        alpha_rm, color_rm = e(R * S), e(R * S, 3)
+        alpha_rm, color_rm = e(R * S), e(R * S, 4)
         ctx = dict(R=R, S=S, P_in=P_in, P_out=P_out, pt_in=pt_in, idx_in=idx_in, pt_out=pt_out, idx_out=idx_out,
                    inner_rm=inner_rm, alpha_rm=alpha_rm, color_rm=color_rm, anneal=float(anneal))
         if P_out > 0:
@@ -753,9 +759,9 @@ class Stage1Engine:
             gerr = e(P_in)
             var = self.p['deviation_network.variance']
             L.check(lib.nu_neus_alpha_fwd(c_p(addr(a['YX'])), 288, c_p(addr(a['n'])), c_p(addr(pt_in)), c_p(addr(idx_in)),
-                                          P_in, c_p(addr(var)), c_f(anneal), c_p(addr(alpha_rm)), c_p(addr(gerr)), S_),
-                    "nu_neus_alpha_fwd")
-            s = self.shading_forward(a, pt_in, idx_in, P_in, color_rm, extra_dirs=du)
+                                          P_in, c_p(addr(var)), c_f(anneal), c_p(addr(alpha_rm)), c_p(addr(gerr)),
+                                          c_p(addr(color_rm)), S_), "nu_neus_alpha_fwd")
+            s = self.shading_forward(a, pt_in, idx_in, P_in, color_rm, extra_dirs=du, extra_pts=spec_pts)
             ctx.update(sdf=a, shade=s)
             out['gradient_error'] = gerr
             out['spec_raw'] = s['OLo'][3 * P_in:, :3]
@@ -764,26 +770,27 @@ class Stage1Engine:
             out['aux'] = s['aux']
             out['normal_raw'] = a['n']
         weights = e(R, S) if want_weights else None
-        rgb, acc, rgb_bg = e(R, 3), e(R), e(R, 3)
+        rgb, acc, rgb_bg, nrm_sum = e(R, 3), e(R), e(R, 3), e(R)
         L.check(lib.nu_composite_fwd(c_p(addr(alpha_rm)), c_p(addr(color_rm)), c_p(addr(inner_rm)), R, S,
-                                     c_p(addr(weights)), c_p(addr(rgb)), c_p(addr(acc)), c_p(addr(rgb_bg)), S_),
-                "nu_composite_fwd")
-        out.update(rgb=rgb, acc=acc, rgb_bg=rgb_bg, weights=weights)
+                                     c_p(addr(weights)), c_p(addr(rgb)), c_p(addr(acc)), c_p(addr(rgb_bg)),
+                                     c_p(addr(nrm_sum)), S_), "nu_composite_fwd")
+        out.update(rgb=rgb, acc=acc, rgb_bg=rgb_bg, weights=weights, nrm_sum=nrm_sum)
         self.last_ctx = ctx
         return out, ctx
 
     def render_backward(self, ctx, d_rgb, d_acc, d_rgb_bg, d_gerr=None, d_spec_raw=None, d_occ_raw=None, d_sdf_in=None,
-                        train_inv_s=False):
+                        train_inv_s=False, d_nrm_sum=None):
         """Hand-derived backward of render_forward w.r.t. every network parameter.  Returns the flat gradient
         buffer (layout: self.grad_views)."""
         lib, S_ = self.lib, self.stream()
         e = self.empty
         R, S, P_in, P_out = ctx['R'], ctx['S'], ctx['P_in'], ctx['P_out']
         flat = self.zeros(self.n_grad)
-        dalpha_rm, dcolor_rm = e(R * S), e(R * S, 3)
+        dalpha_rm, dcolor_rm = e(R * S), e(R * S, 4)
         L.check(lib.nu_composite_bwd(c_p(addr(ctx['alpha_rm'])), c_p(addr(ctx['color_rm'])), c_p(addr(ctx['inner_rm'])),
                                      R, S, c_p(addr(d_rgb.contiguous())), c_p(addr(d_acc.contiguous()) if d_acc is not None else 0),
-                                     c_p(addr(d_rgb_bg.contiguous()) if d_rgb_bg is not None else 0), c_p(addr(dalpha_rm)),
+                                     c_p(addr(d_rgb_bg.contiguous()) if d_rgb_bg is not None else 0),
+                                     c_p(addr(d_nrm_sum.contiguous()) if d_nrm_sum is not None else 0), c_p(addr(dalpha_rm)),
                                      c_p(addr(dcolor_rm)), S_), "nu_composite_bwd")
         if P_out > 0:
             self.nerf_backward(ctx['nerf'], ctx['pt_out'], ctx['idx_out'], dalpha_rm, dcolor_rm, flat)
@@ -801,7 +808,8 @@ class Stage1Engine:
             L.check(lib.nu_neus_alpha_bwd(c_p(addr(a['YX'])), 288, c_p(addr(a['n'])), c_p(addr(ctx['pt_in'])),
                                           c_p(addr(ctx['idx_in'])), P_in, c_p(addr(var)), c_f(ctx['anneal']),
                                           c_p(addr(dalpha_rm)), c_p(addr(d_gerr.contiguous()) if d_gerr is not None else 0),
-                                          c_p(addr(dn)), c_p(addr(dYX)), 288, c_p(addr(nbar)),
+                                          c_p(addr(dn)), c_p(addr(dcolor_rm) if d_nrm_sum is not None else 0), c_p(addr(dYX)), 288,
+                                          c_p(addr(nbar)),
                                           c_p(addr(flat, self.var_off) if train_inv_s else 0), S_), "nu_neus_alpha_bwd")
             if d_sdf_in is not None:
                 dYX[:, 0] += d_sdf_in

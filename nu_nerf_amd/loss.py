@@ -122,6 +122,16 @@ class OuterRegLoss(Loss):
         return {}
 
 
+class NormalOrientationLoss(Loss):
+    def __init__(self, cfg):
+        pass
+
+    def __call__(self, data_pr, data_gt, step, *args, **kwargs):
+        if 'loss_normal' in data_pr:
+            return {'loss_normal': torch.mean(data_pr['loss_normal']).reshape(1)}
+        return {}
+
+
 name2loss = {
     'nerf_render': NeRFRenderLoss,
     'eikonal': EikonalLoss,
@@ -130,6 +140,7 @@ name2loss = {
     'occ': OccLoss,
     'mask': MaskLoss,
     'outer_reg': OuterRegLoss,
+    'normal_ori': NormalOrientationLoss,
 }
 
 SPHEREPOT_LOSSES = ['nerf_render', 'eikonal', 'std', 'init_sdf_reg', 'occ', 'mask', 'outer_reg']

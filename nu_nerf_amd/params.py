@@ -44,7 +44,7 @@ def _put_wn(p, prefix, w, bias):
     p[prefix + ".weight_v"] = w.astype(np.float32)
 
 
-def predictor_dims(sphere_direction=False):
+def predictor_dims(sphere_direction=False, refrac_freq=6):
     """(name, in_dim, out_dim, last-bias constant or None) of every make_predictor stack."""
     return [
         ("metallic_predictor", 259, 1, None),
@@ -55,11 +55,11 @@ def predictor_dims(sphere_direction=False):
         ("inner_weight", 39 + 39, 1, -0.95),
         ("transmisstion_weight", 259, 1, None),
         ("iors", 259, 1, None),
-        ("refrac_light", 39 + 39, 3, math.log(0.5)),
+        ("refrac_light", 2 * (3 + 6 * refrac_freq), 3, math.log(0.5)),
     ]
 
 
-def init_stage1_params(seed=6033, sphere_direction=False, sdf_bias=0.5, inv_s_init=0.3):
+def init_stage1_params(seed=6033, sphere_direction=False, sdf_bias=0.5, inv_s_init=0.3, refrac_freq=6):
     """OrderedDict name -> np.float32 array, in the reference module-construction order
     (renderer_zerothick.py:144-162)."""
     rng = np.random.Generator(np.random.PCG64(seed))
@@ -106,7 +106,7 @@ def init_stage1_params(seed=6033, sphere_direction=False, sdf_bias=0.5, inv_s_in
 
     # ---- AppShadingNetwork predictors (field.py:575-611) ----
     p["color_network.FG_LUT"] = load_fg_lut()
-    for name, k, n_out, last_bias in predictor_dims(sphere_direction):
+    for name, k, n_out, last_bias in predictor_dims(sphere_direction, refrac_freq):
         chain = [(k, 256), (256, 256), (256, 256), (256, n_out)]
         for j, (ki, no) in enumerate(chain):
             w, b = _linear_default(rng, no, ki)

@@ -85,7 +85,7 @@ class AppShadingNetwork(nn.Module):
         self.cfg = {**self.default_cfg, **cfg}
         if self.cfg['human_light']:
             raise NotImplementedError("human_light=True is outside the stage-1 hot path of the supported configs")
-        for name, k, n_out, _ in predictor_dims(self.cfg['sphere_direction']):
+        for name, k, n_out, _ in predictor_dims(self.cfg['sphere_direction'], self.cfg['refrac_freq']):
             setattr(self, name, _predictor(k, n_out))
         self.register_buffer('FG_LUT', torch.zeros(1, 256, 256, 2))
 
@@ -106,8 +106,8 @@ class _RenderCoreFn(torch.autograd.Function):
     """render_core as ONE differentiable op: forward + hand-derived backward, both sequences of HIP kernels."""
 
     @staticmethod
-    def forward(ctx, engine, o, d, z, anneal, train_inv_s, names, *params):
-        out, c = engine.render_forward(o, d, z, anneal)
+    def forward(ctx, engine, o, d, z, anneal, train_inv_s, names, spec_pts, *params):
+        out, c = engine.render_forward(o, d, z, anneal, spec_pts=spec_pts)
         ctx.engine, ctx.c, ctx.names, ctx.train_inv_s = engine, c, names, train_inv_s
         ctx.set_materialize_grads(False)
         dev = o.device
@@ -117,16 +117,17 @@ class _RenderCoreFn(torch.autograd.Function):
         else:
             gerr = torch.zeros(0, device=dev)
             spec, occ, sdf_in = torch.zeros(o.shape[0], 3, device=dev), torch.zeros(0, device=dev), torch.zeros(0, device=dev)
-        return out['rgb'], out['acc'], out['rgb_bg'], gerr, spec, occ, sdf_in
+        return out['rgb'], out['acc'], out['rgb_bg'], gerr, spec, occ, sdf_in, out['nrm_sum']
 
     @staticmethod
-    def backward(ctx, d_rgb, d_acc, d_rgb_bg, d_gerr, d_spec, d_occ, d_sdf):
+    def backward(ctx, d_rgb, d_acc, d_rgb_bg, d_gerr, d_spec, d_occ, d_sdf, d_nrm):
         eng, c = ctx.engine, ctx.c
         R = c['R']
         dev = c['alpha_rm'].device
         if d_rgb is None:
             d_rgb = torch.zeros(R, 3, device=dev)
-        flat = eng.render_backward(c, d_rgb, d_acc, d_rgb_bg, d_gerr, d_spec, d_occ, d_sdf, train_inv_s=ctx.train_inv_s)
+        flat = eng.render_backward(c, d_rgb, d_acc, d_rgb_bg, d_gerr, d_spec, d_occ, d_sdf, train_inv_s=ctx.train_inv_s,
+                                   d_nrm_sum=d_nrm)
         grads = []
         for n in ctx.names:
             off, shape = eng.grad_views[n]
@@ -136,7 +137,7 @@ class _RenderCoreFn(torch.autograd.Function):
             numel = int(np.prod(shape)) if len(shape) else 1
             grads.append(flat[off:off + numel].view(shape))
         ctx.c = None
-        return (None,) * 7 + tuple(grads)
+        return (None,) * 8 + tuple(grads)
 
 
 class _SdfValueFn(torch.autograd.Function):
@@ -217,7 +218,8 @@ class NeROShapeRenderer(nn.Module):
         `torch.manual_seed` (train/trainer_zero.py:96) makes construction reproducible."""
         seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
         init = init_stage1_params(seed, sphere_direction=self.color_network.cfg['sphere_direction'],
-                                  sdf_bias=self.cfg['sdf_bias'], inv_s_init=self.cfg['inv_s_init'])
+                                  sdf_bias=self.cfg['sdf_bias'], inv_s_init=self.cfg['inv_s_init'],
+                                  refrac_freq=self.color_network.cfg['refrac_freq'])
         self.load_param_dict(init)
 
     def load_param_dict(self, arrays):
@@ -333,17 +335,20 @@ class NeROShapeRenderer(nn.Module):
             eng.pack()
         cfg = self.cfg
         frozen = cfg['freeze_inv_s_step'] is not None and step < cfg['freeze_inv_s_step']
-        rgb, acc, rgb_bg, gerr, spec_raw, occ_raw, sdf_in = _RenderCoreFn.apply(
-            eng, rays_o, rays_d, z_vals, float(cos_anneal_ratio), not frozen, self._grad_names, *self._grad_params)
+        spec_pts, cand = self._spec_query_points(rays_o, rays_d, z_vals)
+        rgb, acc, rgb_bg, gerr, spec_raw, occ_raw, sdf_in, nrm_sum = _RenderCoreFn.apply(
+            eng, rays_o, rays_d, z_vals, float(cos_anneal_ratio), not frozen, self._grad_names, spec_pts, *self._grad_params)
         color = rgb + (1. - acc[..., None]) if is_nerf else rgb
         exp_max = eng.exp_max
+        color_spec = linear_to_srgb(torch.exp(torch.clamp(spec_raw, max=exp_max)))
         outputs = {
             'ray_rgb': torch.clamp(color, min=0.0, max=1.0),
             'gradient_error': gerr if gerr.numel() else torch.zeros(1, device=rgb.device),
             'acc': acc,
-            'color_bkgr': rgb_bg,
-            'color_spec': linear_to_srgb(torch.exp(torch.clamp(spec_raw, max=exp_max))),
+            'color_bkgr': rgb_bg if cand is None else rgb_bg[cand],
+            'color_spec': color_spec if cand is None else color_spec[cand],
         }
+        self._extra_outputs(outputs, nrm_sum)
         var = self.deviation_network.variance
         inv_s = torch.exp(var * 10.0).clip(1e-6, 1e6)
         outputs['std'] = (1.0 / inv_s).detach() if gerr.numel() else torch.zeros(1, device=rgb.device)
@@ -361,6 +366,14 @@ class NeROShapeRenderer(nn.Module):
             else:
                 outputs['loss_occ'] = torch.zeros(1, device=rgb.device)
         return outputs
+
+    def _spec_query_points(self, rays_o, rays_d, z_vals):
+        """Zero-thickness renderer: colour_spec is queried per ray from the direction alone
+        (renderer_zerothick.py:780-781)."""
+        return None, None
+
+    def _extra_outputs(self, outputs, nrm_sum):
+        pass
 
     def _init_reg_points(self, eng, c, sdf_in):
         """Points with |x| < 1.2 and their SDF (renderer_zerothick.py:804-807): the inner set reuses the main pass;

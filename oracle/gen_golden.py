@@ -222,5 +222,75 @@ def main():
     run_step("step500_r32_noperturb", 32, 500, ray_seed=300, perturb=False)
 
 
+def main_std():
+    """Vectors from the reference's NON-zero-thickness stage-1 renderer (network/renderer.py) with
+    sphere_direction = True and refrac_freq = 3 (configs/shape/real/real_bottle.yaml), real-capture near/far."""
+    from network.renderer import NeROShapeRenderer as RefStd   # reference
+    from network.loss import name2loss
+    from nu_nerf_amd.params import init_stage1_params, randomize_for_parity
+    from nu_nerf_amd.synthetic import make_rays, make_jitter
+    cfg = {'name': 'golden_std', 'network': 'shape', 'database_name': 'custom/x/720', 'apply_occ_loss': True,
+           'occ_loss_step': 15000, 'is_nerf': False, 'freeze_inv_s_step': 15000, 'eikonal_weight': 0.05, 'get_mask': False,
+           'shader_config': {'sphere_direction': True, 'human_light': False, 'refrac_freq': 3},
+           'loss': ['nerf_render', 'eikonal', 'std', 'init_sdf_reg', 'occ', 'outer_reg', 'normal_ori'],
+           'outer_reg_loss_weight': 0.1, 'n_samples': 64, 'n_importance': 32, 'n_bg_samples': 16}
+    net = RefStd(cfg, training=False)
+    params = randomize_for_parity(init_stage1_params(6033, sphere_direction=True, refrac_freq=3), seed=1)
+    print("load_state_dict (std):", net.load_state_dict(to_t(params), strict=True))
+    losses = [name2loss[n](cfg) for n in cfg['loss']]
+    R, step, ray_seed = 40, 20000, 400
+    rays = make_rays(R, seed=ray_seed)
+    # real captures look at the unit sphere from nearby: pull the origins in so near/far_from_sphere is exercised
+    o = torch.from_numpy(rays['rays_o']) * 0.6
+    d = torch.from_numpy(rays['rays_d'])
+    rgbs = torch.from_numpy(rays['rgbs'])
+    u1, u2 = make_jitter(R, cfg['n_bg_samples'], seed=ray_seed + 7)
+    draws = [torch.from_numpy(u1), torch.from_numpy(u2)]
+    real_rand = torch.rand
+    torch.rand = lambda *a, **k: draws.pop(0)
+    try:
+        dn = torch.nn.functional.normalize(d, dim=-1)
+        near, far = net.near_far_from_sphere(o, dn)
+        net.zero_grad()
+        z = net.sample_ray(o, dn, near, far, 1.0)
+        outputs = net.render_core(o, dn, z, torch.zeros(R, 3, 4), cos_anneal_ratio=net.get_anneal_val(step), step=step,
+                                  is_train=True, is_nerf=False)
+    finally:
+        torch.rand = real_rand
+    outputs['loss_rgb'] = net.compute_rgb_loss(outputs['ray_rgb'], rgbs)
+    log = {}
+    for ls in losses:
+        log.update(ls(outputs, {}, step))
+    total = 0
+    for k, v in log.items():
+        if k.startswith('loss'):
+            total = total + torch.mean(v)
+    total.backward()
+    res = {'rays_o': o.numpy(), 'rays_d': rays['rays_d'], 'rgbs': rays['rgbs'], 'u1': u1, 'u2': u2, 'step': np.asarray(step),
+           'z_vals': z.numpy(), 'near': near.numpy(), 'far': far.numpy(), 'total_loss': total.detach().numpy()}
+    for k in ('ray_rgb', 'acc', 'color_bkgr', 'color_spec', 'gradient_error', 'loss_normal', 'loss_occ', 'loss_rgb'):
+        res['out_' + k] = outputs[k].detach().numpy()
+    for k, v in log.items():
+        if k.startswith('loss'):
+            res['term_' + k] = torch.mean(v).detach().numpy()
+    gn = {n: p.grad for n, p in net.named_parameters() if p.grad is not None}
+    res['grad_names'] = np.asarray(sorted(gn.keys()))
+    res['grad_norms'] = np.asarray([float(gn[k].double().norm()) for k in sorted(gn.keys())])
+    for k in ('sdf_network.lin0.weight_v', 'sdf_network.lin8.weight_v', 'color_network.outer_light.0.weight_v',
+              'color_network.refrac_light.0.weight_v', 'color_network.roughness_predictor.6.bias',
+              'deviation_network.variance'):
+        res['grad__' + k] = gn[k].numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "train_std_step20000_r40.npz"), **res)
+    print("std loss", float(total), {k: float(v) for k, v in res.items() if k.startswith('term_')},
+          "candidates", int(outputs['color_spec'].shape[0]), "of", R)
+
+
 if __name__ == "__main__":
-    main()
+    if "--std-only" in sys.argv:
+        install_shims()
+        torch.manual_seed(0)
+        torch.set_num_threads(8)
+        main_std()
+    else:
+        main()
+        main_std()

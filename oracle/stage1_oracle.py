@@ -244,7 +244,8 @@ def shading_forward(params, cfg, points, normals, view_dirs, feats, prefix='colo
 
     t = torch.clamp(1 - nov, 0.0, 1.0)
     fres = torch.clamp(0.04 + 0.96 * t * t * t * t * t, 0.0, 1.0)
-    refrac = predictor(params, f'{prefix}.refrac_light', torch.cat([embed(points, 6), embed(v, 6)], -1),
+    rf = cfg.get('refrac_freq', 6)                                  # field.py:590-591
+    refrac = predictor(params, f'{prefix}.refrac_light', torch.cat([embed(points, rf), embed(v, rf)], -1),
                        'exp', exp_max)
     uv = torch.cat([torch.clamp(nov, 0.0, 1.0), torch.clamp(rough, 0.0, 1.0)], -1)
     fg = lut_bilinear_clamp(params[f'{prefix}.FG_LUT'][0], uv)
@@ -425,8 +426,9 @@ def compute_occ_loss(params, cfg, occ_info, points, sdf, grads, dirs, step, perm
     return torch.zeros(1)
 
 
-def render_core(params, cfg, rays_o, rays_d, z_vals, step, cos_anneal=0.0, is_nerf=True, occ_perm=None):
-    """Stage-1 render_core for training (renderer_zerothick.py:725-820)."""
+def render_core(params, cfg, rays_o, rays_d, z_vals, step, cos_anneal=0.0, is_nerf=True, occ_perm=None, std=False):
+    """Stage-1 render_core for training (renderer_zerothick.py:725-820).  std=True follows the non-zero-thickness
+    file instead (network/renderer.py:738-859): loss_normal, candidate-ray colour_spec / colour_bkgr."""
     R, S = z_vals.shape
     dists = z_vals[..., 1:] - z_vals[..., :-1]
     dists = torch.cat([dists, dists[..., -1:]], -1)
@@ -445,9 +447,12 @@ def render_core(params, cfg, rays_o, rays_d, z_vals, step, cos_anneal=0.0, is_ne
     alpha_bg, color_bg = alpha, color
 
     out = {}
+    normal_dir = torch.zeros(R, S, 1)
     if inner.any():
         a, grads, feats, s, sdf = compute_sdf_alpha(params, cfg, points[inner], dists[inner], dirs[inner],
                                                     cos_anneal, step)
+        gfl = torch.zeros(R, S, 3).index_put((inner,), grads)
+        normal_dir = torch.clamp(torch.sum(gfl * dirs, dim=-1, keepdim=True), min=0.0)
         c, occ_info = shading_forward(params, cfg, points[inner], grads, -dirs[inner], feats)
         alpha = alpha.index_put((inner,), a)
         color = color.index_put((inner,), c)
@@ -466,9 +471,24 @@ def render_core(params, cfg, rays_o, rays_d, z_vals, step, cos_anneal=0.0, is_ne
     rgb = (color * w[..., None]).sum(1)
     w_bg = _excl_cumprod_weights(alpha_bg)
     out['color_bkgr'] = (color_bg * w_bg[..., None]).sum(1)
-    enc = ide(dirs[:, 0, :], torch.zeros(R, 1))
-    out['color_spec'] = linear_to_srgb(predictor(params, 'color_network.outer_light', enc, 'exp',
-                                                 cfg['light_exp_max']))
+    if not std:
+        enc = ide(dirs[:, 0, :], torch.zeros(R, 1))
+        out['color_spec'] = linear_to_srgb(predictor(params, 'color_network.outer_light', enc, 'exp',
+                                                     cfg['light_exp_max']))
+    else:
+        # renderer.py:705-725
+        out['loss_normal'] = (normal_dir * w[..., None]).sum(dim=1)
+        pc, dc = points[:, 64, :], dirs[:, 0, :]
+        cand = torch.norm(pc, dim=-1) <= 1.0
+        pf, df = pc[cand], dc[cand]
+        enc = ide(df, torch.zeros(df.shape[0], 1))
+        if cfg['sphere_direction']:
+            sp = offset_points_to_sphere(pf)
+            sp = F.normalize(sp + df * sphere_exit_distance(sp, df), dim=-1)
+            enc = torch.cat([enc, ide(sp, torch.zeros(sp.shape[0], 1))], -1)
+        out['color_spec'] = linear_to_srgb(predictor(params, 'color_network.outer_light', enc, 'exp',
+                                                     cfg['light_exp_max']))
+        out['color_bkgr'] = out['color_bkgr'][cand]
     acc = w.sum(-1)
     if is_nerf:
         rgb = rgb + (1. - acc[..., None])
@@ -533,6 +553,10 @@ def assemble_losses(out, cfg, step):
     if step >= 15000:
         terms['loss_outer_reg'] = F.mse_loss(out['color_bkgr'].flatten(), out['color_spec'].flatten()) \
             * cfg['outer_reg_loss_weight']
+    if 'loss_normal' in out and cfg.get('normal_ori', False):
+        terms['loss_normal'] = torch.mean(out['loss_normal']).reshape(1)
+    if 'loss_mask' in out:
+        terms['loss_mask'] = out['loss_mask'].reshape(1) * 0.01
     total = 0
     for v in terms.values():
         total = total + torch.mean(v)
@@ -542,6 +566,31 @@ def assemble_losses(out, cfg, step):
 def get_anneal_val(cfg, step):
     """renderer_zerothick.py:313-317."""
     return 1.0 if cfg['anneal_end'] < 0 else float(min(1.0, step / cfg['anneal_end']))
+
+
+def near_far_from_sphere(rays_o, rays_d):
+    """renderer.py:320-327."""
+    a = torch.sum(rays_d ** 2, dim=-1, keepdim=True)
+    b = 2.0 * torch.sum(rays_o * rays_d, dim=-1, keepdim=True)
+    mid = 0.5 * (-b) / a
+    return torch.clamp(mid - 1.0, min=1e-3), mid + 1.0
+
+
+def train_step_std(params, cfg, rays_o, rays_d, rgb_gt, step, rand=None, real=True):
+    """One forward of the non-zero-thickness stage-1 renderer (network/renderer.py:465-479, :347-361): real captures
+    take near/far from the unit sphere and composite no white background."""
+    rays_d = F.normalize(rays_d, dim=-1)
+    R = rays_o.shape[0]
+    if real:
+        nr, fr = near_far_from_sphere(rays_o, rays_d)
+    else:
+        nr, fr = torch.full((R, 1), 0.8), torch.full((R, 1), 4.5)
+    z = sample_ray(params, cfg, rays_o, rays_d, nr, fr, cfg['perturb'], rand)
+    out = render_core(params, cfg, rays_o, rays_d, z, step, get_anneal_val(cfg, step), not real, None, std=True)
+    out['z_vals'] = z
+    out['loss_rgb'] = rgb_loss(out['ray_rgb'], rgb_gt, cfg['rgb_loss'])
+    total, terms = assemble_losses(out, cfg, step)
+    return total, terms, out
 
 
 def train_step(params, cfg, rays_o, rays_d, rgb_gt, step, rand=None, occ_perm=None, near=0.8, far=4.5):

@@ -108,3 +108,31 @@ def test_train_step(name, perturb):
             # inner_weight's gradient is O(1e-8) (difference of two nearly equal light terms): cancellation noise
             tol = 3e-2 if 'inner_weight' in k else 2e-3
             assert rel_err(params[k[6:]].grad, g[k]) < tol, k
+
+
+def test_train_step_standard_renderer_sphere_direction():
+    """Non-zero-thickness stage-1 renderer (network/renderer.py) with sphere_direction=True, refrac_freq=3, real-capture
+    near/far: loss_normal, candidate-ray colour_spec, 144-d outer_light."""
+    from helpers import STD_CFG
+    g = golden("train_std_step20000_r40.npz")
+    params = parity_params(requires_grad=True, sphere_direction=True, refrac_freq=3)
+    cfg = dict(O.DEFAULT_CFG)
+    cfg.update(STD_CFG)
+    step = int(g['step'])
+    total, terms, out = O.train_step_std(params, cfg, torch.from_numpy(g['rays_o']), torch.from_numpy(g['rays_d']),
+                                         torch.from_numpy(g['rgbs']), step,
+                                         rand=(torch.from_numpy(g['u1']), torch.from_numpy(g['u2'])), real=True)
+    dz = np.abs(out['z_vals'].numpy() - g['z_vals']) / np.maximum(1.0, np.abs(g['z_vals']))
+    assert (dz < 1e-5).mean() >= 0.97 and dz.max() < 2e-3
+    for k in ('ray_rgb', 'acc', 'color_bkgr', 'color_spec', 'loss_normal'):
+        np.testing.assert_allclose(out[k].detach().numpy(), g['out_' + k], rtol=2e-4, atol=2e-5, err_msg=k)
+    for k in g:
+        if k.startswith('term_'):
+            np.testing.assert_allclose(float(torch.mean(terms[k[5:]]).detach()), float(g[k]), rtol=3e-4, atol=1e-7, err_msg=k)
+    np.testing.assert_allclose(float(total.detach()), float(g['total_loss']), rtol=1e-5)
+    total.backward()
+    for n, ref_norm in zip([str(s) for s in g['grad_names']], g['grad_norms']):
+        assert abs(float(params[n].grad.double().norm()) - ref_norm) <= 2e-3 * ref_norm + 1e-9, n
+    for k in g:
+        if k.startswith('grad__'):
+            assert rel_err(params[k[6:]].grad, g[k]) < 1e-2, k     # element-wise: sensitive to the shifted samples

@@ -242,3 +242,43 @@ def test_edge_cases_all_rays_miss_and_single_ray(gpu):
     assert out1['ray_rgb'].shape == (1, 3) and net.engine().last_ctx['P_in'] > 0
     total_loss(out1, [name2loss[n](CFG) for n in SPHEREPOT_LOSSES], 0)[0].backward()
     assert bool(torch.isfinite(net.sdf_network.lin0.weight_v.grad).all())
+
+
+def test_standard_renderer_sphere_direction_vs_reference_golden(gpu):
+    """nu_nerf_amd.renderer_std (drop-in for network/renderer.py's stage-1 renderer): sphere_direction=True (144-d
+    outer_light input), refrac_freq=3, real-capture near/far, loss_normal, candidate-ray colour_spec."""
+    from helpers import STD_CFG
+    from nu_nerf_amd.renderer_std import NeROShapeRenderer as StdRenderer
+    from nu_nerf_amd.params import init_stage1_params, randomize_for_parity
+    from nu_nerf_amd.loss import name2loss, total_loss
+    g = golden("train_std_step20000_r40.npz")
+    cfg = {'is_nerf': False, 'n_samples': 64, 'n_importance': 32, 'n_bg_samples': 16, 'freeze_inv_s_step': 15000,
+           'apply_occ_loss': True, 'occ_loss_step': 15000, 'eikonal_weight': 0.05, 'outer_reg_loss_weight': 0.1,
+           'shader_config': {'sphere_direction': True, 'human_light': False, 'refrac_freq': 3}}
+    net = StdRenderer(cfg, training=False)
+    net.load_param_dict(randomize_for_parity(init_stage1_params(6033, sphere_direction=True, refrac_freq=3), seed=1))
+    net = net.to(gpu)
+    step = int(g['step'])
+    o = torch.from_numpy(g['rays_o']).to(gpu)
+    d = torch.nn.functional.normalize(torch.from_numpy(g['rays_d']).to(gpu), dim=-1)
+    near, far = net.near_far_from_sphere(o, d)
+    np.testing.assert_allclose(near.cpu().numpy(), g['near'], rtol=1e-5, atol=1e-6)
+    out = net.render(o, d, near, far, None, -1, net.get_anneal_val(step), is_train=True, step=step, is_nerf=False,
+                     rand=(torch.from_numpy(g['u1']).to(gpu), torch.from_numpy(g['u2']).to(gpu)))
+    out['loss_rgb'] = net.compute_rgb_loss(out['ray_rgb'], torch.from_numpy(g['rgbs']).to(gpu))
+    names = ['nerf_render', 'eikonal', 'std', 'init_sdf_reg', 'occ', 'outer_reg', 'normal_ori']
+    total, log = total_loss(out, [name2loss[n](cfg) for n in names], step)
+    total.backward()
+    for k in ('ray_rgb', 'acc', 'color_bkgr', 'color_spec', 'loss_normal'):
+        np.testing.assert_allclose(out[k].detach().cpu().numpy(), g['out_' + k], rtol=2e-4, atol=3e-5, err_msg=k)
+    for k in g:
+        if k.startswith('term_'):
+            np.testing.assert_allclose(float(torch.mean(log[k[5:]]).detach()), float(g[k]), rtol=5e-4, atol=1e-7, err_msg=k)
+    np.testing.assert_allclose(float(total.detach()), float(g['total_loss']), rtol=2e-5)
+    named = dict(net.named_parameters())
+    for n, ref_norm in zip([str(s) for s in g['grad_names']], g['grad_norms']):
+        assert named[n].grad is not None, n
+        assert abs(float(named[n].grad.double().norm()) - ref_norm) <= 3e-3 * ref_norm + 1e-9, (n, float(named[n].grad.norm()), ref_norm)
+    for k in g:
+        if k.startswith('grad__'):
+            assert rel_err(named[k[6:]].grad.cpu(), g[k]) < 1.5e-2, k   # element-wise: sensitive to the shifted samples
