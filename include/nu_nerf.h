@@ -142,6 +142,13 @@ int nu_shade_encode_bwd(const float* nrm, const float* pt, int pt_ld, const floa
 int nu_spec_encode(const float* dirs, const float* x, int R, int sphere, float* out, int ldo, hipStream_t stream);
 /* NeRF++ inputs (x/|x|, 1/|x|) L=10 and view -d L=4 (renderer_zerothick.py:687-690; field.py:266-269) */
 int nu_nerf_embed(const float* pt, int pt_ld, int P, float* E4, float* U5, float* V, hipStream_t stream);
+/* input gradients (stage 2: sample positions depend on the learned IoR, renderer_zerothick.py:1642-1684): d L / d x of the
+ * SDF network incl. the second-order term of its normal, and d L / d x, d L / d dir of the NeRF++ inputs */
+int nu_embed_jt2(const float* E, const float* dE, int lde, const float* dS, int lds, const float* G0, int ldg0,
+                 const float* Gs, int ldgs, const float* nbar, int P, float* dx, int accumulate, hipStream_t stream);
+int nu_nerf_embed_bwd(const float* pt, int pt_ld, const float* E4, const float* V, const float* gE, int lde,
+                      const float* gS, int lds, const float* gV, int ldv, int P, float* dx, float* ddir,
+                      hipStream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * render_core (renderer_zerothick.py:725-820)

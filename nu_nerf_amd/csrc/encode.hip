@@ -515,3 +515,140 @@ extern "C" int nu_nerf_embed(const float* pt, int pt_ld, int P, float* E4, float
     hipLaunchKernelGGL(nerf_embed_kernel, dim3(blocks), dim3(256), 0, stream, pt, pt_ld, P, E4, U5, V);
     return nu_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------
+// Input gradients (stage 2: sample positions depend on the learned IoR through the refracted directions)
+// ------------------------------------------------------------------------------------------------
+// d L / d x of the SDF network: first-order part J_emb^T (dE + dSkip) plus, when nbar is given, the derivative of
+// n = J_emb(x)^T gbar through J_emb itself:  sum_col gbar[col] * nbar_c * emb''_col,  emb'' = -f^2 * emb for sin/cos.
+__global__ __launch_bounds__(256) void embed_jt2_kernel(const float* __restrict__ E, const float* __restrict__ dE, int lde,
+                                                        const float* __restrict__ dS, int lds, const float* __restrict__ G0,
+                                                        int ldg0, const float* __restrict__ Gs, int ldgs,
+                                                        const float* __restrict__ nbar, int P, float* __restrict__ dx,
+                                                        int accumulate) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwave = (gridDim.x * blockDim.x) >> 6;
+    for (int p = wave; p < P; p += nwave) {
+        float t = 0.f;
+        int c = 0;
+        if (lane < 39) {
+            float g = dE[(long long)p * lde + lane];
+            if (dS) g += dS[(long long)p * lds + lane];
+            if (lane < 3) {
+                c = lane;
+                t = g;
+            } else {
+                const int q = lane - 3;
+                const int k = q / 6;
+                const int r = q - 6 * k;
+                c = r >= 3 ? r - 3 : r;
+                const float f = (float)(1 << k);
+                const float self = E[(long long)p * 64 + lane];
+                const float other = r >= 3 ? -E[(long long)p * 64 + lane - 3] : E[(long long)p * 64 + lane + 3];
+                t = g * f * other;
+                if (nbar) {
+                    float gb = G0[(long long)p * ldg0 + lane];
+                    if (Gs) gb += Gs[(long long)p * ldgs + lane];
+                    t -= gb * nbar[(long long)p * 3 + c] * f * f * self;
+                }
+            }
+        }
+        const float s0 = nu_wave_sum(c == 0 ? t : 0.f);
+        const float s1 = nu_wave_sum(c == 1 ? t : 0.f);
+        const float s2 = nu_wave_sum(c == 2 ? t : 0.f);
+        if (lane < 3) {
+            const float v = lane == 0 ? s0 : (lane == 1 ? s1 : s2);
+            float* o = dx + (long long)p * 3 + lane;
+            *o = accumulate ? *o + v : v;
+        }
+    }
+}
+extern "C" int nu_embed_jt2(const float* E, const float* dE, int lde, const float* dS, int lds, const float* G0, int ldg0,
+                            const float* Gs, int ldgs, const float* nbar, int P, float* dx, int accumulate,
+                            hipStream_t stream) {
+    if (P <= 0) return NU_OK;
+    int blocks = nu_cdiv(P, 4);
+    blocks = blocks < 8192 ? blocks : 8192;
+    hipLaunchKernelGGL(embed_jt2_kernel, dim3(blocks), dim3(256), 0, stream, E, dE, lde, dS, lds, G0, ldg0, Gs, ldgs, nbar, P,
+                       dx, accumulate);
+    return nu_launch_status();
+}
+
+// d L / d x and d L / d dir of the NeRF++ inputs from the gradients of its two embeddings:
+//   gE [P, >=84] (+ gS [P, >=84] skip copy) w.r.t. embed((x/|x|, 1/|x|), 10);  gV [P, >=27] w.r.t. embed(-d, 4)
+__global__ __launch_bounds__(256) void nerf_embed_bwd_kernel(const float* __restrict__ pt, int pt_ld, const float* __restrict__ E4,
+                                                             const float* __restrict__ V, const float* __restrict__ gE, int lde,
+                                                             const float* __restrict__ gS, int lds,
+                                                             const float* __restrict__ gV, int ldv, int P,
+                                                             float* __restrict__ dx, float* __restrict__ ddir) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwave = (gridDim.x * blockDim.x) >> 6;
+    for (int p = wave; p < P; p += nwave) {
+        // ---- point embedding: 4 inputs, 10 frequencies, 84 columns (two passes over the lanes) ----
+        float acc4[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int col = lane; col < 84; col += 64) {
+            float g = gE[(long long)p * lde + col];
+            if (gS) g += gS[(long long)p * lds + col];
+            int c;
+            float t;
+            if (col < 4) {
+                c = col;
+                t = g;
+            } else {
+                const int q = col - 4;
+                const int k = q / 8;
+                const int r = q - 8 * k;
+                c = r >= 4 ? r - 4 : r;
+                const float f = (float)(1 << k);
+                const float other = r >= 4 ? -E4[(long long)p * 96 + col - 4] : E4[(long long)p * 96 + col + 4];
+                t = g * f * other;
+            }
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) acc4[cc] += (c == cc) ? t : 0.f;
+        }
+        float g4[4];
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) g4[cc] = nu_wave_sum(acc4[cc]);
+        // ---- view embedding: 3 inputs (-d), 4 frequencies, 27 columns stored at V[:, 256:283] ----
+        float tv = 0.f;
+        int cv = 0;
+        if (lane < 27) {
+            const float g = gV[(long long)p * ldv + lane];
+            if (lane < 3) {
+                cv = lane;
+                tv = g;
+            } else {
+                const int q = lane - 3;
+                const int k = q / 6;
+                const int r = q - 6 * k;
+                cv = r >= 3 ? r - 3 : r;
+                const float f = (float)(1 << k);
+                const float other = r >= 3 ? -V[(long long)p * 288 + 256 + lane - 3] : V[(long long)p * 288 + 256 + lane + 3];
+                tv = g * f * other;
+            }
+        }
+        const float v0 = nu_wave_sum(cv == 0 ? tv : 0.f), v1 = nu_wave_sum(cv == 1 ? tv : 0.f), v2 = nu_wave_sum(cv == 2 ? tv : 0.f);
+        if (lane == 0) {
+            const float x[3] = {pt[(long long)p * pt_ld], pt[(long long)p * pt_ld + 1], pt[(long long)p * pt_ld + 2]};
+            const float nn = sqrtf(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+            const float xh[3] = {x[0] / nn, x[1] / nn, x[2] / nn};
+            const float dotp = xh[0] * g4[0] + xh[1] * g4[1] + xh[2] * g4[2];
+            // x4 = (x/|x|, 1/|x|):  d(x/|x|) = (I - xh xh^T)/|x| ; d(1/|x|) = -x/|x|^3
+#pragma unroll
+            for (int c = 0; c < 3; ++c) dx[(long long)p * 3 + c] = (g4[c] - xh[c] * dotp) / nn - g4[3] * xh[c] / (nn * nn);
+            ddir[(long long)p * 3] = -v0; ddir[(long long)p * 3 + 1] = -v1; ddir[(long long)p * 3 + 2] = -v2;   // view = -d
+        }
+    }
+}
+extern "C" int nu_nerf_embed_bwd(const float* pt, int pt_ld, const float* E4, const float* V, const float* gE, int lde,
+                                 const float* gS, int lds, const float* gV, int ldv, int P, float* dx, float* ddir,
+                                 hipStream_t stream) {
+    if (P <= 0) return NU_OK;
+    int blocks = nu_cdiv(P, 4);
+    blocks = blocks < 8192 ? blocks : 8192;
+    hipLaunchKernelGGL(nerf_embed_bwd_kernel, dim3(blocks), dim3(256), 0, stream, pt, pt_ld, E4, V, gE, lde, gS, lds, gV, ldv, P,
+                       dx, ddir);
+    return nu_launch_status();
+}

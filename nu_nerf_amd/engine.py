@@ -424,14 +424,16 @@ class Stage1Engine:
                         H=addr(H[l]), ldh=256, zero_to=256 if l != 4 else 0)
         G0 = e(P, 64)
         self.nt(addr(D[0]), 256, addr(*ls[0].WpT), ls[0].ldT, P, 39, 256, addr(G0), 64, EPI_PLAIN, zero_to=64)
+        a['G0'] = G0
         a['n'] = e(P, 3)
         L.check(lib.nu_embed_jt(c_p(addr(a['E'])), c_p(addr(G0)), 64, c_p(addr(D[3], 217)), 256, P, c_p(addr(a['n'])), S),
                 "nu_embed_jt")
         return a['n']
 
-    def sdf_backward(self, a, dYX, nbar, flat):
+    def sdf_backward(self, a, dYX, nbar, flat, dx=None):
         """Backward of (y, n) w.r.t. the SDF parameters given dYX [P,288] (cols 0..256 = d y) and nbar [P,3]
-        (may be None: first-order only).  Writes packed weight grads + bias grads (into `flat`)."""
+        (may be None: first-order only).  Writes packed weight grads + bias grads (into `flat`).  dx [P,3] (optional):
+        receives d L / d x through the network (stage 2), to which the caller adds dYX's x-slot."""
         lib, S, P, ls, H, E = self.lib, self.stream(), a['P'], self.sdf, a['H'], a['E']
         e = self.empty
         second = nbar is not None
@@ -461,8 +463,13 @@ class Stage1Engine:
                 srcA, lda, K, WT, ldT = A[l + 1], 256, rup(ls[l + 1].N, 32), ls[l + 1].WpT, ls[l + 1].ldT
             N = ls[l].N
             A[l] = Cb[l] if second else e(P, 256)
-            self.nt(addr(srcA), lda, addr(*WT), ldT, P, N, K, addr(A[l]), 256, EPI_B_SP if second else EPI_MUL_DSP,
-                    H=addr(H[l + 1]), ldh=256, Cadd=addr(Cb[l]) if second else 0, ldadd=256, zero_to=256)
+            if l == 3 and dx is not None:
+                # also keep the plain columns 217..255: gradient w.r.t. the embedding copy of the skip connection
+                self.nt(addr(srcA), lda, addr(*WT), ldT, P, 256, K, addr(A[l]), 256, EPI_B_SP if second else EPI_MUL_DSP,
+                        H=addr(H[l + 1]), ldh=256, Cadd=addr(Cb[l]) if second else 0, ldadd=256, act_cols=217)
+            else:
+                self.nt(addr(srcA), lda, addr(*WT), ldT, P, N, K, addr(A[l]), 256, EPI_B_SP if second else EPI_MUL_DSP,
+                        H=addr(H[l + 1]), ldh=256, Cadd=addr(Cb[l]) if second else 0, ldadd=256, zero_to=256)
         # weight gradients
         for l in range(8):
             u, ldu = (E, 64) if l == 0 else (H[l], 256)
@@ -476,6 +483,12 @@ class Stage1Engine:
         if second:
             # d W8[sdf row] += sum_p q_8   (the reverse sweep starts from W8's sdf row)
             self.colsum(addr(Q[8]), 256, P, 256, addr(*ls[8].dWp), 1)
+        if dx is not None:
+            dE0 = e(P, 64)
+            self.nt(addr(A[0]), 256, addr(*ls[0].WpT), ls[0].ldT, P, 39, 256, addr(dE0), 64, EPI_PLAIN, zero_to=64)
+            L.check(lib.nu_embed_jt2(c_p(addr(E)), c_p(addr(dE0)), 64, c_p(addr(A[3], 217)), 256,
+                                     c_p(addr(a['G0']) if second else 0), 64, c_p(addr(a['D'][3], 217) if second else 0), 256,
+                                     c_p(addr(nbar) if second else 0), P, c_p(addr(dx)), 0, S), "nu_embed_jt2")
 
     # ------------------------------------------------------------------ generic ReLU stacks
     def relu_stack_fwd(self, layers, X, ldx, rows):
@@ -610,11 +623,13 @@ class Stage1Engine:
 
     # ------------------------------------------------------------------ NeRF++ background
     def nerf_forward(self, pt, idx, P, alpha_rm, color_rm):
+        """pt [P, 8] point records (x, dist, unit direction).  With alpha_rm = None the fused activation/scatter is skipped
+        and the raw heads are returned in the dict (stage 2)."""
         lib, S = self.lib, self.stream()
         e = self.empty
         b = {'P': P}
         E4, U5, V = e(P, 96), e(P, 352), e(P, 288)
-        L.check(lib.nu_nerf_embed(c_p(addr(pt)), 8, P, c_p(addr(E4)), c_p(addr(U5)), c_p(addr(V)), S), "nu_nerf_embed")
+        L.check(lib.nu_nerf_embed(c_p(addr(pt)), pt.shape[1], P, c_p(addr(E4)), c_p(addr(U5)), c_p(addr(V)), S), "nu_nerf_embed")
         H = [E4]
         src, lds = E4, 96
         for i in range(8):
@@ -634,46 +649,67 @@ class Stage1Engine:
                 bias=addr(self.nerf_view.b))
         rgb = e(P, 4)
         self.skinny_fwd(addr(HV), 128, P, 128, addr(*self.nerf_rgb.Wp), 128, addr(self.nerf_rgb.b), 3, addr(rgb), 4)
-        L.check(lib.nu_nerf_act_fwd(c_p(addr(sig)), 1, c_p(addr(rgb)), 4, c_p(addr(pt)), c_p(addr(idx)), P,
-                                    c_p(addr(alpha_rm)), c_p(addr(color_rm)), S), "nu_nerf_act_fwd")
+        if alpha_rm is not None:
+            L.check(lib.nu_nerf_act_fwd(c_p(addr(sig)), 1, c_p(addr(rgb)), 4, c_p(addr(pt)), c_p(addr(idx)), P,
+                                        c_p(addr(alpha_rm)), c_p(addr(color_rm)), S), "nu_nerf_act_fwd")
         b.update(V=V, HV=HV, sig=sig, rgb=rgb)
         return b
 
-    def nerf_backward(self, b, pt, idx, dalpha_rm, dcolor_rm, flat):
+    def nerf_backward(self, b, pt, idx, dalpha_rm, dcolor_rm, flat, dsig=None, drgb=None, dx=None, ddir=None):
+        """Backward of the NeRF++ stack.  Either (dalpha_rm, dcolor_rm) through the fused activation kernel (stage 1) or raw
+        head cotangents (dsig [P], drgb [P,4]) directly (stage 2).  dx/ddir [P,3] (optional) receive the input gradients."""
         lib, S, P = self.lib, self.stream(), b['P']
         e = self.empty
         H = b['H']
-        dsig, drgb = e(P), e(P, 4)
-        L.check(lib.nu_nerf_act_bwd(c_p(addr(b['sig'])), 1, c_p(addr(b['rgb'])), 4, c_p(addr(pt)), c_p(addr(idx)), P,
-                                    c_p(addr(dalpha_rm)), c_p(addr(dcolor_rm)), c_p(addr(dsig)), 1, c_p(addr(drgb)), 4, S),
-                "nu_nerf_act_bwd")
+        want_in = dx is not None
+        if dsig is None:
+            dsig, drgb = e(P), e(P, 4)
+            L.check(lib.nu_nerf_act_bwd(c_p(addr(b['sig'])), 1, c_p(addr(b['rgb'])), 4, c_p(addr(pt)), c_p(addr(idx)), P,
+                                        c_p(addr(dalpha_rm)), c_p(addr(dcolor_rm)), c_p(addr(dsig)), 1, c_p(addr(drgb)), 4, S),
+                    "nu_nerf_act_bwd")
         # rgb head -> view layer
         dHV = e(P, 128)
         self.skinny_bwd(addr(drgb), 4, addr(b['HV']), 128, P, 128, addr(*self.nerf_rgb.Wp), 128, 3, addr(dHV), 128, 1, 0,
                         addr(*self.nerf_rgb.dWp), 128, addr(flat, self.nerf_rgb.db_off))
         self.wgrad(addr(dHV), 128, addr(b['V']), 288, P, 128, 288, addr(*self.nerf_view.dWp), 288,
                    addr(flat, self.nerf_view.db_off))
-        dF = e(P, 256)   # gradient w.r.t. the feature_linear output (first 256 columns of V)
-        self.nt(addr(dHV), 128, addr(*self.nerf_view.WpT), self.nerf_view.ldT, P, 256, 128, addr(dF), 256, EPI_PLAIN)
-        self.wgrad(addr(dF), 256, addr(H[8]), 256, P, 256, 256, addr(*self.nerf_feat.dWp), 256,
+        ldf = 288 if want_in else 256
+        dF = e(P, ldf)   # gradient w.r.t. V = feature_linear output (256) | view embedding (27, stage 2 only)
+        self.nt(addr(dHV), 128, addr(*self.nerf_view.WpT), self.nerf_view.ldT, P, ldf, 128, addr(dF), ldf, EPI_PLAIN)
+        self.wgrad(addr(dF), ldf, addr(H[8]), 256, P, 256, 256, addr(*self.nerf_feat.dWp), 256,
                    addr(flat, self.nerf_feat.db_off))
         # density head: dH8_alpha (masked by relu'(H8)), then add the feature path
         dH8a = e(P, 256)
         self.skinny_bwd(addr(dsig), 1, addr(H[8]), 256, P, 256, addr(*self.nerf_alpha.Wp), 256, 1, addr(dH8a), 256, 1, 0,
                         addr(*self.nerf_alpha.dWp), 256, addr(flat, self.nerf_alpha.db_off))
         dA = e(P, 256)
-        self.nt(addr(dF), 256, addr(*self.nerf_feat.WpT), self.nerf_feat.ldT, P, 256, 256, addr(dA), 256, EPI_B_RELU,
+        self.nt(addr(dF), ldf, addr(*self.nerf_feat.WpT), self.nerf_feat.ldT, P, 256, 256, addr(dA), 256, EPI_B_RELU,
                 H=addr(H[8]), ldh=256, Cadd=addr(dH8a), ldadd=256)
-        # trunk, layers 7..0 ; dA = d pre-activation of layer i
+        # trunk, layers 7..0 ; dA = d pre-activation of layer i (row stride lda)
+        dskip, lda = None, 256
         for i in range(7, -1, -1):
             lay = self.nerf[i]
             ldu = 96 if i == 0 else (352 if i == 5 else 256)
-            self.wgrad(addr(dA), 256, addr(H[i]), ldu, P, 256, lay.Kp, addr(*lay.dWp), lay.ldd, addr(flat, lay.db_off))
+            self.wgrad(addr(dA), lda, addr(H[i]), ldu, P, 256, lay.Kp, addr(*lay.dWp), lay.ldd, addr(flat, lay.db_off))
             if i > 0:
-                nxt = e(P, 256)
-                self.nt(addr(dA), 256, addr(*lay.WpT), lay.ldT, P, 256, 256, addr(nxt), 256, EPI_MUL_DRELU,
-                        H=addr(H[i]), ldh=ldu)
-                dA = nxt
+                if i == 5 and want_in:
+                    # columns 256..339 of the layer-5 input are the re-concatenated embedding: keep their plain gradient
+                    nxt = e(P, 352)
+                    self.nt(addr(dA), lda, addr(*lay.WpT), lay.ldT, P, 340, 256, addr(nxt), 352, EPI_MUL_DRELU,
+                            H=addr(H[i]), ldh=ldu, act_cols=256, zero_to=352)
+                    dskip = nxt
+                    dA, lda = nxt, 352
+                else:
+                    nxt = e(P, 256)
+                    self.nt(addr(dA), lda, addr(*lay.WpT), lay.ldT, P, 256, 256, addr(nxt), 256, EPI_MUL_DRELU,
+                            H=addr(H[i]), ldh=ldu)
+                    dA, lda = nxt, 256
+            elif want_in:
+                dE4 = e(P, 96)
+                self.nt(addr(dA), lda, addr(*lay.WpT), lay.ldT, P, 84, 256, addr(dE4), 96, EPI_PLAIN, zero_to=96)
+                L.check(lib.nu_nerf_embed_bwd(c_p(addr(pt)), pt.shape[1], c_p(addr(H[0])), c_p(addr(b['V'])), c_p(addr(dE4)), 96,
+                                              c_p(addr(dskip, 256)), 352, c_p(addr(dF, 256)), ldf, P, c_p(addr(dx)),
+                                              c_p(addr(ddir)), S), "nu_nerf_embed_bwd")
 
     # ------------------------------------------------------------------ sampler (no grad)
     def _sampler_consts(self, Nc, Nbg, n_new):

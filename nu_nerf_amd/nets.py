@@ -1,0 +1,205 @@
+"""Network-level differentiable ops over the HIP engine, WITH input gradients.
+
+Stage 1 never needs d L / d x (sample positions do not depend on parameters), so its whole render_core is one fused
+op (renderer._RenderCoreFn).  Stage 2 does: refracted directions, hit points and therefore every sample position
+depend on the learned IoR (renderer_zerothick.py:1642-1684).  These Functions expose the three MLP stacks at network
+granularity -- value, SDF normal (second order) and gradients w.r.t. parameters AND inputs -- so that the ragged
+per-bounce bookkeeping of stage 2 can stay in torch while every GEMM runs in the HIP library.
+
+  SdfFn       x[P,3]                -> y[P,257] (sdf | feature), n[P,3] = d sdf / d x       (field.py:133-170)
+  NerfFn      x[P,3], dir[P,3]      -> sigma[P], rgb_raw[P,3]  (inputs (x/|x|, 1/|x|), -dir) (field.py:265-289)
+  StackFn     X[rows, K]            -> raw[rows, n_out]   one make_predictor stack          (field.py:371-408)
+  MaterialsFn feat[P,256], x[P,3]   -> raw[P,6] (metallic, roughness, albedo(3), transmission; pre-sigmoid)
+"""
+import numpy as np
+import torch
+
+from .engine import addr, rup
+
+
+def _grads_from_flat(eng, flat, names):
+    out = []
+    for n in names:
+        off, shape = eng.grad_views[n]
+        numel = int(np.prod(shape)) if len(shape) else 1
+        out.append(flat[off:off + numel].view(shape))
+    return out
+
+
+class SdfFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, eng, x, names, *params):
+        x = x.detach().contiguous()
+        P = x.shape[0]
+        a = eng.sdf_forward(addr(x), 3, P, keep=True, want_feat=True)
+        n = eng.sdf_normal(a)
+        ctx.eng, ctx.a, ctx.names = eng, a, names
+        ctx.set_materialize_grads(False)
+        return a['YX'][:, :257].clone(), n.clone()
+
+    @staticmethod
+    def backward(ctx, dy, dn):
+        eng, a = ctx.eng, ctx.a
+        P = a['P']
+        flat = eng.zeros(eng.n_grad)
+        dYX = eng.zeros(P, 288)
+        if dy is not None:
+            dYX[:, :257] = dy
+        nbar = dn.contiguous() if dn is not None else None
+        dx = eng.empty(P, 3)
+        eng.sdf_backward(a, dYX, nbar, flat, dx=dx)
+        eng.unpack_grads(flat)
+        ctx.a = None
+        return (None, dx, None) + tuple(_grads_from_flat(eng, flat, ctx.names))
+
+
+class NerfFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, eng, x, d, names, *params):
+        P = x.shape[0]
+        pt = eng.zeros(P, 8)
+        pt[:, :3] = x.detach()
+        pt[:, 4:7] = d.detach()
+        b = eng.nerf_forward(pt, None, P, None, None)
+        ctx.eng, ctx.b, ctx.pt, ctx.names = eng, b, pt, names
+        ctx.set_materialize_grads(False)
+        return b['sig'].clone(), b['rgb'][:, :3].clone()
+
+    @staticmethod
+    def backward(ctx, dsig, drgb):
+        eng, b, pt = ctx.eng, ctx.b, ctx.pt
+        P = b['P']
+        flat = eng.zeros(eng.n_grad)
+        ds = dsig.contiguous() if dsig is not None else eng.zeros(P)
+        dr = eng.zeros(P, 4)
+        if drgb is not None:
+            dr[:, :3] = drgb
+        dx, dd = eng.empty(P, 3), eng.empty(P, 3)
+        eng.nerf_backward(b, pt, None, None, None, flat, dsig=ds, drgb=dr, dx=dx, ddir=dd)
+        eng.unpack_grads(flat)
+        ctx.b = None
+        return (None, dx, dd, None) + tuple(_grads_from_flat(eng, flat, ctx.names))
+
+
+class StackFn(torch.autograd.Function):
+    """One make_predictor stack (3 hidden ReLU layers + skinny head) on already-encoded inputs."""
+
+    @staticmethod
+    def forward(ctx, eng, layers, X, names, *params):
+        rows, K = X.shape
+        Kp = layers[0].Kp
+        Xp = eng.zeros(rows, Kp)
+        Xp[:, :K] = X.detach()
+        Hs = eng.relu_stack_fwd(layers, Xp, Kp, rows)
+        head = layers[3]
+        no = head.N
+        out = eng.empty(rows, 4)
+        eng.skinny_fwd(addr(Hs[2]), 256, rows, 256, addr(*head.Wp), 256, addr(head.b), no, addr(out), 4)
+        ctx.eng, ctx.layers, ctx.Xp, ctx.Hs, ctx.names, ctx.K, ctx.no = eng, layers, Xp, Hs, names, K, no
+        ctx.set_materialize_grads(False)
+        return out[:, :no].clone()
+
+    @staticmethod
+    def backward(ctx, dout):
+        eng, layers, Xp, Hs = ctx.eng, ctx.layers, ctx.Xp, ctx.Hs
+        rows, Kp = Xp.shape
+        flat = eng.zeros(eng.n_grad)
+        dy = eng.zeros(rows, 4)
+        if dout is not None:
+            dy[:, :ctx.no] = dout
+        head = layers[3]
+        dH3 = eng.empty(rows, 256)
+        eng.skinny_bwd(addr(dy), 4, addr(Hs[2]), 256, rows, 256, addr(*head.Wp), 256, ctx.no, addr(dH3), 256, 1, 0,
+                       addr(*head.dWp), head.ldd, addr(flat, head.db_off))
+        dX = eng.empty(rows, Kp)
+        eng.relu_stack_bwd(layers, Xp, Kp, rows, Hs, dH3, flat, dX, Kp, Kp)
+        eng.unpack_grads(flat)
+        ctx.Hs = ctx.Xp = None
+        return (None, None, dX[:, :ctx.K], None) + tuple(_grads_from_flat(eng, flat, ctx.names))
+
+
+class MaterialsFn(torch.autograd.Function):
+    """The four material predictors batched (metallic, roughness, albedo, transmission) on [feature, x]."""
+
+    @staticmethod
+    def forward(ctx, eng, feat, x, names, *params):
+        from .engine import EPI_BIAS_RELU
+        P = feat.shape[0]
+        YX = eng.zeros(P, 288)
+        YX[:, 1:257] = feat.detach()
+        YX[:, 257:260] = x.detach()
+        e = eng.empty
+        M1, M2, M3 = e(P, 1024), e(P, 1024), e(P, 1024)
+        eng.nt(addr(YX), 288, addr(eng.WpM0), 288, P, 1024, 288, addr(M1), 1024, EPI_BIAS_RELU, bias=addr(eng.bM0))
+        for j, (src, dst) in ((1, (M1, M2)), (2, (M2, M3))):
+            eng.nt(addr(src), 1024, addr(eng.WpM[j]), 256, P, 256, 256, addr(dst), 1024, EPI_BIAS_RELU,
+                   bias=addr(eng.bM[j]), groups=4, sA=256, sB=65536, sC=256, sBias=256)
+        Mraw = e(P, 8)
+        eng.skinny_fwd(addr(M3), 1024, P, 1024, addr(eng.Ws6), 1024, addr(eng.b6), 6, addr(Mraw), 8)
+        ctx.eng, ctx.s, ctx.names = eng, dict(YX=YX, M1=M1, M2=M2, M3=M3), names
+        ctx.set_materialize_grads(False)
+        return Mraw[:, :6].clone()
+
+    @staticmethod
+    def backward(ctx, dM):
+        from .engine import EPI_MUL_DRELU, EPI_PLAIN
+        eng, s = ctx.eng, ctx.s
+        P = s['YX'].shape[0]
+        e = eng.empty
+        flat = eng.zeros(eng.n_grad)
+        dMraw = eng.zeros(P, 8)
+        if dM is not None:
+            dMraw[:, :6] = dM
+        db0, db12, db6 = eng.mat_db
+        dM3 = e(P, 1024)
+        eng.skinny_bwd(addr(dMraw), 8, addr(s['M3']), 1024, P, 1024, addr(eng.Ws6), 1024, 6, addr(dM3), 1024, 1, 0,
+                       addr(eng.dWs6), 1024, addr(flat, db6))
+        dA = dM3
+        for j, Hin in ((2, s['M2']), (1, s['M1'])):
+            eng.wgrad(addr(dA), 1024, addr(Hin), 1024, P, 256, 256, addr(eng.dWpM[j]), 256, addr(flat, db12[j]),
+                      groups=4, sA0=256, sB0=256, sW=65536, sDb=256)
+            nxt = e(P, 1024)
+            eng.nt(addr(dA), 1024, addr(eng.WpTM[j]), 256, P, 256, 256, addr(nxt), 1024, EPI_MUL_DRELU,
+                   H=addr(Hin), ldh=1024, groups=4, sA=256, sB=65536, sC=256, sH=256)
+            dA = nxt
+        eng.wgrad(addr(dA), 1024, addr(s['YX']), 288, P, 1024, 288, addr(eng.dWpM0), 288, addr(flat, db0))
+        dYX = e(P, 288)
+        eng.nt(addr(dA), 1024, addr(eng.WpTM0), 1024, P, 288, 1024, addr(dYX), 288, EPI_PLAIN)
+        eng.unpack_grads(flat)
+        ctx.s = None
+        return (None, dYX[:, 1:257], dYX[:, 257:260], None) + tuple(_grads_from_flat(eng, flat, ctx.names))
+
+
+class Stage1Nets:
+    """Differentiable callables over one Stage1Engine (SDF, variance, NeRF++, the shading predictors)."""
+
+    def __init__(self, eng, named, prefix_map=None):
+        self.eng = eng
+        g = list(eng.grad_views.keys())
+        self.named = named
+
+        def sel(pred):
+            names = [n for n in g if pred(n)]
+            return names, [named[n] for n in names]
+        self.sdf_names, self.sdf_params = sel(lambda n: n.startswith('sdf_network.'))
+        self.nerf_names, self.nerf_params = sel(lambda n: n.startswith('outer_nerf.'))
+        mats = ('metallic_predictor', 'roughness_predictor', 'albedo_predictor', 'transmisstion_weight')
+        self.mat_names, self.mat_params = sel(lambda n: n.startswith(tuple('color_network.' + m + '.' for m in mats)))
+        self.stack = {}
+        for nm, layers in (('outer_light', eng.outer_light), ('inner_light', eng.inner_light),
+                           ('inner_weight', eng.inner_weight), ('refrac_light', eng.refrac_light)):
+            names, params = sel(lambda n, nm=nm: n.startswith('color_network.' + nm + '.'))
+            self.stack[nm] = (layers, names, params)
+
+    def sdf(self, x):
+        return SdfFn.apply(self.eng, x, self.sdf_names, *self.sdf_params)
+
+    def nerf(self, x, d):
+        return NerfFn.apply(self.eng, x, d, self.nerf_names, *self.nerf_params)
+
+    def materials(self, feat, x):
+        return MaterialsFn.apply(self.eng, feat, x, self.mat_names, *self.mat_params)
+
+    def predictor(self, name, X):
+        layers, names, params = self.stack[name]
+        return StackFn.apply(self.eng, layers, X, names, *params)

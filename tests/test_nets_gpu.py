@@ -1,0 +1,109 @@
+"""GPU parity of the network-level ops WITH input gradients (nu_nerf_amd/nets.py) against torch autograd on the CPU oracle:
+SDF value / normal / second-order input gradient, NeRF++ input gradients, predictor stacks, batched materials."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import parity_params, rel_err
+from oracle import stage1_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def nets(gpu):
+    from nu_nerf_amd.renderer import NeROShapeRenderer
+    from nu_nerf_amd.params import init_stage1_params, randomize_for_parity
+    from nu_nerf_amd.nets import Stage1Nets
+    net = NeROShapeRenderer({'is_nerf': True}, training=False)
+    net.load_param_dict(randomize_for_parity(init_stage1_params(6033), seed=1))
+    net = net.to(gpu)
+    eng = net.engine()
+    eng.pack()
+    return net, Stage1Nets(eng, net._named())
+
+
+def test_sdf_value_normal_and_input_gradient(nets, gpu):
+    net, N = nets
+    g = np.random.Generator(np.random.PCG64(21))
+    P = 300
+    x = torch.from_numpy(g.uniform(-0.8, 0.8, (P, 3)).astype(np.float32))
+    cy = torch.from_numpy(g.standard_normal((P, 257)).astype(np.float32))
+    cn = torch.from_numpy(g.standard_normal((P, 3)).astype(np.float32))
+    # oracle: y(x), n(x) with x requiring grad -> dL/dx incl. the Hessian-vector term
+    Pm = parity_params(requires_grad=True)
+    xo = x.clone().requires_grad_(True)
+    y = O.sdf_forward(Pm, xo)
+    (n,) = torch.autograd.grad(y[:, :1], xo, torch.ones(P, 1), create_graph=True)
+    L = (y * cy).sum() + (n * cn).sum()
+    gx, gw = torch.autograd.grad(L, [xo, Pm['sdf_network.lin2.weight_v']])
+    # HIP
+    xg = x.to(gpu).requires_grad_(True)
+    net.zero_grad()
+    yg, ng = N.sdf(xg)
+    assert rel_err(yg.cpu(), y) < 1e-5 and rel_err(ng.cpu(), n) < 1e-5
+    ((yg * cy.to(gpu)).sum() + (ng * cn.to(gpu)).sum()).backward()
+    assert rel_err(xg.grad.cpu(), gx) < 1e-4
+    assert rel_err(net.sdf_network.lin2.weight_v.grad.cpu(), gw) < 1e-4
+    # first-order only (no cotangent on n)
+    xg2 = x.to(gpu).requires_grad_(True)
+    y2, _ = N.sdf(xg2)
+    (y2 * cy.to(gpu)).sum().backward()
+    xo2 = x.clone().requires_grad_(True)
+    (O.sdf_forward(parity_params(), xo2) * cy).sum().backward()
+    assert rel_err(xg2.grad.cpu(), xo2.grad) < 1e-4
+
+
+def test_nerf_input_gradients(nets, gpu):
+    net, N = nets
+    g = np.random.Generator(np.random.PCG64(22))
+    P = 257
+    x = torch.from_numpy((g.standard_normal((P, 3)) * 2.0).astype(np.float32))
+    x = x * (1.2 / x.norm(dim=1, keepdim=True)).clamp(min=1.0)            # outside the unit sphere
+    d = torch.nn.functional.normalize(torch.from_numpy(g.standard_normal((P, 3)).astype(np.float32)), dim=-1)
+    cs = torch.from_numpy(g.standard_normal(P).astype(np.float32))
+    cr = torch.from_numpy(g.standard_normal((P, 3)).astype(np.float32))
+    Pm = parity_params(requires_grad=True)
+    xo, do = x.clone().requires_grad_(True), d.clone().requires_grad_(True)
+    nn = xo.norm(dim=-1, keepdim=True)
+    sig, rgb = O.nerf_forward(Pm, torch.cat([xo / nn, 1.0 / nn], -1), -do)
+    ((sig[:, 0] * cs).sum() + (rgb * cr).sum()).backward()
+    xg, dg = x.to(gpu).requires_grad_(True), d.to(gpu).requires_grad_(True)
+    net.zero_grad()
+    s2, r2 = N.nerf(xg, dg)
+    assert rel_err(s2.cpu(), sig[:, 0]) < 1e-5 and rel_err(r2.cpu(), rgb) < 1e-5
+    ((s2 * cs.to(gpu)).sum() + (r2 * cr.to(gpu)).sum()).backward()
+    assert rel_err(xg.grad.cpu(), xo.grad) < 1e-4
+    assert rel_err(dg.grad.cpu(), do.grad) < 1e-4
+    assert rel_err(net.outer_nerf.pts_linears[5].weight.grad.cpu(), Pm['outer_nerf.pts_linears.5.weight'].grad) < 1e-4
+
+
+def test_predictor_stack_and_materials(nets, gpu):
+    net, N = nets
+    g = np.random.Generator(np.random.PCG64(23))
+    P = 200
+    Pm = parity_params(requires_grad=True)
+    X = torch.from_numpy(g.standard_normal((P, 111)).astype(np.float32) * 0.5)
+    co = torch.from_numpy(g.standard_normal((P, 3)).astype(np.float32))
+    Xo = X.clone().requires_grad_(True)
+    (O.predictor(Pm, 'color_network.inner_light', Xo, 'none') * co).sum().backward()
+    Xg = X.to(gpu).requires_grad_(True)
+    net.zero_grad()
+    out = N.predictor('inner_light', Xg)
+    (out * co.to(gpu)).sum().backward()
+    assert rel_err(Xg.grad.cpu(), Xo.grad) < 1e-4
+    assert rel_err(net.color_network.inner_light[0].weight_v.grad.cpu(), Pm['color_network.inner_light.0.weight_v'].grad) < 1e-4
+    # materials
+    feat = torch.from_numpy((0.3 * g.standard_normal((P, 256))).astype(np.float32))
+    x = torch.from_numpy(g.uniform(-0.6, 0.6, (P, 3)).astype(np.float32))
+    cm = torch.from_numpy(g.standard_normal((P, 6)).astype(np.float32))
+    fo, xo = feat.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    fx = torch.cat([fo, xo], -1)
+    raws = [O.predictor(Pm, f'color_network.{n}', fx, 'none') for n in
+            ('metallic_predictor', 'roughness_predictor', 'albedo_predictor', 'transmisstion_weight')]
+    (torch.cat(raws, -1) * cm).sum().backward()
+    fg, xg = feat.to(gpu).requires_grad_(True), x.to(gpu).requires_grad_(True)
+    m = N.materials(fg, xg)
+    assert rel_err(m.cpu(), torch.cat(raws, -1)) < 1e-5
+    (m * cm.to(gpu)).sum().backward()
+    assert rel_err(fg.grad.cpu(), fo.grad) < 1e-4 and rel_err(xg.grad.cpu(), xo.grad) < 1e-4
