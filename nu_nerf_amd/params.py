@@ -144,3 +144,48 @@ def randomize_for_parity(params, seed=1):
 
 def count_params(params):
     return int(sum(v.size for k, v in params.items() if not k.endswith("FG_LUT")))
+
+
+def init_ior_params(rng, prefix):
+    """IoRNetwork / ThicknessNetwork (field.py:1046-1087): Sequential 0,2,4,5 = weight-normed linears 39-256-256-256-1."""
+    p = OrderedDict()
+    for idx, (k, n) in zip((0, 2, 4, 5), ((39, 256), (256, 256), (256, 256), (256, 1))):
+        w, b = _linear_default(rng, n, k)
+        _put_wn(p, f"{prefix}.module0.{idx}", w, b)
+    return p
+
+
+def init_stage2_params(seed=6033, inner_seed=7044, shader_cfg=None):
+    """Stage2Renderer.state_dict() names in the reference's registration order (renderer_zerothick.py:919-978):
+    nerf_network, IORs, stage1_network.*, IORs_pred, IoRint_pred, thickness_pred, outer_nerf, color_network.stage1_network.*
+    (the same tensors again), sdf_network_inner, deviation_network_inner, color_network_inner."""
+    shader_cfg = shader_cfg or {}
+    sd = bool(shader_cfg.get('sphere_direction', False))
+    rf = int(shader_cfg.get('refrac_freq', 6))
+    s1 = init_stage1_params(seed, sphere_direction=sd, refrac_freq=rf)
+    inner = init_stage1_params(inner_seed, sphere_direction=sd, refrac_freq=rf)
+    rng = np.random.Generator(np.random.PCG64(seed + 17))
+    p = OrderedDict()
+    p['IORs'] = np.zeros(10, np.float32)          # the module's own parameter precedes its children in state_dict()
+    extra_nerf = init_stage1_params(seed + 1)
+    for k, v in extra_nerf.items():
+        if k.startswith('outer_nerf.'):
+            p['nerf_network.' + k[len('outer_nerf.'):]] = v
+    for k, v in s1.items():
+        p['stage1_network.' + k] = v
+    p.update(init_ior_params(rng, 'IORs_pred'))
+    p.update(init_ior_params(rng, 'IoRint_pred'))
+    p.update(init_ior_params(rng, 'thickness_pred'))
+    for k, v in init_stage1_params(seed + 2).items():
+        if k.startswith('outer_nerf.'):
+            p[k] = v
+    for k, v in s1.items():
+        p['color_network.stage1_network.' + k] = v
+    for k, v in inner.items():
+        if k.startswith('sdf_network.'):
+            p['sdf_network_inner.' + k[len('sdf_network.'):]] = v
+    p['deviation_network_inner.variance'] = inner['deviation_network.variance']
+    for k, v in inner.items():
+        if k.startswith('color_network.'):
+            p['color_network_inner.' + k[len('color_network.'):]] = v
+    return p

@@ -57,3 +57,18 @@ def make_jitter(n_rays, n_bg, seed):
     """The two uniform draws `sample_ray` consumes per step (renderer_zerothick.py:585,591)."""
     rng = np.random.Generator(np.random.PCG64(seed))
     return rng.uniform(0, 1, (n_rays, 1)).astype(np.float32), rng.uniform(0, 1, (n_rays, n_bg)).astype(np.float32)
+
+
+def make_object_rays(n_rays, seed=6033, cam_radius=4.0, aim_radius=0.7):
+    """Rays from the camera shell aimed at random points within `aim_radius` of the origin: a controllable mix of rays that
+    hit / graze / miss a small object (used by the stage-2 and mesh-tracing tests, where most image rays would miss)."""
+    g = np.random.Generator(np.random.PCG64(seed))
+    o = g.standard_normal((n_rays, 3))
+    o = o / np.linalg.norm(o, axis=1, keepdims=True) * cam_radius
+    o[:, 2] = np.abs(o[:, 2])
+    t = g.standard_normal((n_rays, 3))
+    t = t / np.linalg.norm(t, axis=1, keepdims=True) * (aim_radius * g.uniform(0, 1, (n_rays, 1)) ** (1 / 3))
+    d = t - o
+    d = d / np.linalg.norm(d, axis=1, keepdims=True)
+    rgbs = g.uniform(0, 1, (n_rays, 3))
+    return {'rays_o': o.astype(np.float32), 'rays_d': d.astype(np.float32), 'rgbs': rgbs.astype(np.float32)}

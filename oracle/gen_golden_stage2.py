@@ -1,0 +1,131 @@
+"""Golden vectors for STAGE 2 from the reference's own Stage2Renderer (build container only).
+
+The reference class is constructed under the shims of oracle/gen_golden.py; its OptiX-backed `Scene` is replaced by a
+brute-force scene with the same `Dintersect` contract (closest hit by oracle/lbvh_oracle.py, then the reference's own
+JIT_Dintersect / Intersection), everything after the intersection is the reference's code.  The stage-1 checkpoint, the
+stage-1 config and the mesh the constructor reads are written to a temp dir from our seed-reproducible generators.
+"""
+import os
+import sys
+import tempfile
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+from oracle.gen_golden import install_shims, to_t, OUT   # noqa: E402
+
+
+def main():
+    install_shims()
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    import yaml
+    import network.renderer_zerothick as rz
+    import network.DiffRender as DR
+    from network.loss import name2loss
+    from oracle.lbvh_oracle import brute_force_closest_hit
+    from nu_nerf_amd.params import init_stage1_params, init_stage2_params, randomize_for_parity
+    from nu_nerf_amd.synthetic import make_object_rays
+    from nu_nerf_amd.lbvh import icosphere, corner_angles_and_face_normals
+
+    V, F = icosphere(3, 0.5)
+
+    class FakeScene:
+        def __init__(self, mesh_path):
+            self.vertices = torch.from_numpy(V)
+            self.faces = torch.from_numpy(F.astype(np.int64))
+            tri = self.vertices[self.faces]
+            ang, fn = corner_angles_and_face_normals(tri)
+            vn = torch.zeros_like(self.vertices)
+            vn.index_add_(0, self.faces.reshape(-1), (ang[:, :, None] * fn[:, None, :]).reshape(-1, 3))
+            self.normals = vn / vn.norm(dim=1, keepdim=True)
+            self.curv = torch.zeros(self.vertices.shape[0], 1)
+
+        def Dintersect(self, ray):
+            rays = torch.cat([ray.origin, ray.direction], 1).detach().numpy().astype(np.float32)
+            hit, idx, _ = brute_force_closest_hit(V, F, rays)
+            hitted = torch.from_numpy(hit > 0)
+            faces_ind = torch.from_numpy(idx.astype(np.int64))
+            f = self.faces[faces_ind[hitted]]
+            rh = ray.select(hitted)
+            u, v, t, n, gk = DR.JIT_Dintersect(rh.origin, rh.direction, self.vertices[f].float(), self.normals[f].float(),
+                                               self.curv[f].float())
+            return DR.Intersection(u=u, v=v, t=t, n=n, g_k=gk, ray=rh, faces_ind=faces_ind[hitted]), hitted
+
+    rz.Scene = FakeScene
+    tmp = tempfile.mkdtemp()
+    s1 = randomize_for_parity(init_stage1_params(6033), seed=1)
+    torch.save({'network_state_dict': to_t(s1)}, os.path.join(tmp, 's1.pth'))
+    s1cfg = {'name': 's1', 'network': 'shape', 'database_name': 'nerf/spherepot', 'is_nerf': True, 'apply_occ_loss': True,
+             'occ_loss_step': 15000, 'freeze_inv_s_step': 15000, 'zero_thickness': True}
+    with open(os.path.join(tmp, 's1.yaml'), 'w') as fh:
+        yaml.safe_dump(s1cfg, fh)
+    cfg = {'name': 'golden_s2', 'network': 'stage2', 'database_name': 'nerf/spherepot', 'is_nerf': True,
+           'shader_config': {'sphere_direction': False, 'human_light': False}, 'apply_occ_loss': True, 'occ_loss_step': 20000,
+           'loss': ['eikonal', 'std', 'nerf_render'], 'eikonal_weight': 0.02, 'freeze_inv_s_step': 5000,
+           'stage1_ckpt_dir': os.path.join(tmp, 's1.pth'), 'stage1_cfg_dir': os.path.join(tmp, 's1.yaml'),
+           'stage1_mesh_dir': 'unused.ply'}
+    net = rz.Stage2Renderer(cfg, training=False)
+    keys = list(net.state_dict().keys())
+    p2 = init_stage2_params(6033, 7044, cfg['shader_config'])
+    p2 = randomize_for_parity(p2, seed=3)
+    # stage-1 part must equal the checkpoint values used above (both aliases)
+    for k, v in s1.items():
+        p2['stage1_network.' + k] = v
+        p2['color_network.stage1_network.' + k] = v
+    missing = [k for k in keys if k not in p2]
+    extra = [k for k in p2 if k not in keys]
+    print("state_dict keys:", len(keys), "missing in ours:", missing[:5], "extra:", extra[:5])
+    print("load:", net.load_state_dict(to_t(p2), strict=True))
+    losses = [name2loss[n](cfg) for n in cfg['loss']]
+    R, step = 24, 6000
+    rays = make_object_rays(R, seed=500)
+    o, d, rgbs = (torch.from_numpy(rays[k]) for k in ('rays_o', 'rays_d', 'rgbs'))
+    dn = torch.nn.functional.normalize(d, dim=-1)
+    net.zero_grad()
+    pathes, converges, directions, ior_ratios, infinity_bkgr, gradient_mesh, tir_mask = net.ray_trace(o, dn)
+    print("segments", len(pathes), "converged per bounce", [int(c.sum()) for c in converges], "rays per segment",
+          [int(p.shape[0]) for p in pathes], "samples", [int(p.shape[1]) for p in pathes])
+    net.zero_grad()
+    outputs = net.render(o, dn, None, None, None, -1, net.get_anneal_val(step), is_train=True, step=step, is_nerf=True)
+    outputs['loss_rgb'] = net.compute_rgb_loss(outputs['ray_rgb'] * outputs['tir_mask'].detach(), rgbs * outputs['tir_mask'].detach())
+    log = {}
+    for ls in losses:
+        log.update(ls(outputs, {}, step))
+    total = 0
+    for k, v in log.items():
+        if k.startswith('loss'):
+            total = total + torch.mean(v)
+    total.backward()
+    res = {'rays_o': rays['rays_o'], 'rays_d': rays['rays_d'], 'rgbs': rays['rgbs'], 'step': np.asarray(step),
+           'total_loss': total.detach().numpy(), 'out_ray_rgb': outputs['ray_rgb'].detach().numpy(),
+           'out_tir_mask': outputs['tir_mask'].numpy(), 'out_gradient_error': outputs['gradient_error'].detach().numpy(),
+           'out_std': outputs['std'].detach().numpy(),
+           'path0': pathes[0].detach().numpy(), 'conv0': converges[0].numpy(),
+           'path1': pathes[1].detach().numpy() if len(pathes) > 1 else np.zeros(0),
+           'conv1': converges[1].numpy() if len(converges) > 1 else np.zeros(0),
+           'path2': pathes[2].detach().numpy() if len(pathes) > 2 else np.zeros(0),
+           'ior0': ior_ratios[0].detach().numpy() if len(ior_ratios) > 0 else np.zeros(0),
+           'dir1': directions[1].detach().numpy()}
+    for k, v in log.items():
+        if k.startswith('loss'):
+            res['term_' + k] = torch.mean(v).detach().numpy()
+    gn = {n: p.grad for n, p in net.named_parameters() if p.grad is not None}
+    res['grad_names'] = np.asarray(sorted(gn.keys()))
+    res['grad_norms'] = np.asarray([float(gn[k].double().norm()) for k in sorted(gn.keys())])
+    for k in ('IORs_pred.module0.0.weight_v', 'IORs_pred.module0.5.bias', 'sdf_network_inner.lin4.weight_v',
+              'stage1_network.sdf_network.lin8.weight_v', 'stage1_network.outer_nerf.pts_linears.0.weight',
+              'color_network_inner.albedo_predictor.6.bias', 'stage1_network.color_network.outer_light.6.weight_v'):
+        if k in gn:
+            res['grad__' + k] = gn[k].numpy().copy()
+    res['state_dict_keys'] = np.asarray(keys)
+    np.savez_compressed(os.path.join(OUT, "stage2_step6000_r24.npz"), **res)
+    print("stage2 loss", float(total), {k: float(v) for k, v in res.items() if k.startswith('term_')},
+          "tir", outputs['tir_mask'].flatten().tolist()[:8], "n grads", len(gn))
+    print("params without grad:", sorted(set(n.split('.')[0] for n, p in net.named_parameters() if p.grad is None)))
+
+
+if __name__ == "__main__":
+    main()

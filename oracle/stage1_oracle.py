@@ -130,6 +130,17 @@ def sdf_gradient(params, x, prefix='sdf_network'):
     return g
 
 
+def sdf_gradient_wrt(params, x, prefix='sdf_network'):
+    """Same as sdf_gradient but keeps x's own graph (stage 2: x depends on the IoR network), as the reference's
+    `gradient()` does when handed a non-leaf tensor (field.py:158-170)."""
+    if not x.requires_grad:
+        x = x.detach().requires_grad_(True)
+    with torch.enable_grad():
+        y = sdf_forward(params, x, prefix)[..., :1]
+        (g,) = torch.autograd.grad(y, x, torch.ones_like(y), create_graph=True)
+    return g
+
+
 def inv_s_value(params):
     """SingleVarianceNetwork: exp(10 * variance)  (field.py:197-199)."""
     return torch.exp(params['deviation_network.variance'] * 10.0)
