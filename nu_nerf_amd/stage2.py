@@ -1,0 +1,451 @@
+"""Stage-2 renderer (zero-thickness variant): drop-in for `Stage2Renderer` of network/renderer_zerothick.py:868-2055
+(`name2renderer['stage2']`, registry :2057-2060).
+
+What runs where in this first version:
+  * mesh closest-hit tracing: HIP LBVH (nu_nerf_amd/lbvh.py) instead of OptiX + its host round trips;
+  * every MLP contraction (stage-1 SDF / NeRF++ / shading predictors, inner SDF / shading) incl. second-order SDF terms and
+    the INPUT gradients that carry d L / d IoR: HIP GEMMs through nu_nerf_amd/nets.py;
+  * the no-grad segment samplers: HIP sampler kernels for the inner-SDF up-sampling, torch for the NeRF++ importance pass;
+  * the ragged per-bounce bookkeeping, encodings, BRDF mix and segment composites: torch ops (nu_nerf_amd/torch_glue.py);
+  * the IoR network (<= train_ray_num rows per bounce, 0.01 % of the FLOPs): torch.
+state_dict() names/order equal the reference's (574 entries incl. the `color_network.stage1_network.*` aliases).
+"""
+import ctypes
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib as L
+from . import torch_glue as G
+from .engine import Stage1Engine, addr
+from .lbvh import Scene
+from .nets import Stage1Nets
+from .renderer import (AppShadingNetwork, NeRFNetwork, NeROShapeRenderer, SDFNetwork, SingleVarianceNetwork, WNLinear)
+
+
+class IoRNetwork(nn.Module):
+    """Parameter layout of reference IoRNetwork / ThicknessNetwork (field.py:1046-1087): Sequential indices 0,2,4,5."""
+
+    def __init__(self):
+        super().__init__()
+        self.module0 = nn.Sequential(WNLinear(39, 256), nn.ReLU(), WNLinear(256, 256), nn.ReLU(), WNLinear(256, 256),
+                                     WNLinear(256, 1), nn.Sigmoid())
+
+    def forward(self, x):
+        h = G.embed(x, 6)
+        h = F.relu(G.wn_linear(h, self.module0[0]))
+        h = F.relu(G.wn_linear(h, self.module0[2]))
+        h = G.wn_linear(h, self.module0[4])          # no activation between the last two linears (field.py:1056-1057)
+        return torch.sigmoid(G.wn_linear(h, self.module0[5]))
+
+
+class AppShadingNetworkS2(nn.Module):
+    """Holds no parameters of its own; keeps the stage-1 network as a child like the reference (field.py:798-802), which is
+    what puts the `color_network.stage1_network.*` aliases into state_dict()."""
+    default_cfg = {'human_light': False, 'sphere_direction': True, 'light_pos_freq': 6, 'inner_init': -0.95,
+                   'roughness_init': 0.0, 'metallic_init': 0.0, 'light_exp_max': 5.0, 'refrac_freq': 6}
+
+    def __init__(self, cfg, stage1):
+        super().__init__()
+        self.cfg = {**self.default_cfg, **cfg}
+        self.stage1_network = stage1
+
+
+def read_ply(path):
+    """Minimal PLY reader (ascii / binary_little_endian, float xyz vertices, triangle faces)."""
+    with open(path, 'rb') as fh:
+        fmt, nv, nf, vprops, section = None, 0, 0, [], None
+        while True:
+            line = fh.readline().decode('ascii', 'replace').strip()
+            tok = line.split()
+            if tok[:1] == ['format']:
+                fmt = tok[1]
+            elif tok[:2] == ['element', 'vertex']:
+                nv, section = int(tok[2]), 'v'
+            elif tok[:2] == ['element', 'face']:
+                nf, section = int(tok[2]), 'f'
+            elif tok[:1] == ['property'] and section == 'v':
+                vprops.append((tok[1], tok[2]))
+            elif line == 'end_header':
+                break
+        if fmt == 'ascii':
+            rows = [fh.readline().split() for _ in range(nv)]
+            V = np.asarray([[float(r[0]), float(r[1]), float(r[2])] for r in rows], np.float32)
+            Fc = np.asarray([[int(x) for x in fh.readline().split()[1:4]] for _ in range(nf)], np.int32)
+            return V, Fc
+        types = {'float': '<f4', 'float32': '<f4', 'double': '<f8', 'uchar': 'u1', 'uint8': 'u1', 'int': '<i4', 'uint': '<u4',
+                 'short': '<i2', 'ushort': '<u2'}
+        dt = np.dtype([(n, types[t]) for t, n in vprops])
+        vert = np.frombuffer(fh.read(nv * dt.itemsize), dtype=dt, count=nv)
+        V = np.stack([vert['x'], vert['y'], vert['z']], 1).astype(np.float32)
+        fd = np.dtype([('n', 'u1'), ('i', '<i4', (3,))])
+        Fc = np.frombuffer(fh.read(nf * fd.itemsize), dtype=fd, count=nf)['i'].astype(np.int32)
+        return V, Fc
+
+
+class Stage2Renderer(nn.Module):
+    default_cfg = {**NeROShapeRenderer.default_cfg, 'train_ray_num': 1024, 'is_nerf': False}
+
+    def __init__(self, cfg, training=True):
+        super().__init__()
+        self.cfg = {**self.default_cfg, **cfg}
+        self.is_nerf = self.cfg['is_nerf']
+        self.IORs = nn.Parameter(torch.zeros(10))
+        self.nerf_network = NeRFNetwork()
+        self.stage1_network = NeROShapeRenderer(self._load_stage1_cfg(), training=False)
+        self._load_stage1_ckpt()
+        self.IORs_pred = IoRNetwork()
+        self.IoRint_pred = IoRNetwork()
+        self.thickness_pred = IoRNetwork()
+        self.outer_nerf = NeRFNetwork()
+        self.color_network = AppShadingNetworkS2(self.cfg['shader_config'], self.stage1_network)
+        self.sdf_network_inner = SDFNetwork()
+        self.deviation_network_inner = SingleVarianceNetwork(self.cfg['inv_s_init'])
+        self.color_network_inner = AppShadingNetwork(self.cfg['shader_config'])
+        self._init_own_parameters()
+        self._mesh = self._load_mesh()
+        self.scene = None
+        self._nets = None
+        if training:
+            raise NotImplementedError("image databases are out of scope: construct with training=False and feed ray batches")
+
+    # ---- construction helpers ---------------------------------------------------------------------
+    def _load_stage1_cfg(self):
+        c = self.cfg
+        if 'stage1_cfg' in c:
+            return dict(c['stage1_cfg'])
+        import yaml
+        with open(c['stage1_cfg_dir']) as fh:
+            return yaml.safe_load(fh)
+
+    def _load_stage1_ckpt(self):
+        c = self.cfg
+        if c.get('stage1_ckpt_dir') and os.path.exists(c['stage1_ckpt_dir']):
+            ck = torch.load(c['stage1_ckpt_dir'], weights_only=True, map_location='cpu')
+            self.stage1_network.load_state_dict(ck['network_state_dict'], strict=False)
+
+    def _load_mesh(self):
+        c = self.cfg
+        if 'stage1_mesh_arrays' in c:
+            V, Fc = c['stage1_mesh_arrays']
+            return np.asarray(V, np.float32), np.asarray(Fc, np.int32)
+        return read_ply(c['stage1_mesh_dir'])
+
+    def _init_own_parameters(self):
+        from .params import init_stage2_params
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+        init = init_stage2_params(seed, seed + 1, self.cfg['shader_config'])
+        sd = self.state_dict()
+        with torch.no_grad():
+            for k, v in init.items():
+                if k.startswith(('stage1_network.', 'color_network.stage1_network.')):
+                    continue
+                sd[k].copy_(torch.as_tensor(np.asarray(v)).reshape(sd[k].shape))
+
+    def load_param_dict(self, arrays):
+        sd = self.state_dict()
+        with torch.no_grad():
+            for k, v in arrays.items():
+                sd[k].copy_(torch.as_tensor(np.asarray(v)).reshape(sd[k].shape))
+
+    def _apply(self, fn, *a, **k):
+        self._nets = None
+        self.scene = None
+        return super()._apply(fn, *a, **k)
+
+    def nets(self):
+        """(stage-1 nets, inner nets) over two HIP engines + the LBVH scene; rebuilt after device moves."""
+        dev = self.IORs.device
+        if self._nets is None:
+            s1 = self.stage1_network
+            n1 = Stage1Nets(s1.engine(), s1._named())
+            named = {}
+            for k, p in self.sdf_network_inner.named_parameters():
+                named['sdf_network.' + k] = p
+            named['deviation_network.variance'] = self.deviation_network_inner.variance
+            for k, p in self.color_network_inner.named_parameters():
+                named['color_network.' + k] = p
+            named['color_network.FG_LUT'] = self.color_network_inner.FG_LUT
+            for k, p in s1.outer_nerf.named_parameters():      # placeholder: the inner engine never evaluates a NeRF++
+                named['outer_nerf.' + k] = p
+            ecfg = dict(self.cfg)
+            ecfg.update(self.color_network_inner.cfg)
+            n2 = Stage1Nets(Stage1Engine(named, dev, ecfg), named)
+            V, Fc = self._mesh
+            self.scene = Scene(torch.from_numpy(V).to(dev), torch.from_numpy(Fc).to(dev))
+            self._nets = (n1, n2)
+        return self._nets
+
+    def get_anneal_val(self, step):
+        if self.cfg['anneal_end'] < 0:
+            return 1.0
+        return float(np.min([1.0, step / self.cfg['anneal_end']]))
+
+    compute_rgb_loss = NeROShapeRenderer.compute_rgb_loss
+
+    # ---- pieces -----------------------------------------------------------------------------------
+    def _density_alpha(self, n1, pts, dists, dirs):
+        """compute_density_alpha with the stage-1 NeRF++ (renderer_zerothick.py:1531-1540); dirs = ray directions."""
+        sig, rgb = n1.nerf(pts, dirs)
+        alpha = 1.0 - torch.exp(-F.softplus(sig) * dists)
+        return alpha, G.linear_to_srgb(torch.exp(torch.clamp(rgb, max=5.0)))
+
+    @staticmethod
+    def _lights(nets, exp_max, points, n, refl, rough):
+        """The three outer_light and two inner_light queries + the occlusion weight (field.py:636-682), row-batched."""
+        P = points.shape[0]
+        enc = torch.cat([G.ide(n, torch.ones_like(rough)), G.ide(refl, rough), G.ide(refl, torch.zeros_like(rough))], 0)
+        lo = torch.exp(torch.clamp(nets.predictor('outer_light', enc), max=exp_max))
+        pe = G.embed(points, 6)
+        li = torch.exp(torch.clamp(nets.predictor('inner_light', torch.cat([torch.cat([pe, enc[P:2 * P]], -1),
+                                                                              torch.cat([pe, enc[2 * P:]], -1)], 0)), max=exp_max))
+        occ = nets.predictor('inner_weight', torch.cat([pe.detach(), G.embed(refl, 6).detach()], -1)) * 0.5 + 0.5
+        occ_c = torch.clamp(occ, 0.0, 1.0)
+        light = li[:P] * occ_c + lo[P:2 * P] * (1 - occ_c)
+        light0 = li[P:] * occ_c + lo[2 * P:] * (1 - occ_c)
+        return lo[:P], light, light0
+
+    def _shading(self, nets, scfg, lut, points, normals, view_dirs, feats, s2=False, is_internal=False):
+        """AppShadingNetwork.forward (field.py:684-777) or, with s2=True, AppShadingNetwork_S2.forward (field.py:909-1010);
+        sphere_direction False."""
+        exp_max = scfg['light_exp_max']
+        n, v = F.normalize(normals, dim=-1), F.normalize(view_dirs, dim=-1)
+        nov = torch.sum(n * v, -1, keepdim=True)
+        refl = nov * n * 2 - v
+        m = torch.sigmoid(nets.materials(feats, points))
+        metallic, rough, albedo, trans = m[:, 0:1], m[:, 1:2], m[:, 2:5], m[:, 5:6]
+        diffuse_light, light, light0 = self._lights(nets, exp_max, points, n, refl, rough)
+        t = torch.clamp(1 - nov, 0.0, 1.0)
+        fres = torch.clamp(0.04 + 0.96 * t * t * t * t * t, 0.0, 1.0)
+        fg = G.lut_bilinear_clamp(lut[0], torch.cat([torch.clamp(nov, 0.0, 1.0), torch.clamp(rough, 0.0, 1.0)], -1))
+        spec_albedo = 0.04 * (1 - metallic) + metallic * albedo
+        base = ((1 - metallic) * albedo * diffuse_light + (spec_albedo * fg[:, 0:1] + fg[:, 1:2]) * light) * (1 - trans)
+        if s2:
+            color = base + (fres * light0) * trans
+            if is_internal:
+                color = color * 0
+            return G.linear_to_srgb(color), (1 - fres) * trans
+        rf = scfg.get('refrac_freq', 6)
+        refrac = torch.exp(torch.clamp(nets.predictor('refrac_light', torch.cat([G.embed(points, rf), G.embed(v, rf)], -1)),
+                                       max=exp_max))
+        return G.linear_to_srgb(base + (fres * light0 + (1 - fres) * refrac) * trans), None
+
+    def _upsample_inner(self, n2, start, dirs, end):
+        """Segment-1 hierarchical sampling against the inner SDF (renderer_zerothick.py:1742-1760): 64 uniform fractions,
+        two rounds of 32 importance samples on the HIP sampler kernels; returns the 128 sorted fractions (no grad).  As in the
+        reference, radii and new SDF samples are taken at start + dir * z with the FRACTION z used as a distance."""
+        eng = n2.eng
+        lib, S = eng.lib, eng.stream()
+        M, dev = start.shape[0], start.device
+        cp = ctypes.c_void_p
+        zn = torch.linspace(0, 1, 64, device=dev)
+        pts = (start[:, None, :] + (end - start)[:, None, :] * zn[None, :, None]).reshape(-1, 3).contiguous()
+        sdf = eng.sdf_forward(addr(pts), 3, M * 64, keep=False, want_feat=False)['sdf']
+        z = zn[None, :].expand(M, 64).contiguous()
+        o, d = start.contiguous(), dirs.contiguous()
+        uv = torch.linspace(0.5 / 32, 1.0 - 0.5 / 32, steps=32).to(dev)
+        var = self.deviation_network_inner.variance
+        sn = 64
+        for it in range(2):
+            zn_new, Xn = eng.empty(M, 32), eng.empty(M * 32, 3)
+            L.check(lib.nu_upsample(cp(addr(o)), cp(addr(d)), cp(addr(z)), cp(addr(sdf)), M, sn, cp(addr(var)),
+                                    ctypes.c_float(64.0 * 2 ** it), 1 if self.cfg['clip_sample_variance'] else 0,
+                                    cp(addr(uv)), 32, cp(addr(zn_new)), cp(addr(Xn)), S), "nu_upsample")
+            last = it == 1
+            sdf_n = None if last else eng.sdf_forward(addr(Xn), 3, M * 32, keep=False, want_feat=False)['sdf']
+            zo, so = eng.empty(M, sn + 32), (None if last else eng.empty(M, sn + 32))
+            L.check(lib.nu_merge_sorted(cp(addr(z)), cp(addr(sdf)), sn, cp(addr(zn_new)), cp(addr(sdf_n)), 32, M,
+                                        cp(addr(zo)), cp(addr(so)), S), "nu_merge_sorted")
+            z, sdf, sn = zo, so, sn + 32
+        return z
+
+    # ---- ray_trace --------------------------------------------------------------------------------
+    def ray_trace(self, rays_o, rays_d):
+        """Up to 3 refraction bounces against the mesh + per-segment sample placement (renderer_zerothick.py:1571-1828)."""
+        n1, n2 = self.nets()
+        scene, dev = self.scene, rays_o.device
+        next_start, next_dir = rays_o, rays_d
+        starts, directions = [rays_o], [rays_d]
+        intersections, converges, infinity_bkgr, ior_ratios, gradient_mesh, tirs = [], [], [], [], [], []
+        outside = True
+        for i in range(3):
+            N = next_start.shape[0]
+            tir = torch.ones(N, 1, dtype=torch.bool, device=dev)
+            inter, hit = scene.Dintersect(next_start, next_dir)
+            point = inter['point']
+            converged = hit.reshape(-1, 1)
+            normal = F.normalize(inter['n'], dim=-1) if outside else -F.normalize(inter['n'], dim=-1)
+            infinity_bkgr.append(~converged)
+            mask = converged.flatten()
+            cos_i = torch.sum(normal * -next_dir[mask], dim=-1, keepdim=True)
+            sin2_i = 1 - cos_i * cos_i
+            ratio = 1 / (self.IORs_pred(point.reshape(-1, 3)).reshape(-1, 1) * 1.0 + 1)
+            if not outside:
+                ratio = 1 / ratio
+            refr = ~(ratio * ratio * sin2_i > 0.999)
+            converged_out = converged.clone()
+            converged_out[mask] = refr
+            tir[mask] = refr.detach()
+            tirs.append(tir)
+            sel = refr.flatten()
+            ratio = ratio[sel]
+            sin2_t = sin2_i[sel] * ratio * ratio
+            nd = ratio * next_dir[converged_out.flatten()] + (ratio * cos_i[sel] - torch.sqrt(1 - sin2_t)) * normal[sel]
+            ns = point[sel] + nd * 1e-5
+            nd = nd / (torch.linalg.norm(nd, dim=-1, keepdim=True) + 0.0001)
+            gm = normal[sel]
+            next_dir, next_start = nd, ns
+            directions.append(nd)
+            starts.append(ns)
+            converges.append(converged_out)
+            intersections.append(point)
+            if torch.all(~converged_out):
+                break
+            gradient_mesh.append(gm)
+            ior_ratios.append(ratio)
+            outside = not outside
+        for i in range(len(tirs) - 1, 0, -1):
+            m = converges[i - 1].flatten()
+            tirs[i - 1][m] = tirs[i - 1][m] & tirs[i]
+        paths = []
+        for k in range(len(converges)):
+            start = starts[k].reshape(-1, 3)
+            dk = directions[k]
+            end = start + dk * 4.5
+            hitk = ~infinity_bkgr[k].flatten()
+            z = torch.linspace(0, 1, 256 if k != 1 else 128, device=dev)
+            sv = start[:, None, :] + (end - start)[:, None, :] * z[None, :, None]
+            if hitk.any():
+                end = end.clone()
+                end[hitk] = intersections[k]
+                sh, eh = start[hitk], end[hitk]
+                sv = sv.clone()
+                if k != 1:
+                    sv[hitk] = sh[:, None, :] + (eh - sh)[:, None, :] * z[None, :, None]
+                else:
+                    with torch.no_grad():
+                        zz = self._upsample_inner(n2, sh.detach(), dk[hitk].detach(), eh.detach())
+                    sv[hitk] = sh[:, None, :] + (eh - sh)[:, None, :] * zz[..., None]
+            if (~hitk).any() and k != 1:
+                miss = ~hitk
+                sm, dm = start[miss], dk[miss]
+                with torch.no_grad():
+                    zo = torch.linspace(0.1, 64.0, 192, device=dev)
+                    M = sm.shape[0]
+                    pts = (sm[:, None, :] + dm[:, None, :] * zo[None, :, None]).detach()
+                    zo2 = zo[None, :].expand(M, 192)
+                    dists = zo2[..., 1:] - zo2[..., :-1]
+                    dists = torch.cat([dists, dists[..., -1:]], -1)
+                    alpha, _ = self._density_alpha(n1, pts.reshape(-1, 3), dists.reshape(-1),
+                                                   dm.detach()[:, None, :].expand(-1, 192, 3).reshape(-1, 3))
+                    alpha = alpha.reshape(M, 192)
+                    w = alpha * G.cumprod_excl(alpha)[:, :-1]
+                    newz = G.sample_pdf_det(zo2.contiguous(), w[:, :-1], 64)
+                    zo2 = torch.sort(torch.cat([zo2, newz], -1), dim=-1)[0]
+                sv = sv.clone()
+                sv[miss] = sm[:, None, :] + dm[:, None, :] * zo2[..., None]
+            paths.append(sv)
+        return paths, converges, directions, ior_ratios, infinity_bkgr, gradient_mesh, tirs[0]
+
+    # ---- render_core ------------------------------------------------------------------------------
+    def render_core(self, rays_o, rays_d, paths, converges, directions, infinity_bkgr, gradient_mesh, ior_ratios,
+                    human_poses=None, cos_anneal_ratio=0.0, step=None, is_train=True, is_nerf=False):
+        """Per-segment composite in linear RGB with a running transmittance (renderer_zerothick.py:1835-2011, training)."""
+        n1, n2 = self.nets()
+        dev = rays_o.device
+        N0 = converges[0].shape[0]
+        T = torch.ones(N0, 3, device=dev)
+        colors = []
+        out = {'gradient_error': torch.zeros(1, device=dev), 'std': torch.zeros(1, device=dev)}
+        s1c = self.stage1_network.color_network
+        for i in range(len(paths)):
+            cp, cd, cc = paths[i], directions[i], converges[i].flatten()
+            N = cp.shape[0]
+            color_now = torch.zeros(N, 3, device=dev)
+            pfn = cp[:, :-1, :]
+            dists = torch.linalg.norm(pfn[:, 1:] - pfn[:, :-1], dim=-1)
+            dists = torch.cat([dists, dists[..., -1:]], -1)
+            ns = pfn.shape[1]
+            p_neus = cp[cc][:, -1, :]
+            inner = torch.norm(pfn, dim=-1) <= 1.0
+            outer = ~inner
+            dirs = cd[:, None, :].expand(N, ns, 3)
+            alpha = torch.zeros(N, ns, device=dev)
+            col = torch.zeros(N, ns, 3, device=dev)
+            if outer.any():
+                a, c = self._density_alpha(n1, pfn[outer], dists[outer], dirs[outer])
+                alpha = alpha.index_put((outer,), a)
+                col = col.index_put((outer,), c)
+            if i == 1 and inner.any():
+                pin, din, dsin = pfn[inner], dirs[inner], dists[inner]
+                y, grads = n2.sdf(pin)
+                sdf, feats = y[:, 0], y[:, 1:]
+                s = torch.exp(self.deviation_network_inner.variance * 10.0).clip(1e-6, 1e6)
+                if self.cfg['freeze_inv_s_step'] is not None and step < self.cfg['freeze_inv_s_step']:
+                    s = s.detach()
+                cosv = (din * grads).sum(-1)
+                it = -(F.relu(-cosv * 0.5 + 0.5) * (1.0 - cos_anneal_ratio) + F.relu(-cosv) * cos_anneal_ratio)
+                pc = torch.sigmoid((sdf - it * dsin * 0.5) * s)
+                nc = torch.sigmoid((sdf + it * dsin * 0.5) * s)
+                a = ((pc - nc + 1e-5) / (pc + 1e-5)).clip(0.0, 1.0)
+                c, _ = self._shading(n2, self.color_network_inner.cfg, self.color_network_inner.FG_LUT, pin, grads, -din, feats)
+                alpha = alpha.index_put((inner,), a)
+                col = col.index_put((inner,), c)
+                out['std'] = torch.mean(1 / s)
+                out['gradient_error'] = (torch.linalg.norm(grads, dim=-1) - 1.0) ** 2
+            have_hit = p_neus.numel() > 0
+            if have_hit:
+                y, _ = n1.sdf(p_neus)
+                col_sdf, refr_coeff = self._shading(n1, s1c.cfg, s1c.FG_LUT, p_neus, gradient_mesh[i], -cd[cc], y[:, 1:],
+                                                    s2=True, is_internal=(i % 2 != 0))
+            col = G.srgb_to_linear(col)
+            cpx = G.cumprod_excl(alpha)
+            w = alpha * cpx[:, :-1]
+            color_now = color_now + (col * w[..., None]).sum(dim=1) * T
+            T = T * cpx[:, -1:]
+            if have_hit:
+                color_now = color_now + torch.zeros_like(color_now).index_put((cc,), G.srgb_to_linear(col_sdf) * T[cc])
+                T = T[cc] * refr_coeff
+                colors.append(color_now)
+            else:
+                colors.append(color_now)
+                break
+        for i in range(len(colors) - 1, 0, -1):
+            m = converges[i - 1].flatten()
+            colors[i - 1] = colors[i - 1] + torch.zeros_like(colors[i - 1]).index_put((m,), colors[i])
+        out['ray_rgb'] = torch.clamp(G.linear_to_srgb(colors[0]), min=0.0, max=1.0)
+        out['acc'] = torch.ones(N0, device=dev)
+        return out
+
+    def render(self, rays_o, rays_d, near=None, far=None, human_poses=None, perturb_overwrite=-1, cos_anneal_ratio=0.0,
+               is_train=True, step=None, is_nerf=False):
+        """renderer_zerothick.py:1442-1466."""
+        n1, n2 = self.nets()
+        n1.eng.pack()
+        n2.eng.pack()
+        paths, conv, dirs, iors, inf_b, gmesh, tir = self.ray_trace(rays_o, rays_d)
+        ret = self.render_core(rays_o, rays_d, paths, conv, dirs, inf_b, gmesh, iors, human_poses,
+                               cos_anneal_ratio=cos_anneal_ratio, step=step, is_train=is_train, is_nerf=is_nerf)
+        ret['tir_mask'] = tir
+        ret['_paths'], ret['_ior_ratios'], ret['_directions'] = paths, iors, dirs
+        return ret
+
+    def train_step_rays(self, batch, step):
+        """renderer_zerothick.py:1259-1275 on an explicit ray batch."""
+        rays_d = F.normalize(batch['rays_d'], dim=-1)
+        out = self.render(batch['rays_o'], rays_d, None, None, None, -1, self.get_anneal_val(step), is_train=True, step=step,
+                          is_nerf=self.is_nerf)
+        tm = out['tir_mask'].detach().float()
+        out['loss_rgb'] = self.compute_rgb_loss(out['ray_rgb'] * tm, batch['rgbs'] * tm)
+        return out
+
+    def forward(self, data):
+        raise NotImplementedError("stage-2 forward(data) needs an image database: use train_step_rays / render")
+
+
+from .renderer import name2renderer  # noqa: E402
+
+name2renderer['stage2'] = Stage2Renderer          # registry of network/renderer_zerothick.py:2057-2060
