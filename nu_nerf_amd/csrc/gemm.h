@@ -8,7 +8,8 @@
 //
 // Both run on v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD -> 157.3 TFLOP/s chip peak).
 // 128x128 workgroup tile, 4 waves as 2x2, each wave 64x64 = 2x2 MFMA tiles (64 accumulator
-// VGPRs), BK = 32, register-prefetched double-buffered LDS.  K is required to be a multiple of
+// VGPRs), BK = 32, next chunk prefetched into registers, one 36.9 KB LDS buffer (k contiguous per
+// operand row, stride 36) so that 2-3 workgroups share a CU.  K is required to be a multiple of
 // 32: every operand buffer in this library is allocated with a padded leading dimension whose
 // pad columns are zero (weights) / finite (activations).
 #pragma once

@@ -10,6 +10,7 @@
 #define TBN 128
 #define TBK 32
 #define NT_LDS 36   // padded row stride (floats): 36*r mod 64 hits every 16-B slot once per 16 rows
+#define NT_WPC 3    // workgroups per CU the NT kernel is built for (LDS 36.9 KB, <= 168 VGPRs)
 
 // ------------------------------------------------------------------------------------------------
 // NT kernel: persistent workgroups walk the output tiles; the first k-tile of the NEXT output tile is
@@ -17,7 +18,7 @@
 // workgroup exposes global-load latency.  Epilogue goes through a wave-private LDS transpose so that
 // global stores (and the aux loads of the derivative epilogues) are 16 B per lane, 256 B per row.
 // ------------------------------------------------------------------------------------------------
-#define EPI_LDS 68  // row stride (floats) of the per-wave 64x64 epilogue scratch
+#define EPI_LDS 68  // row stride (floats) of the per-wave 32x64 epilogue scratch
 
 template <int EPI>
 static __device__ inline float nu_epi_apply(float v, float bv, float h, float d, float ca, float& out2) {
@@ -37,9 +38,16 @@ static __device__ inline float nu_epi_apply(float v, float bv, float h, float d,
     return v;
 }
 
-template <int EPI, int ABL = 0>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NuGemmNT g) {
-    __shared__ __attribute__((aligned(16))) float smem[2][2][TBM * NT_LDS];   // 73728 B; epilogue scratch aliases it
+// development aid: {shader cycles, 100 MHz wall ticks} of block 0 of the last mfma_peak launch
+__device__ unsigned long long nu_dbg_clk[2];
+
+// One LDS buffer (36.9 KB per workgroup) -> 3 workgroups per CU.  The next k-chunk travels global -> registers
+// under the MFMAs; only the register -> LDS hand-over sits between two barriers, and the other resident workgroups
+// keep the matrix pipe busy meanwhile (measured: +5..12 % over a double-buffered 2-workgroup build on the K = 256
+// layers, where the per-tile epilogue is 10-15 % of a tile).  Epilogue in two 32-row halves per wave.
+template <int EPI>
+__global__ __launch_bounds__(256, NT_WPC) void gemm_nt_kernel(NuGemmNT g) {
+    __shared__ __attribute__((aligned(16))) float smem[2][TBM * NT_LDS];   // 36864 B; epilogue scratch aliases it
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -96,17 +104,17 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NuGemmNT g) {
             rb4[i] = *reinterpret_cast<const f32x4*>(bp[i] + koff);
         }
     };
-    auto store_regs = [&](int buf) {
+    auto store_regs = [&]() {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<f32x4*>(&smem[buf][0][(r0 + 32 * i) * NT_LDS + 4 * c4]) = ra4[i];
-            *reinterpret_cast<f32x4*>(&smem[buf][1][(r0 + 32 * i) * NT_LDS + 4 * c4]) = rb4[i];
+            *reinterpret_cast<f32x4*>(&smem[0][(r0 + 32 * i) * NT_LDS + 4 * c4]) = ra4[i];
+            *reinterpret_cast<f32x4*>(&smem[1][(r0 + 32 * i) * NT_LDS + 4 * c4]) = rb4[i];
         }
     };
 
     set_ptrs(mt, nt);
     load_regs(0);
-    store_regs(0);
+    store_regs();
     __syncthreads();
 
     float* __restrict__ C = g.C + (long long)z * g.sC;
@@ -143,30 +151,20 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NuGemmNT g) {
                 for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.0f;
 
         for (int kt = 0; kt < nk; ++kt) {
-            const int cur = kt & 1;
-            if (ABL != 1) {   // ABL 1: no global loads after the first tile (timing-only build)
-                if (kt + 1 < nk) {
-                    load_regs((kt + 1) * TBK);
-                } else if (has_next) {
-                    set_ptrs(mtn, ntnx);
-                    load_regs(0);
-                }
+            if (kt + 1 < nk) {
+                load_regs((kt + 1) * TBK);
+            } else if (has_next) {
+                set_ptrs(mtn, ntnx);
+                load_regs(0);
             }
-            const float* As = smem[cur][0];
-            const float* Bs = smem[cur][1];
+            const float* As = smem[0];
+            const float* Bs = smem[1];
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 f32x4 a0 = *reinterpret_cast<const f32x4*>(&As[a_off + kk * 8]);
                 f32x4 a1 = *reinterpret_cast<const f32x4*>(&As[a_off + 32 * NT_LDS + kk * 8]);
                 f32x4 b0 = *reinterpret_cast<const f32x4*>(&Bs[b_off + kk * 8]);
                 f32x4 b1 = *reinterpret_cast<const f32x4*>(&Bs[b_off + 32 * NT_LDS + kk * 8]);
-                if (ABL == 2) {   // ABL 2: no MFMA (operands kept live) -- data-path-only timing build
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        acc[0][0][e] += a0[e] * b0[e]; acc[0][1][e] += a0[e] * b1[e];
-                        acc[1][0][e] += a1[e] * b0[e]; acc[1][1][e] += a1[e] * b1[e];
-                    }
-                } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b0[e], acc[0][0], 0, 0, 0);
@@ -174,27 +172,16 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NuGemmNT g) {
                     acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b0[e], acc[1][0], 0, 0, 0);
                     acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b1[e], acc[1][1], 0, 0, 0);
                 }
-                }
             }
-            if (kt + 1 < nk) store_regs(cur ^ 1);
-            __syncthreads();
+            __syncthreads();   // every wave is done reading this chunk (and, after the last one, the scratch is free)
+            if (kt + 1 < nk) {
+                store_regs();
+                __syncthreads();
+            }
         }
 
-        if (ABL == 3) {   // ABL 3: no epilogue (accumulators kept live through one store)
-            if (!has_next) { if (acc[0][0][0] + acc[0][1][1] + acc[1][0][2] + acc[1][1][3] == 123.456f) g.C[0] = 1.f; break; }
-            __syncthreads(); store_regs(0); __syncthreads();
-            j = jn; mt = mtn; nt = ntnx;
-            continue;
-        }
-        // ---- epilogue: accumulators -> wave-private LDS scratch -> row-contiguous float4 ----
-        float* scr = &smem[0][0][0] + wid * (64 * EPI_LDS);
-#pragma unroll
-        for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-            for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    scr[(tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * EPI_LDS + tn * 32 + li] = acc[tm][tn][r];
+        // ---- epilogue: accumulators -> wave-private LDS scratch (32 rows at a time) -> row-contiguous float4 ----
+        float* scr = &smem[0][0] + wid * (32 * EPI_LDS);
         const int colq = (lane & 15) * 4;
         const int gcol = n0 + wc * 64 + colq;
         float bv[4] = {0.f, 0.f, 0.f, 0.f};
@@ -202,55 +189,63 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NuGemmNT g) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) bv[e] = (gcol + e < g.N) ? bias[gcol + e] : 0.f;
         }
-        if (gcol < zero_to) {
-            const bool full = vec_ok && (gcol + 3 < g.N) && (gcol + 3 < act_cols || gcol >= act_cols);
+        const bool full = vec_ok && (gcol + 3 < g.N) && (gcol + 3 < act_cols || gcol >= act_cols);
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm) {
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    scr[((r & 3) + 8 * (r >> 2) + 4 * lh) * EPI_LDS + tn * 32 + li] = acc[tm][tn][r];
+            if (gcol < zero_to) {
 #pragma unroll 4
-            for (int i = 0; i < 16; ++i) {
-                const int rl = i * 4 + (lane >> 4);
-                const int row = m0 + wr * 64 + rl;
-                const f32x4 v4 = *reinterpret_cast<const f32x4*>(&scr[rl * EPI_LDS + colq]);
-                if (row >= g.M) continue;
-                if (full) {
-                    f32x4 h4 = {0.f, 0.f, 0.f, 0.f}, d4 = h4, c4v = h4, o4, o24;
-                    const bool plain = gcol >= act_cols;
-                    if (kNeedH && !plain) h4 = *reinterpret_cast<const f32x4*>(H + (long long)row * g.ldh + gcol);
-                    if (kNeedD && !plain) d4 = *reinterpret_cast<const f32x4*>(D + (long long)row * g.ldd + gcol);
-                    if (kNeedAdd && !plain) c4v = *reinterpret_cast<const f32x4*>(Cadd + (long long)row * g.ldadd + gcol);
+                for (int i = 0; i < 8; ++i) {
+                    const int rl = i * 4 + (lane >> 4);
+                    const int row = m0 + wr * 64 + tm * 32 + rl;
+                    const f32x4 v4 = *reinterpret_cast<const f32x4*>(&scr[rl * EPI_LDS + colq]);
+                    if (row >= g.M) continue;
+                    if (full) {
+                        f32x4 h4 = {0.f, 0.f, 0.f, 0.f}, d4 = h4, c4v = h4, o4, o24;
+                        const bool plain = gcol >= act_cols;
+                        if (kNeedH && !plain) h4 = *reinterpret_cast<const f32x4*>(H + (long long)row * g.ldh + gcol);
+                        if (kNeedD && !plain) d4 = *reinterpret_cast<const f32x4*>(D + (long long)row * g.ldd + gcol);
+                        if (kNeedAdd && !plain) c4v = *reinterpret_cast<const f32x4*>(Cadd + (long long)row * g.ldadd + gcol);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float o2;
-                        const float v = g.alpha * v4[e];
-                        o4[e] = (kNeedH && plain) ? v : nu_epi_apply<EPI>(v, bv[e], h4[e], d4[e], c4v[e], o2);
-                        o24[e] = (kNeedH && plain) ? 0.f : o2;
-                    }
-                    *reinterpret_cast<f32x4*>(C + (long long)row * g.ldc + gcol) = o4;
-                    if (kNeedD) *reinterpret_cast<f32x4*>(C2 + (long long)row * g.ldc2 + gcol) = o24;
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int col = gcol + e;
-                        if (col >= zero_to) continue;
-                        float out = 0.f, out2 = 0.f;
-                        if (col < g.N) {
+                        for (int e = 0; e < 4; ++e) {
+                            float o2;
                             const float v = g.alpha * v4[e];
-                            if (kNeedH && col >= act_cols) {
-                                out = v;
-                            } else {
-                                const float h = kNeedH ? H[(long long)row * g.ldh + col] : 0.f;
-                                const float d = kNeedD ? D[(long long)row * g.ldd + col] : 0.f;
-                                const float ca = kNeedAdd ? Cadd[(long long)row * g.ldadd + col] : 0.f;
-                                out = nu_epi_apply<EPI>(v, bv[e], h, d, ca, out2);
-                            }
+                            o4[e] = (kNeedH && plain) ? v : nu_epi_apply<EPI>(v, bv[e], h4[e], d4[e], c4v[e], o2);
+                            o24[e] = (kNeedH && plain) ? 0.f : o2;
                         }
-                        C[(long long)row * g.ldc + col] = out;
-                        if (kNeedD) C2[(long long)row * g.ldc2 + col] = out2;
+                        *reinterpret_cast<f32x4*>(C + (long long)row * g.ldc + gcol) = o4;
+                        if (kNeedD) *reinterpret_cast<f32x4*>(C2 + (long long)row * g.ldc2 + gcol) = o24;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int col = gcol + e;
+                            if (col >= zero_to) continue;
+                            float out = 0.f, out2 = 0.f;
+                            if (col < g.N) {
+                                const float v = g.alpha * v4[e];
+                                if (kNeedH && col >= act_cols) {
+                                    out = v;
+                                } else {
+                                    const float h = kNeedH ? H[(long long)row * g.ldh + col] : 0.f;
+                                    const float d = kNeedD ? D[(long long)row * g.ldd + col] : 0.f;
+                                    const float ca = kNeedAdd ? Cadd[(long long)row * g.ldadd + col] : 0.f;
+                                    out = nu_epi_apply<EPI>(v, bv[e], h, d, ca, out2);
+                                }
+                            }
+                            C[(long long)row * g.ldc + col] = out;
+                            if (kNeedD) C2[(long long)row * g.ldc2 + col] = out2;
+                        }
                     }
                 }
             }
         }
         if (!has_next) break;
         __syncthreads();   // every wave is done with the scratch
-        store_regs(0);
+        store_regs();
         __syncthreads();
         j = jn; mt = mtn; nt = ntnx;
     }
@@ -265,18 +260,11 @@ int nu_gemm_nt_launch(const NuGemmNT& g, hipStream_t stream) {
     const long long nslots = (long long)nu_rup(nu_cdiv(g.M, TBM), 8) * ntn;
     if (nslots > 0x7fffffffLL) return NU_ERR_ARG;
     const int groups = g.groups > 0 ? g.groups : 1;
-    // persistent: 2 workgroups per CU (256 CUs) shared over the groups, a multiple of 8 so the XCD grouping holds
-    static const int grid_target = getenv("NU_NT_GRID") ? atoi(getenv("NU_NT_GRID")) : 512;
+    // persistent: NT_WPC workgroups per CU (256 CUs) shared over the groups, a multiple of 8 so the XCD grouping holds
+    static const int grid_target = getenv("NU_NT_GRID") ? atoi(getenv("NU_NT_GRID")) : 256 * NT_WPC;
     long long per = nu_rup(nu_cdiv(grid_target, groups), 8);
     if (per > nslots) per = nslots;
     dim3 grid((unsigned)per, 1, groups), block(256);
-    static const int abl = getenv("NU_NT_ABL") ? atoi(getenv("NU_NT_ABL")) : 0;
-    if (abl && g.epi == NU_EPI_PLAIN) {
-        if (abl == 1) hipLaunchKernelGGL((gemm_nt_kernel<NU_EPI_PLAIN, 1>), grid, block, 0, stream, g);
-        if (abl == 2) hipLaunchKernelGGL((gemm_nt_kernel<NU_EPI_PLAIN, 2>), grid, block, 0, stream, g);
-        if (abl == 3) hipLaunchKernelGGL((gemm_nt_kernel<NU_EPI_PLAIN, 3>), grid, block, 0, stream, g);
-        return nu_launch_status();
-    }
     switch (g.epi) {
 #define NU_CASE(E) case E: hipLaunchKernelGGL(gemm_nt_kernel<E>, grid, block, 0, stream, g); break;
         NU_CASE(NU_EPI_BIAS_NONE)
@@ -297,10 +285,14 @@ int nu_gemm_nt_launch(const NuGemmNT& g, hipStream_t stream) {
 // ------------------------------------------------------------------------------------------------
 // TN kernel (weight gradients): split over the reduced (point) dimension, partial slabs out.
 // ------------------------------------------------------------------------------------------------
-#define TN_LDS 128
-
+// The operands are transposed on their way into LDS ([column][k], k contiguous, row stride 36): each
+// thread fetches 16 consecutive reduced rows of ONE column (a wave load = 256 contiguous bytes of one row), so the
+// inner loop is exactly the NT kernel's (one ds_read_b128 feeds four MFMA k-steps) and nothing consumes a global
+// load before the hand-over to LDS -- the loads stay in flight under the 64 MFMAs of the current chunk.
+// BIG = operands of 4 GiB or more (64-bit element offsets instead of one uniform base + a 32-bit byte offset).
+template <bool BIG>
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(NuGemmTN g) {
-    __shared__ __attribute__((aligned(16))) float smem[2][2][TBK * TN_LDS];
+    __shared__ __attribute__((aligned(16))) float smem[2][128 * NT_LDS];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -322,8 +314,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(NuGemmTN g) {
     const int npair = g.A1 ? 2 : 1;
     const int total = ntile * npair;
 
-    const int c4 = tid & 31;
-    const int r0 = tid >> 5;  // 0..7
+    const int c = tid & 127;    // column of the 128-wide operand tile this thread fetches
+    const int kg = tid >> 7;    // which 16 of the chunk's 32 reduced rows (wave-uniform)
+    const bool do_bias = (g.bias_slab != nullptr) && (n2t == 0);
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -332,65 +325,91 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(NuGemmTN g) {
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
-    const bool do_bias = (g.bias_slab != nullptr) && (n2t == 0);
 
     f32x4 ra4[4], rb4[4];
+    int nvalid = 16;            // rows of the pending chunk that exist (ragged tail of the last split)
+    bool pend_pair0 = true;
+    float bs = 0.f;
     auto load_tile = [&](int t) {
-        const int pair = t / ntile;  // ntile > 0 whenever called
+        const int pair = t >= ntile ? 1 : 0;
         const int kt = t - pair * ntile;
-        const float* __restrict__ A = pair ? g.A1 + (long long)grp * g.sA1 : g.A0 + (long long)grp * g.sA0;
-        const float* __restrict__ B = pair ? g.B1 + (long long)grp * g.sB1 : g.B0 + (long long)grp * g.sB0;
+        const char* __restrict__ A = (const char*)(pair ? g.A1 + (long long)grp * g.sA1 : g.A0 + (long long)grp * g.sA0);
+        const char* __restrict__ B = (const char*)(pair ? g.B1 + (long long)grp * g.sB1 : g.B0 + (long long)grp * g.sB0);
         const int lda = pair ? g.lda1 : g.lda0;
         const int ldb = pair ? g.ldb1 : g.ldb0;
-        const int ca = n1_0 + 4 * c4, cb = n2_0 + 4 * c4;
+        int ca = n1_0 + c, cb = n2_0 + c;
+        ca = ca < lda ? ca : lda - 1;      // columns past the operand only feed slab rows the reducer never reads
+        cb = cb < ldb ? cb : ldb - 1;
+        const int pbase = p_begin + kt * TBK + kg * 16;
+        nvalid = p_end - pbase;
+        pend_pair0 = pair == 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int p = p_begin + kt * TBK + r0 + 8 * i;
-            f32x4 va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
-            if (p < p_end) {
-                if (ca + 3 < lda) va = *reinterpret_cast<const f32x4*>(A + (long long)p * lda + ca);
-                if (cb + 3 < ldb) vb = *reinterpret_cast<const f32x4*>(B + (long long)p * ldb + cb);
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                int pr = pbase + 4 * i + e;
+                pr = pr < p_end ? pr : p_end - 1;   // ragged tail: re-read the last row, zeroed at the hand-over
+                if (BIG) {
+                    ra4[i][e] = reinterpret_cast<const float*>(A)[(long long)pr * lda + ca];
+                    rb4[i][e] = reinterpret_cast<const float*>(B)[(long long)pr * ldb + cb];
+                } else {
+                    const unsigned oa = ((unsigned)pr * (unsigned)lda + (unsigned)ca) * 4u;
+                    const unsigned ob = ((unsigned)pr * (unsigned)ldb + (unsigned)cb) * 4u;
+                    ra4[i][e] = *reinterpret_cast<const float*>(A + oa);
+                    rb4[i][e] = *reinterpret_cast<const float*>(B + ob);
+                }
             }
-            ra4[i] = va;
-            rb4[i] = vb;
-            if (do_bias && pair == 0) bsum += va;
-        }
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool ok = 4 * i + e < nvalid;
+                ra4[i][e] = ok ? ra4[i][e] : 0.f;
+                rb4[i][e] = ok ? rb4[i][e] : 0.f;
+            }
+        if (do_bias && pend_pair0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bs += (ra4[i][0] + ra4[i][1]) + (ra4[i][2] + ra4[i][3]);
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<f32x4*>(&smem[buf][0][(r0 + 8 * i) * TN_LDS + 4 * c4]) = ra4[i];
-            *reinterpret_cast<f32x4*>(&smem[buf][1][(r0 + 8 * i) * TN_LDS + 4 * c4]) = rb4[i];
+            *reinterpret_cast<f32x4*>(&smem[0][c * NT_LDS + kg * 16 + 4 * i]) = ra4[i];
+            *reinterpret_cast<f32x4*>(&smem[1][c * NT_LDS + kg * 16 + 4 * i]) = rb4[i];
         }
     };
 
     if (total > 0) {
         load_tile(0);
-        store_tile(0);
+        store_tile();
     }
     __syncthreads();
 
     const int li = lane & 31, lh = lane >> 5;
+    const int a_off = (wr * 64 + li) * NT_LDS + 4 * lh;
+    const int b_off = (wc * 64 + li) * NT_LDS + 4 * lh;
     for (int t = 0; t < total; ++t) {
-        const int cur = t & 1;
         if (t + 1 < total) load_tile(t + 1);
-        const float* As = smem[cur][0];
-        const float* Bs = smem[cur][1];
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const int ro = (2 * s + lh) * TN_LDS;
-            float a0 = As[ro + wr * 64 + li];
-            float a1 = As[ro + wr * 64 + 32 + li];
-            float b0 = Bs[ro + wc * 64 + li];
-            float b1 = Bs[ro + wc * 64 + 32 + li];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        for (int kk = 0; kk < 4; ++kk) {
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(&smem[0][a_off + kk * 8]);
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(&smem[0][a_off + 32 * NT_LDS + kk * 8]);
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(&smem[1][b_off + kk * 8]);
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(&smem[1][b_off + 32 * NT_LDS + kk * 8]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b0[e], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b1[e], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b0[e], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b1[e], acc[1][1], 0, 0, 0);
+            }
         }
-        if (t + 1 < total) store_tile(cur ^ 1);
         __syncthreads();
+        if (t + 1 < total) {
+            store_tile();
+            __syncthreads();
+        }
     }
 
     float* __restrict__ slab = g.slab + (long long)grp * g.sSlab + (long long)split * N1p * N2p;
@@ -407,16 +426,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(NuGemmTN g) {
         }
 
     if (do_bias) {
-        // reduce the 8 row-groups that share a column quad
-        float* red = &smem[0][0][0];
-        *reinterpret_cast<f32x4*>(&red[r0 * 128 + 4 * c4]) = bsum;
+        float* red = &smem[0][0];
+        red[kg * 128 + c] = bs;
         __syncthreads();
-        if (tid < 128) {
-            float s = 0.f;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) s += red[i * 128 + tid];
-            g.bias_slab[(long long)grp * g.sBiasSlab + (long long)split * N1p + n1_0 + tid] = s;
-        }
+        if (tid < 128) g.bias_slab[(long long)grp * g.sBiasSlab + (long long)split * N1p + n1_0 + tid] = red[tid] + red[128 + tid];
     }
 }
 
@@ -424,7 +437,10 @@ int nu_gemm_tn_launch(const NuGemmTN& g, hipStream_t stream) {
     if (g.N1 <= 0 || g.N2 <= 0 || g.S <= 0) return NU_ERR_ARG;
     if ((g.lda0 & 3) || (g.ldb0 & 3) || (g.A1 && ((g.lda1 & 3) || (g.ldb1 & 3)))) return NU_ERR_ARG;
     dim3 grid(nu_cdiv(g.N1, 128) * nu_cdiv(g.N2, 128), g.S, g.groups > 0 ? g.groups : 1), block(256);
-    hipLaunchKernelGGL(gemm_tn_kernel, grid, block, 0, stream, g);
+    const long long max_ld = (g.lda0 > g.ldb0 ? g.lda0 : g.ldb0) > (g.A1 ? (g.lda1 > g.ldb1 ? g.lda1 : g.ldb1) : 0)
+                                 ? (g.lda0 > g.ldb0 ? g.lda0 : g.ldb0) : (g.lda1 > g.ldb1 ? g.lda1 : g.ldb1);
+    if ((long long)g.P * max_ld * 4 >= (1LL << 32)) hipLaunchKernelGGL((gemm_tn_kernel<true>), grid, block, 0, stream, g);
+    else hipLaunchKernelGGL((gemm_tn_kernel<false>), grid, block, 0, stream, g);
     return nu_launch_status();
 }
 
@@ -542,13 +558,14 @@ extern "C" int nu_wgrad(const NuGemmTN* gin, float* dW, int ldw, long long sW, f
 extern "C" int nu_debug_occupancy(int which) {
     int n = -1;
     if (which == 0) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_nt_kernel<NU_EPI_BIAS_SOFTPLUS>, 256, 0);
-    else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_tn_kernel, 256, 0);
+    else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (gemm_tn_kernel<false>), 256, 0);
     return n;
 }
 
 // development aid: bare fp32-MFMA issue loop (no memory) -- what the matrix pipe delivers at the clock it holds
 __global__ __launch_bounds__(256) void mfma_peak_kernel(float* out, int iters) {
     f32x16 a0 = {}, a1 = {}, a2 = {}, a3 = {};
+    const unsigned long long c0 = clock64(), w0 = wall_clock64();
     float x = (float)threadIdx.x * 1e-3f, y = 1.0f + (float)blockIdx.x * 1e-6f;
     for (int i = 0; i < iters; ++i) {
         a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a0, 0, 0, 0);
@@ -559,6 +576,13 @@ __global__ __launch_bounds__(256) void mfma_peak_kernel(float* out, int iters) {
     float s = 0.f;
     for (int r = 0; r < 16; ++r) s += a0[r] + a1[r] + a2[r] + a3[r];
     if (s == 123.456f) out[0] = s;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { nu_dbg_clk[0] = clock64() - c0; nu_dbg_clk[1] = wall_clock64() - w0; }
+}
+// development aid: effective shader clock (MHz) seen by block 0 of the last instrumented launch (synchronises)
+extern "C" double nu_debug_clock_mhz(void) {
+    unsigned long long h[2] = {0, 0};
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(nu_dbg_clk), sizeof(h)) != hipSuccess || h[1] == 0) return -1.0;
+    return (double)h[0] / (double)h[1] * 100.0;
 }
 extern "C" int nu_debug_mfma_peak(float* out, int blocks, int iters, hipStream_t stream) {
     hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, stream, out, iters);

@@ -110,6 +110,35 @@ def test_tn_weight_grad(gpu, P, N1, N2, S):
     torch.testing.assert_close(bo.double(), A0[:, :N1].double().sum(0), rtol=2e-5, atol=tol)
 
 
+def test_tn_weight_grad_operand_over_4gib(gpu):
+    """Operands of 4 GiB or more take the 64-bit-offset build of the TN kernel (32-bit byte offsets elsewhere)."""
+    from nu_nerf_amd import _lib as L
+    lib = L.load()
+    lib.nu_gemm_tn_workspace_bytes.restype = ctypes.c_longlong
+    P, ld, N1, N2, S = (1 << 20) + 77, 1024, 96, 130, 64
+    X = torch.empty(P, ld, device=gpu)
+    X.normal_()
+    assert X.numel() * 4 >= 1 << 32
+    a_col, b_col = 8, 512                      # two column windows of the same big matrix
+    wsb = lib.nu_gemm_tn_workspace_bytes(N1, N2, S)
+    ws = torch.empty(wsb // 4, device=gpu)
+    C = torch.full((N1, N2), float("nan"), device=gpu)
+    bo = torch.full((N1,), float("nan"), device=gpu)
+    rc = lib.nu_gemm_tn(ctypes.c_void_p(X.data_ptr() + 4 * a_col), ld, ctypes.c_void_p(X.data_ptr() + 4 * b_col), ld,
+                        None, 0, None, 0, P, N1, N2, L.ptr(C), N2, L.ptr(bo), S, L.ptr(ws), ctypes.c_longlong(wsb),
+                        L.stream())
+    L.check(rc, "nu_gemm_tn")
+    ref = torch.zeros(N1, N2, dtype=torch.float64, device=gpu)
+    bref = torch.zeros(N1, dtype=torch.float64, device=gpu)
+    for lo in range(0, P, 1 << 18):
+        a = X[lo:lo + (1 << 18), a_col:a_col + N1].double()
+        ref += a.t() @ X[lo:lo + (1 << 18), b_col:b_col + N2].double()
+        bref += a.sum(0)
+    tol = 3e-5 * P ** 0.5
+    torch.testing.assert_close(C.double(), ref, rtol=2e-5, atol=tol)
+    torch.testing.assert_close(bo.double(), bref, rtol=2e-5, atol=tol)
+
+
 def test_gemm_throughput_smoke(gpu):
     """Not a pass/fail perf gate: prints achieved TFLOP/s of the 256x256 layer GEMM."""
     M, N, K = 262144, 256, 256
