@@ -74,8 +74,25 @@ typedef struct NuGemmTN {      /* dW[N1,N2] = A0^T B0 (+ A1^T B1), reduced over 
     long long sA0, sB0, sA1, sB1, sSlab, sBiasSlab;
 } NuGemmTN;
 
+/* One deterministic split reduction: out[n1*ldo + n2] (+)= alpha * sum_{s<S} slab[s*ss + n1*rs + n2], n1 < N1, n2 < N2.
+ * Producers (nu_wgrad_enqueue, nu_skinny_bwd_enqueue, nu_colsum_enqueue) append these to a caller-owned HOST array;
+ * nu_slab_reduce_batched runs up to NU_REDUCE_MAX of them per launch.  G and blk_begin are filled by the library. */
+#define NU_REDUCE_MAX 48
+typedef struct NuReduceDesc {
+    const float* slab; float* out;
+    long long ss;
+    int S, N1, N2, rs, ldo, accumulate, G, blk_begin;
+    float alpha; int pad_;
+} NuReduceDesc;
+int nu_reduce_desc_size(void);
+int nu_slab_reduce_batched(const NuReduceDesc* descs_host, int n, hipStream_t stream);
+
 int nu_gemm_nt_ex(const NuGemmNT* g, hipStream_t stream);
 long long nu_wgrad_workspace_bytes(int N1, int N2, int S, int groups);
+/* deferred weight gradient: split GEMM now, reductions appended to descs[*ndesc...] (capacity cap); the workspace must
+ * stay untouched until nu_slab_reduce_batched(descs, *ndesc) has been enqueued */
+int nu_wgrad_enqueue(const NuGemmTN* g, float* dW, int ldw, long long sW, float* db, long long sDb, void* workspace,
+                     long long workspace_bytes, NuReduceDesc* descs, int* ndesc, int cap, hipStream_t stream);
 /* dW (ld = ldw, group stride sW) and optionally db[N1] = column sums of A0 (group stride sDb) */
 int nu_wgrad(const NuGemmTN* g, float* dW, int ldw, long long sW, float* db, long long sDb, void* workspace,
              long long workspace_bytes, hipStream_t stream);
@@ -111,7 +128,13 @@ long long nu_skinny_bwd_workspace_bytes(int K, int NO);
 int nu_skinny_bwd(const float* dy, int ldy, const float* H, int ldh, int P, int K, const float* Ws, int ldw, int NO,
                   float* dH, int lddh, int relu_mask, int accumulate, float* dWs, int lddw, float* db, void* workspace,
                   long long workspace_bytes, hipStream_t stream);
+int nu_skinny_bwd_enqueue(const float* dy, int ldy, const float* H, int ldh, int P, int K, const float* Ws, int ldw,
+                          int NO, float* dH, int lddh, int relu_mask, int accumulate, float* dWs, int lddw, float* db,
+                          void* workspace, long long workspace_bytes, NuReduceDesc* descs, int* ndesc, int cap,
+                          hipStream_t stream);
 long long nu_colsum_workspace_bytes(int ncols);
+int nu_colsum_enqueue(const float* A, int lda, int P, int ncols, float* out, int accumulate, void* workspace,
+                      long long workspace_bytes, NuReduceDesc* descs, int* ndesc, int cap, hipStream_t stream);
 int nu_colsum(const float* A, int lda, int P, int ncols, float* out, int accumulate, void* workspace,
               long long workspace_bytes, hipStream_t stream);
 /* D = w[col] * softplus'(H): seed of the reverse sweep of SDFNetwork.gradient (field.py:158-170) */

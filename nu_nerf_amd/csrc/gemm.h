@@ -20,10 +20,6 @@
 
 int nu_gemm_nt_launch(const NuGemmNT& g, hipStream_t stream);
 int nu_gemm_tn_launch(const NuGemmTN& g, hipStream_t stream);
-// out[n1*ldo + n2] (+)= alpha * sum_s slab[s][n1][n2]
-int nu_slab_reduce_launch(const float* slab, int S, int N1, int N2, float* out, int ldo, float alpha,
-                          int accumulate, hipStream_t stream);
-// out[n1] (+)= sum_s bias_slab[s][n1]
-int nu_bias_slab_reduce_launch(const float* bslab, int S, int N1, float* out, int accumulate, hipStream_t stream);
-int nu_slab_reduce_strided_launch(const float* slab, int S, int N1, int N2, int N1p, int N2p, float* out, int ldo,
-                                  float alpha, int accumulate, hipStream_t stream);
+// append one reduction problem (see NuReduceDesc) to a host-side list
+int nu_reduce_push(NuReduceDesc* descs, int* ndesc, int cap, const float* slab, int S, int N1, int N2, int rs,
+                   long long ss, float* out, int ldo, float alpha, int accumulate);

@@ -444,49 +444,100 @@ int nu_gemm_tn_launch(const NuGemmTN& g, hipStream_t stream) {
     return nu_launch_status();
 }
 
-__global__ void slab_reduce_kernel(const float* __restrict__ slab, int S, int N1, int N2, int N1p, int N2p,
-                                   float* __restrict__ out, int ldo, float alpha, int accumulate) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= N1 * N2) return;
-    const int n1 = idx / N2, n2 = idx - n1 * N2;
-    const float* p = slab + (long long)n1 * N2p + n2;
-    const long long stride = (long long)N1p * N2p;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int s = 0;
-    for (; s + 3 < S; s += 4) {
-        s0 += p[(long long)s * stride];
-        s1 += p[(long long)(s + 1) * stride];
-        s2 += p[(long long)(s + 2) * stride];
-        s3 += p[(long long)(s + 3) * stride];
+// ------------------------------------------------------------------------------------------------
+// Deterministic split reduction, batched: out[n1*ldo + n2] (+)= alpha * sum_s slab[s*ss + n1*rs + n2] for up to
+// NU_REDUCE_MAX independent problems per launch (descriptors travel in the kernel argument block, so there is no
+// host -> device copy).  A problem with few outputs and many slabs (bias sums, the skinny heads) spreads each
+// output over G threads (fixed order: thread g takes slabs g, g+G, ...; then g = 0 adds the partials in order).
+// ------------------------------------------------------------------------------------------------
+struct NuReduceBatch {
+    NuReduceDesc d[NU_REDUCE_MAX];
+    int n;
+};
+
+__global__ __launch_bounds__(256) void slab_reduce_batched_kernel(NuReduceBatch b) {
+    __shared__ float red[256];
+    int di = 0;
+    for (int i = 1; i < b.n; ++i) di = ((int)blockIdx.x >= b.d[i].blk_begin) ? i : di;
+    const float* __restrict__ slab = b.d[di].slab;
+    float* __restrict__ out = b.d[di].out;
+    const int S = b.d[di].S, N1 = b.d[di].N1, N2 = b.d[di].N2, rs = b.d[di].rs, G = b.d[di].G;
+    const long long ss = b.d[di].ss;
+    const int opb = 256 / G;
+    const int o = threadIdx.x % opb, g = threadIdx.x / opb;
+    const int idx = ((int)blockIdx.x - b.d[di].blk_begin) * opb + o;
+    const bool live = idx < N1 * N2;
+    float v = 0.f;
+    int n1 = 0, n2 = 0;
+    if (live) {
+        n1 = idx / N2;
+        n2 = idx - n1 * N2;
+        const float* p = slab + (long long)n1 * rs + n2;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int s = g;
+        for (; s + 3 * G < S; s += 4 * G) {
+            s0 += p[(long long)s * ss];
+            s1 += p[(long long)(s + G) * ss];
+            s2 += p[(long long)(s + 2 * G) * ss];
+            s3 += p[(long long)(s + 3 * G) * ss];
+        }
+        for (; s < S; s += G) s0 += p[(long long)s * ss];
+        v = (s0 + s1) + (s2 + s3);
     }
-    for (; s < S; ++s) s0 += p[(long long)s * stride];
-    float v = alpha * ((s0 + s1) + (s2 + s3));
-    float* o = out + (long long)n1 * ldo + n2;
-    *o = accumulate ? *o + v : v;
+    if (G > 1) {
+        red[threadIdx.x] = v;
+        __syncthreads();
+        if (g == 0)
+            for (int gg = 1; gg < G; ++gg) v += red[gg * opb + o];
+    }
+    if (live && g == 0) {
+        float* q = out + (long long)n1 * b.d[di].ldo + n2;
+        v *= b.d[di].alpha;
+        *q = b.d[di].accumulate ? *q + v : v;
+    }
 }
 
-int nu_slab_reduce_launch(const float* slab, int S, int N1, int N2, float* out, int ldo, float alpha,
-                          int accumulate, hipStream_t stream) {
-    const int n = N1 * N2;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(nu_cdiv(n, 256)), dim3(256), 0, stream, slab, S, N1, N2,
-                       nu_rup(N1, 128), nu_rup(N2, 128), out, ldo, alpha, accumulate);
+static int nu_reduce_launch_chunk(const NuReduceDesc* descs, int n, hipStream_t stream) {
+    NuReduceBatch b;
+    int blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        b.d[i] = descs[i];
+        const long long nout = (long long)descs[i].N1 * descs[i].N2;
+        int G = 1;
+        while (G < 16 && nout * G < 16384 && 2 * G <= descs[i].S) G *= 2;
+        b.d[i].G = G;
+        b.d[i].blk_begin = blocks;
+        blocks += (int)nu_cdivl(nout, 256 / G);
+    }
+    b.n = n;
+    if (blocks <= 0) return NU_OK;
+    hipLaunchKernelGGL(slab_reduce_batched_kernel, dim3(blocks), dim3(256), 0, stream, b);
     return nu_launch_status();
 }
 
-int nu_slab_reduce_strided_launch(const float* slab, int S, int N1, int N2, int N1p, int N2p, float* out, int ldo,
-                                  float alpha, int accumulate, hipStream_t stream) {
-    const int n = N1 * N2;
-    if (n <= 0) return NU_OK;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(nu_cdiv(n, 256)), dim3(256), 0, stream, slab, S, N1, N2, N1p, N2p,
-                       out, ldo, alpha, accumulate);
-    return nu_launch_status();
+// An accumulating problem may depend on an earlier one writing the same output: it gets a launch of its own, after
+// everything queued before it (stream order).
+extern "C" int nu_slab_reduce_batched(const NuReduceDesc* descs, int n, hipStream_t stream) {
+    int i = 0;
+    while (i < n) {
+        if (descs[i].N1 <= 0 || descs[i].N2 <= 0 || descs[i].S <= 0) return NU_ERR_ARG;
+        int j = i + 1;
+        if (!descs[i].accumulate)
+            while (j < n && j - i < NU_REDUCE_MAX && !descs[j].accumulate) ++j;
+        const int rc = nu_reduce_launch_chunk(descs + i, j - i, stream);
+        if (rc) return rc;
+        i = j;
+    }
+    return NU_OK;
 }
 
-int nu_bias_slab_reduce_launch(const float* bslab, int S, int N1, float* out, int accumulate, hipStream_t stream) {
-    // a bias slab is a [S][N1p][1]-shaped slab: reuse the reducer with N2p = 1
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(nu_cdiv(N1, 256)), dim3(256), 0, stream, bslab, S, N1, 1,
-                       nu_rup(N1, 128), 1, out, 1, 1.0f, accumulate);
-    return nu_launch_status();
+int nu_reduce_push(NuReduceDesc* descs, int* ndesc, int cap, const float* slab, int S, int N1, int N2, int rs,
+                   long long ss, float* out, int ldo, float alpha, int accumulate) {
+    if (*ndesc >= cap) return NU_ERR_WORKSPACE;
+    NuReduceDesc& d = descs[(*ndesc)++];
+    d.slab = slab; d.out = out; d.ss = ss; d.S = S; d.N1 = N1; d.N2 = N2; d.rs = rs; d.ldo = ldo;
+    d.accumulate = accumulate; d.G = 1; d.blk_begin = 0; d.alpha = alpha;
+    return NU_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -510,18 +561,10 @@ extern "C" long long nu_gemm_tn_workspace_bytes(int N1, int N2, int S) {
 extern "C" int nu_gemm_tn(const float* A0, int lda0, const float* B0, int ldb0, const float* A1, int lda1,
                           const float* B1, int ldb1, int P, int N1, int N2, float* C, int ldc, float* bias_out,
                           int S, void* workspace, long long workspace_bytes, hipStream_t stream) {
-    if (workspace_bytes < nu_gemm_tn_workspace_bytes(N1, N2, S)) return NU_ERR_WORKSPACE;
     NuGemmTN g = {};
     g.A0 = A0; g.lda0 = lda0; g.B0 = B0; g.ldb0 = ldb0; g.A1 = A1; g.lda1 = lda1; g.B1 = B1; g.ldb1 = ldb1;
     g.P = P; g.N1 = N1; g.N2 = N2; g.S = S; g.groups = 1;
-    g.slab = (float*)workspace;
-    g.bias_slab = bias_out ? g.slab + (long long)S * nu_rup(N1, 128) * nu_rup(N2, 128) : nullptr;
-    int rc = nu_gemm_tn_launch(g, stream);
-    if (rc) return rc;
-    rc = nu_slab_reduce_launch(g.slab, S, N1, N2, C, ldc, 1.0f, 0, stream);
-    if (rc) return rc;
-    if (bias_out) rc = nu_bias_slab_reduce_launch(g.bias_slab, S, N1, bias_out, 0, stream);
-    return rc;
+    return nu_wgrad(&g, C, ldc, 0, bias_out, 0, workspace, workspace_bytes, stream);
 }
 
 // struct-pointer entry points (what the Python host layer binds; one pointer argument keeps ctypes cheap)
@@ -533,14 +576,19 @@ extern "C" int nu_gemm_nt_ex(const NuGemmNT* g, hipStream_t stream) { return nu_
 extern "C" long long nu_wgrad_workspace_bytes(int N1, int N2, int S, int groups) {
     return (long long)(groups > 0 ? groups : 1) * S * nu_rup(N1, 128) * (nu_rup(N2, 128) + 1) * sizeof(float);
 }
-extern "C" int nu_wgrad(const NuGemmTN* gin, float* dW, int ldw, long long sW, float* db, long long sDb,
-                        void* workspace, long long workspace_bytes, hipStream_t stream) {
+// Deferred form: launches the split GEMM into `workspace` (which must stay untouched until the reductions ran)
+// and appends the reduction problems to descs[*ndesc ...]; nu_slab_reduce_batched(descs, *ndesc) finishes them.
+extern "C" int nu_wgrad_enqueue(const NuGemmTN* gin, float* dW, int ldw, long long sW, float* db, long long sDb,
+                                void* workspace, long long workspace_bytes, NuReduceDesc* descs, int* ndesc, int cap,
+                                hipStream_t stream) {
     NuGemmTN g = *gin;
     const int groups = g.groups > 0 ? g.groups : 1;
     if (g.P <= 0) return NU_ERR_ARG;
     if (workspace_bytes < nu_wgrad_workspace_bytes(g.N1, g.N2, g.S, groups)) return NU_ERR_WORKSPACE;
-    const long long slab_per = (long long)g.S * nu_rup(g.N1, 128) * nu_rup(g.N2, 128);
-    const long long bias_per = (long long)g.S * nu_rup(g.N1, 128);
+    if (*ndesc + groups * (db ? 2 : 1) > cap) return NU_ERR_WORKSPACE;
+    const int N1p = nu_rup(g.N1, 128), N2p = nu_rup(g.N2, 128);
+    const long long slab_per = (long long)g.S * N1p * N2p;
+    const long long bias_per = (long long)g.S * N1p;
     g.slab = (float*)workspace;
     g.sSlab = slab_per;
     g.bias_slab = db ? g.slab + slab_per * groups : nullptr;
@@ -548,10 +596,23 @@ extern "C" int nu_wgrad(const NuGemmTN* gin, float* dW, int ldw, long long sW, f
     g.groups = groups;
     int rc = nu_gemm_tn_launch(g, stream);
     for (int z = 0; z < groups && rc == NU_OK; ++z) {
-        rc = nu_slab_reduce_launch(g.slab + z * slab_per, g.S, g.N1, g.N2, dW + z * sW, ldw, 1.0f, 0, stream);
-        if (rc == NU_OK && db) rc = nu_bias_slab_reduce_launch(g.bias_slab + z * bias_per, g.S, g.N1, db + z * sDb, 0, stream);
+        rc = nu_reduce_push(descs, ndesc, cap, g.slab + z * slab_per, g.S, g.N1, g.N2, N2p, (long long)N1p * N2p,
+                            dW + z * sW, ldw, 1.0f, 0);
+        if (rc == NU_OK && db)
+            rc = nu_reduce_push(descs, ndesc, cap, g.bias_slab + z * bias_per, g.S, g.N1, 1, 1, N1p, db + z * sDb, 1, 1.0f, 0);
     }
     return rc;
+}
+
+extern "C" int nu_wgrad(const NuGemmTN* gin, float* dW, int ldw, long long sW, float* db, long long sDb,
+                        void* workspace, long long workspace_bytes, hipStream_t stream) {
+    const int groups = gin->groups > 0 ? gin->groups : 1;
+    if (groups > NU_REDUCE_MAX / 2) return NU_ERR_ARG;
+    NuReduceDesc descs[NU_REDUCE_MAX];
+    int n = 0;
+    int rc = nu_wgrad_enqueue(gin, dW, ldw, sW, db, sDb, workspace, workspace_bytes, descs, &n, NU_REDUCE_MAX, stream);
+    if (rc) return rc;
+    return nu_slab_reduce_batched(descs, n, stream);
 }
 
 // development aid: occupancy query for the two GEMM kernels (blocks per CU)

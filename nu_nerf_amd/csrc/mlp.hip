@@ -88,6 +88,7 @@ extern "C" int nu_unpack_grads(const void* descs, int ndesc, int total_rows, flo
     return nu_launch_status();
 }
 extern "C" int nu_pack_desc_size() { return (int)sizeof(NuPackDesc); }
+extern "C" int nu_reduce_desc_size() { return (int)sizeof(NuReduceDesc); }
 
 // ------------------------------------------------------------------------------------------------
 // skinny heads: out[p, j] = sum_k H[p, k] * Ws[j, k] + b[j],  j < NO <= 8.   HBM-bound (reads H once).
@@ -238,11 +239,13 @@ extern "C" long long nu_skinny_bwd_workspace_bytes(int K, int NO) {
     return (long long)NU_SKINNY_BLOCKS * NO * (K + 1) * sizeof(float);
 }
 
-extern "C" int nu_skinny_bwd(const float* dy, int ldy, const float* H, int ldh, int P, int K, const float* Ws, int ldw,
-                             int NO, float* dH, int lddh, int relu_mask, int accumulate, float* dWs, int lddw,
-                             float* db, void* workspace, long long workspace_bytes, hipStream_t stream) {
+extern "C" int nu_skinny_bwd_enqueue(const float* dy, int ldy, const float* H, int ldh, int P, int K, const float* Ws,
+                                     int ldw, int NO, float* dH, int lddh, int relu_mask, int accumulate, float* dWs,
+                                     int lddw, float* db, void* workspace, long long workspace_bytes,
+                                     NuReduceDesc* descs, int* ndesc, int cap, hipStream_t stream) {
     if (P <= 0) return NU_ERR_ARG;
     if (workspace_bytes < nu_skinny_bwd_workspace_bytes(K, NO)) return NU_ERR_WORKSPACE;
+    if (*ndesc + 2 > cap) return NU_ERR_WORKSPACE;
     int blocks = nu_cdiv(P, 64);
     blocks = blocks < NU_SKINNY_BLOCKS ? blocks : NU_SKINNY_BLOCKS;
     float* slab = (float*)workspace;
@@ -271,11 +274,21 @@ extern "C" int nu_skinny_bwd(const float* dy, int ldy, const float* H, int ldh, 
 #undef NU_ARGS
     int rc = nu_launch_status();
     if (rc) return rc;
-    // slab is [blocks][NO][K]: view as S=blocks slabs of an NO x K matrix with exact strides
-    rc = nu_slab_reduce_strided_launch(slab, blocks, NO, K, NO, K, dWs, lddw, 1.0f, 0, stream);
-    if (rc) return rc;
-    if (db) rc = nu_slab_reduce_strided_launch(bslab, blocks, NO, 1, NO, 1, db, 1, 1.0f, 0, stream);
+    // slab is [blocks][NO][K]: `blocks` slabs of an NO x K matrix
+    rc = nu_reduce_push(descs, ndesc, cap, slab, blocks, NO, K, K, (long long)NO * K, dWs, lddw, 1.0f, 0);
+    if (rc == NU_OK && db) rc = nu_reduce_push(descs, ndesc, cap, bslab, blocks, NO, 1, 1, NO, db, 1, 1.0f, 0);
     return rc;
+}
+
+extern "C" int nu_skinny_bwd(const float* dy, int ldy, const float* H, int ldh, int P, int K, const float* Ws, int ldw,
+                             int NO, float* dH, int lddh, int relu_mask, int accumulate, float* dWs, int lddw,
+                             float* db, void* workspace, long long workspace_bytes, hipStream_t stream) {
+    NuReduceDesc descs[2];
+    int n = 0;
+    int rc = nu_skinny_bwd_enqueue(dy, ldy, H, ldh, P, K, Ws, ldw, NO, dH, lddh, relu_mask, accumulate, dWs, lddw, db,
+                                   workspace, workspace_bytes, descs, &n, 2, stream);
+    if (rc) return rc;
+    return nu_slab_reduce_batched(descs, n, stream);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -296,8 +309,8 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
 
 #define NU_COLSUM_BLOCKS 512
 extern "C" long long nu_colsum_workspace_bytes(int ncols) { return (long long)NU_COLSUM_BLOCKS * ncols * sizeof(float); }
-extern "C" int nu_colsum(const float* A, int lda, int P, int ncols, float* out, int accumulate, void* workspace,
-                         long long workspace_bytes, hipStream_t stream) {
+extern "C" int nu_colsum_enqueue(const float* A, int lda, int P, int ncols, float* out, int accumulate, void* workspace,
+                                 long long workspace_bytes, NuReduceDesc* descs, int* ndesc, int cap, hipStream_t stream) {
     if (P <= 0 || ncols <= 0) return NU_ERR_ARG;
     if (workspace_bytes < nu_colsum_workspace_bytes(ncols)) return NU_ERR_WORKSPACE;
     int blocks = nu_cdiv(P, 128);
@@ -306,8 +319,17 @@ extern "C" int nu_colsum(const float* A, int lda, int P, int ncols, float* out, 
                        (float*)workspace);
     int rc = nu_launch_status();
     if (rc) return rc;
-    return nu_slab_reduce_strided_launch((const float*)workspace, blocks, 1, ncols, 1, ncols, out, ncols, 1.0f,
-                                         accumulate, stream);
+    return nu_reduce_push(descs, ndesc, cap, (const float*)workspace, blocks, 1, ncols, ncols, ncols, out, ncols, 1.0f,
+                          accumulate);
+}
+
+extern "C" int nu_colsum(const float* A, int lda, int P, int ncols, float* out, int accumulate, void* workspace,
+                         long long workspace_bytes, hipStream_t stream) {
+    NuReduceDesc d[1];
+    int n = 0;
+    int rc = nu_colsum_enqueue(A, lda, P, ncols, out, accumulate, workspace, workspace_bytes, d, &n, 1, stream);
+    if (rc) return rc;
+    return nu_slab_reduce_batched(d, n, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

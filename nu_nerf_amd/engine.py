@@ -46,6 +46,13 @@ class GemmTN(ctypes.Structure):
                 ("sB1", c_ll), ("sSlab", c_ll), ("sBiasSlab", c_ll)]
 
 
+class ReduceDesc(ctypes.Structure):
+    """Mirror of NuReduceDesc (include/nu_nerf.h): one deferred deterministic split reduction."""
+    _fields_ = [("slab", c_p), ("out", c_p), ("ss", c_ll), ("S", c_int), ("N1", c_int), ("N2", c_int), ("rs", c_int),
+                ("ldo", c_int), ("accumulate", c_int), ("G", c_int), ("blk_begin", c_int), ("alpha", ctypes.c_float),
+                ("pad_", c_int)]
+
+
 class PackDesc(ctypes.Structure):
     _fields_ = [("v", c_p), ("g", c_p), ("colmap", c_p), ("Wp", c_p), ("WpT", c_p), ("dWp", c_p), ("dv_off", c_ll),
                 ("dg_off", c_ll), ("bias", c_p), ("bias_p", c_p), ("scale", c_f), ("N", c_int), ("K", c_int),
@@ -96,6 +103,14 @@ class Stage1Engine:
                    "nu_gemm_tn_workspace_bytes"):
             getattr(lib, fn).restype = c_ll
         assert lib.nu_pack_desc_size() == ctypes.sizeof(PackDesc), "PackDesc ABI mismatch"
+        assert lib.nu_reduce_desc_size() == ctypes.sizeof(ReduceDesc), "ReduceDesc ABI mismatch"
+        # deferred split reductions (weight gradients, skinny heads, column sums): partial slabs live in a bump arena
+        # until flush_reductions() sums them all in a few batched launches (before unpack_grads reads the results)
+        self._rd_cap = 1024
+        self._rd = (ReduceDesc * self._rd_cap)()
+        self._nrd = c_int(0)
+        self._arena = None
+        self._arena_off = 0
         self._ws = None
         self._ptr_sig = None
         self._ktime = None
@@ -117,6 +132,24 @@ class Stage1Engine:
 
     def stream(self):
         return c_p(torch.cuda.current_stream(self.dev).cuda_stream)
+
+    def _arena_take(self, nbytes):
+        """Device address of `nbytes` of slab space that stays untouched until the next flush_reductions()."""
+        n = (int(nbytes) + 255) // 256 * 64          # floats, 256-byte granules
+        if self._arena is None or self._arena_off + n > self._arena.numel():
+            self.flush_reductions()                   # stream order: later producers may then reuse the space
+            if self._arena is None or n > self._arena.numel():
+                self._arena = None
+                self._arena = torch.empty(max(n, 1 << 28), dtype=torch.float32, device=self.dev)   # >= 1 GiB
+        off = self._arena_off
+        self._arena_off += n
+        return self._arena.data_ptr() + 4 * off, n * 4
+
+    def flush_reductions(self):
+        if self._nrd.value:
+            L.check(self.lib.nu_slab_reduce_batched(self._rd, self._nrd.value, self.stream()), "nu_slab_reduce_batched")
+            self._nrd.value = 0
+        self._arena_off = 0
 
     # ------------------------------------------------------------------ layer tables
     def _build_layers(self):
@@ -289,6 +322,7 @@ class Stage1Engine:
                 "nu_pack_layers")
 
     def unpack_grads(self, flat):
+        self.flush_reductions()
         L.check(self.lib.nu_unpack_grads(c_p(self._desc_dev.data_ptr()), len(self.layers), self.total_rows,
                                          c_p(flat.data_ptr()), self.stream()), "nu_unpack_grads")
 
@@ -344,27 +378,31 @@ class Stage1Engine:
     def _wgrad(self, A0, lda0, B0, ldb0, P, N1, N2, dW, ldw, db, A1, lda1, B1, ldb1, groups, sA0, sB0, sA1, sB1, sW, sDb):
         tiles = ((N1 + 127) // 128) * ((N2 + 127) // 128) * groups
         S = max(1, min((P + 255) // 256, max(1, 512 // tiles)))   # 2 workgroups per CU; fewer, larger slabs
-        nbytes = self.lib.nu_wgrad_workspace_bytes(N1, N2, S, groups)
-        ws = self.workspace(nbytes)
+        if self._nrd.value + 2 * groups > self._rd_cap:
+            self.flush_reductions()
+        ws, nb = self._arena_take(self.lib.nu_wgrad_workspace_bytes(N1, N2, S, groups))
         g = GemmTN(A0, lda0, B0, ldb0, A1, lda1, B1, ldb1, P, N1, N2, 0, 0, S, groups, sA0, sB0, sA1, sB1, 0, 0)
-        L.check(self.lib.nu_wgrad(ctypes.byref(g), c_p(dW), ldw, c_ll(sW), c_p(db), c_ll(sDb), c_p(ws.data_ptr()),
-                                  c_ll(ws.numel() * 4), self.stream()), "nu_wgrad")
+        L.check(self.lib.nu_wgrad_enqueue(ctypes.byref(g), c_p(dW), ldw, c_ll(sW), c_p(db), c_ll(sDb), c_p(ws), c_ll(nb),
+                                          self._rd, ctypes.byref(self._nrd), self._rd_cap, self.stream()), "nu_wgrad_enqueue")
 
     def skinny_fwd(self, H, ldh, P, K, Ws, ldw, b, NO, out, ldo):
         L.check(self.lib.nu_skinny_fwd(c_p(H), ldh, P, K, c_p(Ws), ldw, c_p(b), NO, c_p(out), ldo, self.stream()),
                 "nu_skinny_fwd")
 
     def skinny_bwd(self, dy, ldy, H, ldh, P, K, Ws, ldw, NO, dH, lddh, relu_mask, accumulate, dWs, lddw, db):
-        nbytes = self.lib.nu_skinny_bwd_workspace_bytes(K, NO)
-        ws = self.workspace(nbytes)
-        L.check(self.lib.nu_skinny_bwd(c_p(dy), ldy, c_p(H), ldh, P, K, c_p(Ws), ldw, NO, c_p(dH), lddh, relu_mask,
-                                       accumulate, c_p(dWs), lddw, c_p(db), c_p(ws.data_ptr()), c_ll(ws.numel() * 4),
-                                       self.stream()), "nu_skinny_bwd")
+        if self._nrd.value + 2 > self._rd_cap:
+            self.flush_reductions()
+        ws, nb = self._arena_take(self.lib.nu_skinny_bwd_workspace_bytes(K, NO))
+        L.check(self.lib.nu_skinny_bwd_enqueue(c_p(dy), ldy, c_p(H), ldh, P, K, c_p(Ws), ldw, NO, c_p(dH), lddh, relu_mask,
+                                               accumulate, c_p(dWs), lddw, c_p(db), c_p(ws), c_ll(nb), self._rd,
+                                               ctypes.byref(self._nrd), self._rd_cap, self.stream()), "nu_skinny_bwd_enqueue")
 
     def colsum(self, A, lda, P, ncols, out, accumulate):
-        ws = self.workspace(self.lib.nu_colsum_workspace_bytes(ncols))
-        L.check(self.lib.nu_colsum(c_p(A), lda, P, ncols, c_p(out), accumulate, c_p(ws.data_ptr()), c_ll(ws.numel() * 4),
-                                   self.stream()), "nu_colsum")
+        if self._nrd.value + 1 > self._rd_cap:
+            self.flush_reductions()
+        ws, nb = self._arena_take(self.lib.nu_colsum_workspace_bytes(ncols))
+        L.check(self.lib.nu_colsum_enqueue(c_p(A), lda, P, ncols, c_p(out), accumulate, c_p(ws), c_ll(nb), self._rd,
+                                           ctypes.byref(self._nrd), self._rd_cap, self.stream()), "nu_colsum_enqueue")
 
     # ------------------------------------------------------------------ SDF network
     def sdf_forward(self, X, x_ld, P, *, keep=True, want_feat=True):
