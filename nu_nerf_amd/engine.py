@@ -114,6 +114,7 @@ class Stage1Engine:
         self._ws = None
         self._ptr_sig = None
         self._ktime = None
+        self.ktime_on = True
         self.last_ctx = None
         self._build_layers()
 
@@ -336,7 +337,7 @@ class Stage1Engine:
             return
         g = GemmNT(A, lda, B, ldb, M, N, K, C, ldc, C2, ldc2, bias, H, ldh, D, ldd, Cadd, ldadd, zero_to, act_cols,
                    alpha, groups, sA, sB, sC, sC2, sBias, sH, sD, sCadd, epi)
-        kt = self._ktime
+        kt = self._ktime if self.ktime_on else None
         if kt is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -348,8 +349,10 @@ class Stage1Engine:
             kt['nt'].append((e0, e1, 2.0 * M * (ntrue or N) * (ktrue or K) * groups, abytes))
 
     def begin_kernel_timing(self):
-        """Bracket every GEMM launch with HIP events on the launch stream (bench.py's roofline leg)."""
+        """Bracket every GEMM launch with HIP events on the launch stream (bench.py's roofline leg).  The event pairs cost
+        about 4 ms per step (two queue barriers per launch), so the bench switches `ktime_on` per step to sample."""
         self._ktime = {'nt': [], 'tn': []}
+        self.ktime_on = True
 
     def end_kernel_timing(self):
         kt, self._ktime = self._ktime, None
@@ -364,7 +367,7 @@ class Stage1Engine:
 
     def wgrad(self, A0, lda0, B0, ldb0, P, N1, N2, dW, ldw, db, *, A1=0, lda1=0, B1=0, ldb1=0, groups=1, sA0=0, sB0=0,
               sA1=0, sB1=0, sW=0, sDb=0, n2true=None):
-        kt = self._ktime
+        kt = self._ktime if self.ktime_on else None
         if kt is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
