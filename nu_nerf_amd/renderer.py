@@ -9,6 +9,8 @@ default-tensor-type flips) so one process per GPU works.
 """
 import math
 
+import weakref
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -49,6 +51,31 @@ class SDFNetwork(nn.Module):
         for l in range(9):
             out_dim = dims[l + 1] - dims[0] if l + 1 == 4 else dims[l + 1]
             setattr(self, f"lin{l}", WNLinear(dims[l], out_dim))
+        object.__setattr__(self, '_owner', None)    # weakref to the renderer whose HIP engine evaluates this network
+
+    # evaluation surface of the reference module (field.py:133-170), used by its scripts (extract_mesh_stage1.py:30,
+    # train_valid / relight tooling): all three run the HIP MLP of the owning renderer, with gradients to the parameters
+    def _nets(self):
+        owner = self._owner() if self._owner is not None else None
+        if owner is None:
+            raise RuntimeError("SDFNetwork is a parameter holder: evaluate it through its NeROShapeRenderer")
+        from .nets import Stage1Nets
+        eng = owner.engine()
+        eng.pack()
+        return Stage1Nets(eng, owner._named())
+
+    def forward(self, x):
+        shp = x.shape[:-1]
+        y, _ = self._nets().sdf(x.reshape(-1, 3).contiguous())
+        return y.reshape(*shp, 257)
+
+    def sdf(self, x):
+        return self.forward(x)[..., :1]
+
+    def gradient(self, x):
+        shp = x.shape[:-1]
+        _, n = self._nets().sdf(x.reshape(-1, 3).contiguous())
+        return n.reshape(*shp, 3)
 
 
 class SingleVarianceNetwork(nn.Module):
@@ -203,6 +230,7 @@ class NeROShapeRenderer(nn.Module):
             raise NotImplementedError("only the default SDF/variance architecture is built (every shipped config uses it)")
         self.is_nerf = c['is_nerf']
         self.sdf_network = SDFNetwork()
+        object.__setattr__(self.sdf_network, '_owner', weakref.ref(self))
         self.deviation_network = SingleVarianceNetwork(c['inv_s_init'])
         self.outer_nerf = NeRFNetwork()
         self.color_network = AppShadingNetwork(c['shader_config'])
@@ -365,6 +393,9 @@ class NeROShapeRenderer(nn.Module):
                 outputs['loss_occ'] = self.compute_occ_loss(eng, c, occ_raw, step)
             else:
                 outputs['loss_occ'] = torch.zeros(1, device=rgb.device)
+        if not is_train:
+            from .validation import composite_weights, compute_validation_info
+            outputs.update(compute_validation_info(self, z_vals, rays_o, rays_d, composite_weights(eng, c), step))
         return outputs
 
     def _spec_query_points(self, rays_o, rays_d, z_vals):

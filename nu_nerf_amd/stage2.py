@@ -23,6 +23,7 @@ from . import torch_glue as G
 from .engine import Stage1Engine, addr
 from .lbvh import Scene
 from .nets import Stage1Nets
+from .shading_glue import shade
 from .renderer import (AppShadingNetwork, NeRFNetwork, NeROShapeRenderer, SDFNetwork, SingleVarianceNetwork, WNLinear)
 
 
@@ -193,45 +194,8 @@ class Stage2Renderer(nn.Module):
         alpha = 1.0 - torch.exp(-F.softplus(sig) * dists)
         return alpha, G.linear_to_srgb(torch.exp(torch.clamp(rgb, max=5.0)))
 
-    @staticmethod
-    def _lights(nets, exp_max, points, n, refl, rough):
-        """The three outer_light and two inner_light queries + the occlusion weight (field.py:636-682), row-batched."""
-        P = points.shape[0]
-        enc = torch.cat([G.ide(n, torch.ones_like(rough)), G.ide(refl, rough), G.ide(refl, torch.zeros_like(rough))], 0)
-        lo = torch.exp(torch.clamp(nets.predictor('outer_light', enc), max=exp_max))
-        pe = G.embed(points, 6)
-        li = torch.exp(torch.clamp(nets.predictor('inner_light', torch.cat([torch.cat([pe, enc[P:2 * P]], -1),
-                                                                              torch.cat([pe, enc[2 * P:]], -1)], 0)), max=exp_max))
-        occ = nets.predictor('inner_weight', torch.cat([pe.detach(), G.embed(refl, 6).detach()], -1)) * 0.5 + 0.5
-        occ_c = torch.clamp(occ, 0.0, 1.0)
-        light = li[:P] * occ_c + lo[P:2 * P] * (1 - occ_c)
-        light0 = li[P:] * occ_c + lo[2 * P:] * (1 - occ_c)
-        return lo[:P], light, light0
-
     def _shading(self, nets, scfg, lut, points, normals, view_dirs, feats, s2=False, is_internal=False):
-        """AppShadingNetwork.forward (field.py:684-777) or, with s2=True, AppShadingNetwork_S2.forward (field.py:909-1010);
-        sphere_direction False."""
-        exp_max = scfg['light_exp_max']
-        n, v = F.normalize(normals, dim=-1), F.normalize(view_dirs, dim=-1)
-        nov = torch.sum(n * v, -1, keepdim=True)
-        refl = nov * n * 2 - v
-        m = torch.sigmoid(nets.materials(feats, points))
-        metallic, rough, albedo, trans = m[:, 0:1], m[:, 1:2], m[:, 2:5], m[:, 5:6]
-        diffuse_light, light, light0 = self._lights(nets, exp_max, points, n, refl, rough)
-        t = torch.clamp(1 - nov, 0.0, 1.0)
-        fres = torch.clamp(0.04 + 0.96 * t * t * t * t * t, 0.0, 1.0)
-        fg = G.lut_bilinear_clamp(lut[0], torch.cat([torch.clamp(nov, 0.0, 1.0), torch.clamp(rough, 0.0, 1.0)], -1))
-        spec_albedo = 0.04 * (1 - metallic) + metallic * albedo
-        base = ((1 - metallic) * albedo * diffuse_light + (spec_albedo * fg[:, 0:1] + fg[:, 1:2]) * light) * (1 - trans)
-        if s2:
-            color = base + (fres * light0) * trans
-            if is_internal:
-                color = color * 0
-            return G.linear_to_srgb(color), (1 - fres) * trans
-        rf = scfg.get('refrac_freq', 6)
-        refrac = torch.exp(torch.clamp(nets.predictor('refrac_light', torch.cat([G.embed(points, rf), G.embed(v, rf)], -1)),
-                                       max=exp_max))
-        return G.linear_to_srgb(base + (fres * light0 + (1 - fres) * refrac) * trans), None
+        return shade(nets, scfg, lut, points, normals, view_dirs, feats, s2=s2, is_internal=is_internal)
 
     def _upsample_inner(self, n2, start, dirs, end):
         """Segment-1 hierarchical sampling against the inner SDF (renderer_zerothick.py:1742-1760): 64 uniform fractions,

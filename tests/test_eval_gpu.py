@@ -1,0 +1,94 @@
+"""Inference-only paths against vectors the reference produced (oracle/gen_golden_eval.py):
+validation rendering (render(..., is_train=False) -> depth / normal / material and light images / traced occlusion)
+and extract_fields (dense SDF grid through the HIP MLP)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import golden
+
+pytestmark = pytest.mark.gpu
+
+
+def build(gpu, g):
+    from nu_nerf_amd.renderer import NeROShapeRenderer
+    from nu_nerf_amd.params import init_stage1_params, randomize_for_parity
+    cfg = {'name': 'golden', 'network': 'shape', 'database_name': 'synthetic/64', 'apply_occ_loss': True,
+           'occ_loss_step': 15000, 'is_nerf': True, 'freeze_inv_s_step': 15000,
+           'n_samples': 32, 'n_importance': 32, 'n_bg_samples': 16}
+    net = NeROShapeRenderer(cfg, training=False)
+    params = randomize_for_parity(init_stage1_params(6033), seed=1)
+    for k in g:
+        if k.startswith('override__'):
+            params[k[len('override__'):]] = g[k]
+    net.load_param_dict(params)
+    return net.to(gpu)
+
+
+def test_validation_render_vs_reference_golden(gpu):
+    g = golden("eval_step20000_r40.npz")
+    net = build(gpu, g)
+    o = torch.from_numpy(g['rays_o']).to(gpu)
+    d = torch.nn.functional.normalize(torch.from_numpy(g['rays_d']).to(gpu), dim=-1)
+    R = o.shape[0]
+    near, far = torch.full((R, 1), 0.8, device=gpu), torch.full((R, 1), 4.5, device=gpu)
+    out = net.render(o, d, near, far, None, 0, 0, is_train=False, step=int(g['step']), is_nerf=True)
+    hit = np.linalg.norm(g['out_depth'] * d.cpu().numpy() + g['rays_o'], axis=-1) <= 1.0
+    assert 10 <= hit.sum() <= 30                       # the fixture has rays on and off the surface
+    depth = out['depth'].cpu().numpy()
+    np.testing.assert_allclose(depth[hit], g['out_depth'][hit], rtol=2e-5)
+    # rays that leave through the background: depth sums z up to far / 1e-3 = 4500 with tiny weights, so the inverse-CDF
+    # placement noise of the sampler (see test_oracle_golden) shows at the 1e-2 level
+    np.testing.assert_allclose(depth[~hit], g['out_depth'][~hit], rtol=2e-2)
+    # inv_s = 245 with 64 samples: a grazing ray's quadrature feels the 1e-5 placement noise of the sampler
+    err = np.abs(out['ray_rgb'].detach().cpu().numpy() - g['out_ray_rgb']).max(-1)
+    assert (err < 1e-4).mean() >= 0.95 and err.max() < 1e-3, err
+    keys = ['normal', 'diffuse_albedo', 'diffuse_light', 'diffuse_color', 'refraction_light', 'specular_albedo',
+            'specular_light', 'specular_color', 'specular_ref', 'transmission_weight', 'roughness', 'occ_prob',
+            'indirect_light', 'occ_prob_gt', 'reflection_weight', 'metallic']
+    for k in keys:
+        a, b = out[k].detach().cpu().numpy(), g['out_' + k]
+        assert a.shape == b.shape, (k, a.shape, b.shape)
+        # depth points sit on a surface with |grad sdf| ~ 1 and inv_s = 245: 1e-6 of depth moves a normal by ~1e-4
+        np.testing.assert_allclose(a, b, rtol=1e-3, atol=5e-4, err_msg=k)
+        assert np.all(a[~hit] == 0), k               # masked outside the unit sphere, like the reference
+    assert float(np.abs(out['normal'].cpu().numpy()[hit]).sum()) > 1.0
+
+
+def test_render_eval_chunks_and_keys(gpu):
+    from nu_nerf_amd.validation import render_eval, _EVAL_KEYS
+    g = golden("eval_step20000_r40.npz")
+    net = build(gpu, g)
+    batch = {'rays_o': torch.from_numpy(g['rays_o']).to(gpu), 'rays_d': torch.from_numpy(g['rays_d']).to(gpu),
+             'rgbs': torch.rand(40, 3, device=gpu)}
+    whole = render_eval(net, batch, int(g['step']), chunk=40)
+    parts = render_eval(net, batch, int(g['step']), chunk=16)        # 16 + 16 + 8: ragged last chunk
+    assert set(_EVAL_KEYS) <= set(whole.keys()) and 'loss_rgb' in whole
+    for k in ('ray_rgb', 'depth', 'normal', 'specular_color', 'occ_prob_gt'):
+        assert whole[k].shape[0] == 40
+        torch.testing.assert_close(whole[k], parts[k], rtol=1e-5, atol=1e-6)       # rays are independent
+    assert np.abs(whole['ray_rgb'].cpu().numpy() - g['out_ray_rgb']).max() < 1e-3
+
+
+def test_extract_fields_and_sdf_surface_vs_reference(gpu):
+    from nu_nerf_amd.validation import extract_fields, extract_geometry
+    g = golden("eval_step20000_r40.npz")
+    net = build(gpu, g)
+    bmin, bmax = torch.from_numpy(g['grid_min']).to(gpu), torch.from_numpy(g['grid_max']).to(gpu)
+    u = extract_fields(bmin, bmax, 24, lambda x: -net.sdf_network.sdf(x), batch_size=16)
+    assert u.shape == (24, 24, 24) and u.dtype == np.float32
+    np.testing.assert_allclose(u, g['grid'], rtol=1e-5, atol=2e-6)
+    assert (u == 1.0).sum() == (g['grid'] == 1.0).sum()              # same outside-the-sphere mask
+    # the evaluation surface of the reference's SDFNetwork module: forward / sdf / gradient, any leading shape
+    x = torch.rand(5, 7, 3, device=gpu) - 0.5
+    y = net.sdf_network(x)
+    assert y.shape == (5, 7, 257) and net.sdf_network.sdf(x).shape == (5, 7, 1)
+    n = net.sdf_network.gradient(x)
+    eps = 1e-3
+    for c in range(3):
+        dx = torch.zeros(3, device=gpu)
+        dx[c] = eps
+        fd = (net.sdf_network.sdf(x + dx) - net.sdf_network.sdf(x - dx))[..., 0] / (2 * eps)
+        torch.testing.assert_close(n[..., c], fd, rtol=2e-2, atol=2e-3)
+    with pytest.raises(ImportError):
+        extract_geometry(bmin, bmax, 8, 0.0, lambda x: -net.sdf_network.sdf(x))
