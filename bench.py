@@ -29,10 +29,13 @@ sys.path.insert(0, ROOT)
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 
 
-def build_cfg(rays):
-    return {'name': 'bench', 'network': 'shape', 'database_name': 'synthetic/0', 'is_nerf': True, 'apply_occ_loss': True,
-            'occ_loss_step': 15000, 'freeze_inv_s_step': 15000, 'eikonal_weight': 0.1, 'train_ray_num': rays,
-            'n_samples': 64, 'n_importance': 64, 'n_bg_samples': 32, 'up_sample_steps': 4}
+def build_cfg(rays, real_capture=False, mlp_dtype='fp32'):
+    cfg = {'name': 'bench', 'network': 'shape', 'database_name': 'synthetic/0', 'is_nerf': True, 'apply_occ_loss': True,
+           'occ_loss_step': 15000, 'freeze_inv_s_step': 15000, 'eikonal_weight': 0.1, 'train_ray_num': rays,
+           'n_samples': 64, 'n_importance': 64, 'n_bg_samples': 32, 'up_sample_steps': 4, 'mlp_dtype': mlp_dtype}
+    if real_capture:   # configs/shape/real/*.yaml: no white background, near/far from the unit sphere, 144-d outer_light
+        cfg.update(is_nerf=False, shader_config={'sphere_direction': True, 'human_light': False, 'light_exp_max': 5.0})
+    return cfg
 
 
 def warmup_cos_lr(step, end_warm=5000, end_iter=300000, lr=5e-4, alpha=0.05):
@@ -85,6 +88,10 @@ def main():
     ap.add_argument('--rays', type=int, default=4096, help='rays per GPU per step')
     ap.add_argument('--start-step', type=int, default=20000, help='training-step index of the first iteration')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--mlp-dtype', default='fp32', choices=['fp32', 'bf16'],
+                    help="'bf16' = BASELINE config 4's MLP arithmetic (not the headline: the reference computes in fp32)")
+    ap.add_argument('--real-capture', action='store_true',
+                    help='real-capture code path (is_nerf False, sphere_direction True): BASELINE config 4 with --rays 8192 --mlp-dtype bf16')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--time-every', type=int, default=4,
                     help='bracket the GEMM launches with HIP events on every Nth timed step (the event pairs cost ~4 ms/step)')
@@ -114,10 +121,10 @@ def main():
     from nu_nerf_amd.parallel import GradAllReducer
 
     R = args.rays
-    cfg = build_cfg(R)
+    cfg = build_cfg(R, args.real_capture, args.mlp_dtype)
     torch.manual_seed(6033)
     net = NeROShapeRenderer(cfg, training=False)
-    net.load_param_dict(init_stage1_params(6033))       # identical replica on every rank
+    net.load_param_dict(init_stage1_params(6033, sphere_direction=args.real_capture))       # identical replica on every rank
     net = net.to(dev)
     losses = [name2loss[n](cfg) for n in SPHEREPOT_LOSSES]
     opt = torch.optim.Adam(net.parameters(), lr=1e-3, fused=os.environ.get('NU_BENCH_FUSED_ADAM', '1') == '1')
@@ -181,12 +188,19 @@ def main():
     if rank == 0:
         ms = 1e3 * elapsed / args.steps
         value = R * world * args.steps / elapsed
+        if args.real_capture or args.mlp_dtype != 'fp32':
+            workload = ("stage-1 train step, %s code path, %d rays/GPU x (64 + 64 + 32) samples, %s MLP GEMMs (fp32 accumulate), "
+                        "synthetic cameras (BASELINE.json configs[3] when --real-capture --rays 8192 --mlp-dtype bf16)"
+                        % ("real-capture (is_nerf False, sphere_direction True)" if args.real_capture else "Spherepot", R,
+                           args.mlp_dtype))
+        else:
+            workload = ("Spherepot-shaped stage-1 train step, %d rays/GPU x (64 coarse + 64 importance + 32 bg) "
+                        "samples, fp32, synthetic cameras (BASELINE.json configs[1])" % R)
         res = {
             "metric": "train rays/sec", "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "Spherepot-shaped stage-1 train step, %d rays/GPU x (64 coarse + 64 importance + 32 bg) "
-                                   "samples, fp32, synthetic cameras (BASELINE.json configs[1])" % R,
+            "vs_baseline": None, "dtype": "f32" if args.mlp_dtype == 'fp32' else "bf16", "data": "synthetic",
+            "config": {"workload": workload,
                        "rays_per_gpu": R, "global_rays": R * world, "samples_per_ray": 160, "start_step": args.start_step,
                        "parallelism": "dp%d" % world,
                        "mean_inner_points": stats['P_in'] / args.steps, "mean_outer_points": stats['P_out'] / args.steps,
@@ -198,21 +212,28 @@ def main():
             # in separate --pmc runs, gfx950 corrections applied by scripts/summarize_pmc.py); null if absent or other workload
             traffic = None
             tj = os.path.join(ROOT, 'profiles', 'r01', 'traffic_pmc.json')
-            if os.path.exists(tj) and R == 4096 and world == 1:
+            if os.path.exists(tj) and R == 4096 and world == 1 and not args.real_capture and args.mlp_dtype == 'fp32':
                 traffic = json.load(open(tj)).get('gemm_nt_kernel', {}).get('hbm_bytes_per_launch')
-            res["roofline"] = {"bound": "mfma", "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                               "frac": tf / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
-                               "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/r01/traffic_pmc.json)",
-                               "algorithmic_bytes_per_launch": ktime['bytes'] / max(ktime['launches'], 1),
-                               "algorithmic_flops_per_launch": ktime['flops'] / max(ktime['launches'], 1),
-                               "kernel": "gemm_nt_kernel<*> (fp32 v_mfma_f32_32x32x2_f32)",
-                               "launches": ktime['launches'], "avg_launch_us": 1e6 * ktime['seconds'] / max(ktime['launches'], 1),
-                               "event_timed_steps": timed_steps,
-                               "gemm_time_share": ktime['seconds'] / (elapsed * timed_steps / args.steps),
-                               "wgrad": {"achieved": ktime['tn_flops'] / max(ktime['tn_seconds'], 1e-12) / 1e12,
-                                         "launches": ktime['tn_launches'],
-                                         "time_share": ktime['tn_seconds'] / (elapsed * timed_steps / args.steps)}}
-        if world == 1 and not args.no_cpu_baseline:
+            common = {"algorithmic_bytes_per_launch": ktime['bytes'] / max(ktime['launches'], 1),
+                      "algorithmic_flops_per_launch": ktime['flops'] / max(ktime['launches'], 1),
+                      "launches": ktime['launches'], "avg_launch_us": 1e6 * ktime['seconds'] / max(ktime['launches'], 1),
+                      "event_timed_steps": timed_steps,
+                      "gemm_time_share": ktime['seconds'] / (elapsed * timed_steps / args.steps),
+                      "wgrad": {"achieved": ktime['tn_flops'] / max(ktime['tn_seconds'], 1e-12) / 1e12,
+                                "launches": ktime['tn_launches'],
+                                "time_share": ktime['tn_seconds'] / (elapsed * timed_steps / args.steps)}}
+            if args.mlp_dtype != 'fp32':
+                # bf16 build: the operands stay fp32 in HBM and are rounded on load, so the GEMMs are bound by streaming them
+                gbs = ktime['bytes'] / max(ktime['seconds'], 1e-12) / 1e9
+                res["roofline"] = {"bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0,
+                                   "traffic": None, "mfma_tflops": tf,
+                                   "kernel": "gemm_nt_kernel<*, bf16> (v_mfma_f32_32x32x16_bf16, fp32 operands in HBM)", **common}
+            else:
+                res["roofline"] = {"bound": "mfma", "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                   "frac": tf / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
+                                   "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/r01/traffic_pmc.json)",
+                                   "kernel": "gemm_nt_kernel<*> (fp32 v_mfma_f32_32x32x2_f32)", **common}
+        if world == 1 and not args.no_cpu_baseline and not args.real_capture and args.mlp_dtype == 'fp32':
             res["cpu_baseline"] = cpu_baseline(pool, args.start_step)
         print(json.dumps(res), flush=True)
     if world > 1:

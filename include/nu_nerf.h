@@ -63,6 +63,7 @@ typedef struct NuGemmNT {      /* C[M,N] = epi(A[M,K] . B[N,K]^T);  K % 32 == 0,
     int groups;                /* grouped launch; element strides per group follow */
     long long sA, sB, sC, sC2, sBias, sH, sD, sCadd;
     int epi;                   /* enum NuEpi */
+    int bf16;                  /* 0: exact fp32 MFMA (default).  1: operands rounded to bf16 on load, bf16 MFMA, fp32 accumulate */
 } NuGemmNT;
 
 typedef struct NuGemmTN {      /* dW[N1,N2] = A0^T B0 (+ A1^T B1), reduced over P rows in S deterministic splits */
@@ -72,6 +73,7 @@ typedef struct NuGemmTN {      /* dW[N1,N2] = A0^T B0 (+ A1^T B1), reduced over 
     float* slab; float* bias_slab;                           /* filled by nu_wgrad from the workspace */
     int S, groups;
     long long sA0, sB0, sA1, sB1, sSlab, sBiasSlab;
+    int bf16, pad_;                                          /* as NuGemmNT.bf16 */
 } NuGemmTN;
 
 /* One deterministic split reduction: out[n1*ldo + n2] (+)= alpha * sum_{s<S} slab[s*ss + n1*rs + n2], n1 < N1, n2 < N2.
@@ -87,6 +89,8 @@ typedef struct NuReduceDesc {
 int nu_reduce_desc_size(void);
 int nu_slab_reduce_batched(const NuReduceDesc* descs_host, int n, hipStream_t stream);
 
+int nu_gemm_nt_size(void);      /* sizeof(NuGemmNT) / sizeof(NuGemmTN) as compiled: binding-side ABI check */
+int nu_gemm_tn_size(void);
 int nu_gemm_nt_ex(const NuGemmNT* g, hipStream_t stream);
 long long nu_wgrad_workspace_bytes(int N1, int N2, int S, int groups);
 /* deferred weight gradient: split GEMM now, reductions appended to descs[*ndesc...] (capacity cap); the workspace must

@@ -10,6 +10,7 @@
 #define TBN 128
 #define TBK 32
 #define NT_LDS 36   // padded row stride (floats): 36*r mod 64 hits every 16-B slot once per 16 rows
+#define NT_LDSH 40  // bf16 image: padded row stride in elements (80 B)
 #define NT_WPC 3    // workgroups per CU the NT kernel is built for (LDS 36.9 KB, <= 168 VGPRs)
 
 // ------------------------------------------------------------------------------------------------
@@ -45,9 +46,17 @@ __device__ unsigned long long nu_dbg_clk[2];
 // under the MFMAs; only the register -> LDS hand-over sits between two barriers, and the other resident workgroups
 // keep the matrix pipe busy meanwhile (measured: +5..12 % over a double-buffered 2-workgroup build on the K = 256
 // layers, where the per-tile epilogue is 10-15 % of a tile).  Epilogue in two 32-row halves per wave.
-template <int EPI>
+//
+// BF16 = true (cfg mlp_dtype 'bf16', BASELINE config 4): same tiles and epilogues, operands rounded to bf16 (RNE,
+// v_cvt_pk_bf16_f32) on their way into LDS and multiplied on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.
+// Activations and weights stay fp32 in HBM, so this build is bound by streaming them (HBM / L1), not by the
+// matrix pipe: 16x the MFMA rate buys ~3x on the K = 256 layers.
+template <int EPI, bool BF16>
 __global__ __launch_bounds__(256, NT_WPC) void gemm_nt_kernel(NuGemmNT g) {
     __shared__ __attribute__((aligned(16))) float smem[2][TBM * NT_LDS];   // 36864 B; epilogue scratch aliases it
+    // bf16 image: [128 rows][32 k] per operand, rows padded to NT_LDSH elements (80 B: b128 reads stay conflict-free)
+    __bf16* const hA = reinterpret_cast<__bf16*>(&smem[0][0]);
+    __bf16* const hB = hA + TBM * NT_LDSH;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -68,6 +77,8 @@ __global__ __launch_bounds__(256, NT_WPC) void gemm_nt_kernel(NuGemmNT g) {
     const int li = lane & 31, lh = lane >> 5;
     const int a_off = (wr * 64 + li) * NT_LDS + 4 * lh;
     const int b_off = (wc * 64 + li) * NT_LDS + 4 * lh;
+    const int ah_off = (wr * 64 + li) * NT_LDSH + 8 * lh;   // lane (r, h) holds k = 8h .. 8h+7 of a 16-deep MFMA step
+    const int bh_off = (wc * 64 + li) * NT_LDSH + 8 * lh;
 
     auto slot_tile = [&](int j, int& mt, int& nt) -> bool {
         const int grp = j / (8 * ntn);
@@ -107,8 +118,13 @@ __global__ __launch_bounds__(256, NT_WPC) void gemm_nt_kernel(NuGemmNT g) {
     auto store_regs = [&]() {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<f32x4*>(&smem[0][(r0 + 32 * i) * NT_LDS + 4 * c4]) = ra4[i];
-            *reinterpret_cast<f32x4*>(&smem[1][(r0 + 32 * i) * NT_LDS + 4 * c4]) = rb4[i];
+            if (BF16) {
+                *reinterpret_cast<bf16x4*>(&hA[(r0 + 32 * i) * NT_LDSH + 4 * c4]) = nu_to_bf16x4(ra4[i]);
+                *reinterpret_cast<bf16x4*>(&hB[(r0 + 32 * i) * NT_LDSH + 4 * c4]) = nu_to_bf16x4(rb4[i]);
+            } else {
+                *reinterpret_cast<f32x4*>(&smem[0][(r0 + 32 * i) * NT_LDS + 4 * c4]) = ra4[i];
+                *reinterpret_cast<f32x4*>(&smem[1][(r0 + 32 * i) * NT_LDS + 4 * c4]) = rb4[i];
+            }
         }
     };
 
@@ -157,20 +173,34 @@ __global__ __launch_bounds__(256, NT_WPC) void gemm_nt_kernel(NuGemmNT g) {
                 set_ptrs(mtn, ntnx);
                 load_regs(0);
             }
-            const float* As = smem[0];
-            const float* Bs = smem[1];
+            if (BF16) {
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                f32x4 a0 = *reinterpret_cast<const f32x4*>(&As[a_off + kk * 8]);
-                f32x4 a1 = *reinterpret_cast<const f32x4*>(&As[a_off + 32 * NT_LDS + kk * 8]);
-                f32x4 b0 = *reinterpret_cast<const f32x4*>(&Bs[b_off + kk * 8]);
-                f32x4 b1 = *reinterpret_cast<const f32x4*>(&Bs[b_off + 32 * NT_LDS + kk * 8]);
+                for (int ks = 0; ks < 2; ++ks) {
+                    const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(&hA[ah_off + 16 * ks]);
+                    const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(&hA[ah_off + 32 * NT_LDSH + 16 * ks]);
+                    const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(&hB[bh_off + 16 * ks]);
+                    const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(&hB[bh_off + 32 * NT_LDSH + 16 * ks]);
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+                }
+            } else {
+                const float* As = smem[0];
+                const float* Bs = smem[1];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b0[e], acc[0][0], 0, 0, 0);
-                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b1[e], acc[0][1], 0, 0, 0);
-                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b0[e], acc[1][0], 0, 0, 0);
-                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b1[e], acc[1][1], 0, 0, 0);
+                for (int kk = 0; kk < 4; ++kk) {
+                    f32x4 a0 = *reinterpret_cast<const f32x4*>(&As[a_off + kk * 8]);
+                    f32x4 a1 = *reinterpret_cast<const f32x4*>(&As[a_off + 32 * NT_LDS + kk * 8]);
+                    f32x4 b0 = *reinterpret_cast<const f32x4*>(&Bs[b_off + kk * 8]);
+                    f32x4 b1 = *reinterpret_cast<const f32x4*>(&Bs[b_off + 32 * NT_LDS + kk * 8]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b0[e], acc[0][0], 0, 0, 0);
+                        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b1[e], acc[0][1], 0, 0, 0);
+                        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b0[e], acc[1][0], 0, 0, 0);
+                        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b1[e], acc[1][1], 0, 0, 0);
+                    }
                 }
             }
             __syncthreads();   // every wave is done reading this chunk (and, after the last one, the scratch is free)
@@ -266,7 +296,8 @@ int nu_gemm_nt_launch(const NuGemmNT& g, hipStream_t stream) {
     if (per > nslots) per = nslots;
     dim3 grid((unsigned)per, 1, groups), block(256);
     switch (g.epi) {
-#define NU_CASE(E) case E: hipLaunchKernelGGL(gemm_nt_kernel<E>, grid, block, 0, stream, g); break;
+#define NU_CASE(E) case E: if (g.bf16) hipLaunchKernelGGL((gemm_nt_kernel<E, true>), grid, block, 0, stream, g); \
+                           else hipLaunchKernelGGL((gemm_nt_kernel<E, false>), grid, block, 0, stream, g); break;
         NU_CASE(NU_EPI_BIAS_NONE)
         NU_CASE(NU_EPI_BIAS_RELU)
         NU_CASE(NU_EPI_BIAS_SOFTPLUS)
@@ -290,9 +321,11 @@ int nu_gemm_nt_launch(const NuGemmNT& g, hipStream_t stream) {
 // inner loop is exactly the NT kernel's (one ds_read_b128 feeds four MFMA k-steps) and nothing consumes a global
 // load before the hand-over to LDS -- the loads stay in flight under the 64 MFMAs of the current chunk.
 // BIG = operands of 4 GiB or more (64-bit element offsets instead of one uniform base + a 32-bit byte offset).
-template <bool BIG>
+template <bool BIG, bool BF16>
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(NuGemmTN g) {
     __shared__ __attribute__((aligned(16))) float smem[2][128 * NT_LDS];
+    __bf16* const hA = reinterpret_cast<__bf16*>(&smem[0][0]);      // bf16 image, as in the NT kernel
+    __bf16* const hB = hA + 128 * NT_LDSH;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -375,8 +408,13 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(NuGemmTN g) {
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<f32x4*>(&smem[0][c * NT_LDS + kg * 16 + 4 * i]) = ra4[i];
-            *reinterpret_cast<f32x4*>(&smem[1][c * NT_LDS + kg * 16 + 4 * i]) = rb4[i];
+            if (BF16) {
+                *reinterpret_cast<bf16x4*>(&hA[c * NT_LDSH + kg * 16 + 4 * i]) = nu_to_bf16x4(ra4[i]);
+                *reinterpret_cast<bf16x4*>(&hB[c * NT_LDSH + kg * 16 + 4 * i]) = nu_to_bf16x4(rb4[i]);
+            } else {
+                *reinterpret_cast<f32x4*>(&smem[0][c * NT_LDS + kg * 16 + 4 * i]) = ra4[i];
+                *reinterpret_cast<f32x4*>(&smem[1][c * NT_LDS + kg * 16 + 4 * i]) = rb4[i];
+            }
         }
     };
 
@@ -389,20 +427,36 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(NuGemmTN g) {
     const int li = lane & 31, lh = lane >> 5;
     const int a_off = (wr * 64 + li) * NT_LDS + 4 * lh;
     const int b_off = (wc * 64 + li) * NT_LDS + 4 * lh;
+    const int ah_off = (wr * 64 + li) * NT_LDSH + 8 * lh;
+    const int bh_off = (wc * 64 + li) * NT_LDSH + 8 * lh;
     for (int t = 0; t < total; ++t) {
         if (t + 1 < total) load_tile(t + 1);
+        if (BF16) {
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            const f32x4 a0 = *reinterpret_cast<const f32x4*>(&smem[0][a_off + kk * 8]);
-            const f32x4 a1 = *reinterpret_cast<const f32x4*>(&smem[0][a_off + 32 * NT_LDS + kk * 8]);
-            const f32x4 b0 = *reinterpret_cast<const f32x4*>(&smem[1][b_off + kk * 8]);
-            const f32x4 b1 = *reinterpret_cast<const f32x4*>(&smem[1][b_off + 32 * NT_LDS + kk * 8]);
+            for (int ks = 0; ks < 2; ++ks) {
+                const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(&hA[ah_off + 16 * ks]);
+                const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(&hA[ah_off + 32 * NT_LDSH + 16 * ks]);
+                const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(&hB[bh_off + 16 * ks]);
+                const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(&hB[bh_off + 32 * NT_LDSH + 16 * ks]);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+            }
+        } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b0[e], acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b1[e], acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b0[e], acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b1[e], acc[1][1], 0, 0, 0);
+            for (int kk = 0; kk < 4; ++kk) {
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(&smem[0][a_off + kk * 8]);
+                const f32x4 a1 = *reinterpret_cast<const f32x4*>(&smem[0][a_off + 32 * NT_LDS + kk * 8]);
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(&smem[1][b_off + kk * 8]);
+                const f32x4 b1 = *reinterpret_cast<const f32x4*>(&smem[1][b_off + 32 * NT_LDS + kk * 8]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b0[e], acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b1[e], acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b0[e], acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b1[e], acc[1][1], 0, 0, 0);
+                }
             }
         }
         __syncthreads();
@@ -439,8 +493,11 @@ int nu_gemm_tn_launch(const NuGemmTN& g, hipStream_t stream) {
     dim3 grid(nu_cdiv(g.N1, 128) * nu_cdiv(g.N2, 128), g.S, g.groups > 0 ? g.groups : 1), block(256);
     const long long max_ld = (g.lda0 > g.ldb0 ? g.lda0 : g.ldb0) > (g.A1 ? (g.lda1 > g.ldb1 ? g.lda1 : g.ldb1) : 0)
                                  ? (g.lda0 > g.ldb0 ? g.lda0 : g.ldb0) : (g.lda1 > g.ldb1 ? g.lda1 : g.ldb1);
-    if ((long long)g.P * max_ld * 4 >= (1LL << 32)) hipLaunchKernelGGL((gemm_tn_kernel<true>), grid, block, 0, stream, g);
-    else hipLaunchKernelGGL((gemm_tn_kernel<false>), grid, block, 0, stream, g);
+    const bool big = (long long)g.P * max_ld * 4 >= (1LL << 32);
+    if (big && g.bf16) hipLaunchKernelGGL((gemm_tn_kernel<true, true>), grid, block, 0, stream, g);
+    else if (big) hipLaunchKernelGGL((gemm_tn_kernel<true, false>), grid, block, 0, stream, g);
+    else if (g.bf16) hipLaunchKernelGGL((gemm_tn_kernel<false, true>), grid, block, 0, stream, g);
+    else hipLaunchKernelGGL((gemm_tn_kernel<false, false>), grid, block, 0, stream, g);
     return nu_launch_status();
 }
 
@@ -567,6 +624,9 @@ extern "C" int nu_gemm_tn(const float* A0, int lda0, const float* B0, int ldb0, 
     return nu_wgrad(&g, C, ldc, 0, bias_out, 0, workspace, workspace_bytes, stream);
 }
 
+extern "C" int nu_gemm_nt_size(void) { return (int)sizeof(NuGemmNT); }
+extern "C" int nu_gemm_tn_size(void) { return (int)sizeof(NuGemmTN); }
+
 // struct-pointer entry points (what the Python host layer binds; one pointer argument keeps ctypes cheap)
 extern "C" int nu_gemm_nt_ex(const NuGemmNT* g, hipStream_t stream) { return nu_gemm_nt_launch(*g, stream); }
 
@@ -618,8 +678,8 @@ extern "C" int nu_wgrad(const NuGemmTN* gin, float* dW, int ldw, long long sW, f
 // development aid: occupancy query for the two GEMM kernels (blocks per CU)
 extern "C" int nu_debug_occupancy(int which) {
     int n = -1;
-    if (which == 0) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_nt_kernel<NU_EPI_BIAS_SOFTPLUS>, 256, 0);
-    else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (gemm_tn_kernel<false>), 256, 0);
+    if (which == 0) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (gemm_nt_kernel<NU_EPI_BIAS_SOFTPLUS, false>), 256, 0);
+    else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (gemm_tn_kernel<false, false>), 256, 0);
     return n;
 }
 

@@ -10,8 +10,17 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 #define NU_WAVE 64
+
+// round-to-nearest-even fp32 -> bf16 (v_cvt_pk_bf16_f32; NaN stays NaN)
+static __device__ inline bf16x4 nu_to_bf16x4(f32x4 v) {
+    bf16x4 o;
+    o[0] = (__bf16)v[0]; o[1] = (__bf16)v[1]; o[2] = (__bf16)v[2]; o[3] = (__bf16)v[3];
+    return o;
+}
 
 // ceil-div / round-up helpers (host + device)
 static __host__ __device__ inline int nu_cdiv(int a, int b) { return (a + b - 1) / b; }

@@ -36,14 +36,14 @@ class GemmNT(ctypes.Structure):
                 ("C", c_p), ("ldc", c_int), ("C2", c_p), ("ldc2", c_int), ("bias", c_p), ("H", c_p), ("ldh", c_int),
                 ("D", c_p), ("ldd", c_int), ("Cadd", c_p), ("ldadd", c_int), ("zero_to", c_int), ("act_cols", c_int),
                 ("alpha", c_f), ("groups", c_int), ("sA", c_ll), ("sB", c_ll), ("sC", c_ll), ("sC2", c_ll),
-                ("sBias", c_ll), ("sH", c_ll), ("sD", c_ll), ("sCadd", c_ll), ("epi", c_int)]
+                ("sBias", c_ll), ("sH", c_ll), ("sD", c_ll), ("sCadd", c_ll), ("epi", c_int), ("bf16", c_int)]
 
 
 class GemmTN(ctypes.Structure):
     _fields_ = [("A0", c_p), ("lda0", c_int), ("B0", c_p), ("ldb0", c_int), ("A1", c_p), ("lda1", c_int),
                 ("B1", c_p), ("ldb1", c_int), ("P", c_int), ("N1", c_int), ("N2", c_int), ("slab", c_p),
                 ("bias_slab", c_p), ("S", c_int), ("groups", c_int), ("sA0", c_ll), ("sB0", c_ll), ("sA1", c_ll),
-                ("sB1", c_ll), ("sSlab", c_ll), ("sBiasSlab", c_ll)]
+                ("sB1", c_ll), ("sSlab", c_ll), ("sBiasSlab", c_ll), ("bf16", c_int), ("pad_", c_int)]
 
 
 class ReduceDesc(ctypes.Structure):
@@ -104,6 +104,13 @@ class Stage1Engine:
             getattr(lib, fn).restype = c_ll
         assert lib.nu_pack_desc_size() == ctypes.sizeof(PackDesc), "PackDesc ABI mismatch"
         assert lib.nu_reduce_desc_size() == ctypes.sizeof(ReduceDesc), "ReduceDesc ABI mismatch"
+        assert lib.nu_gemm_nt_size() == ctypes.sizeof(GemmNT) and lib.nu_gemm_tn_size() == ctypes.sizeof(GemmTN), "GEMM ABI mismatch"
+        # MLP arithmetic: 'fp32' = exact fp32 MFMA (the reference's precision); 'bf16' = operands rounded to bf16 on their
+        # way into LDS, bf16 MFMA with fp32 accumulation (BASELINE config 4; no reference counterpart, tolerance in the tests)
+        md = str(cfg.get('mlp_dtype', 'fp32')).lower()
+        if md not in ('fp32', 'f32', 'float32', 'bf16', 'bfloat16'):
+            raise ValueError(f"mlp_dtype {md!r}: expected 'fp32' or 'bf16'")
+        self.bf16 = 1 if md.startswith('b') else 0
         # deferred split reductions (weight gradients, skinny heads, column sums): partial slabs live in a bump arena
         # until flush_reductions() sums them all in a few batched launches (before unpack_grads reads the results)
         self._rd_cap = 1024
@@ -336,7 +343,7 @@ class Stage1Engine:
         if M <= 0:
             return
         g = GemmNT(A, lda, B, ldb, M, N, K, C, ldc, C2, ldc2, bias, H, ldh, D, ldd, Cadd, ldadd, zero_to, act_cols,
-                   alpha, groups, sA, sB, sC, sC2, sBias, sH, sD, sCadd, epi)
+                   alpha, groups, sA, sB, sC, sC2, sBias, sH, sD, sCadd, epi, self.bf16)
         kt = self._ktime if self.ktime_on else None
         if kt is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -384,7 +391,7 @@ class Stage1Engine:
         if self._nrd.value + 2 * groups > self._rd_cap:
             self.flush_reductions()
         ws, nb = self._arena_take(self.lib.nu_wgrad_workspace_bytes(N1, N2, S, groups))
-        g = GemmTN(A0, lda0, B0, ldb0, A1, lda1, B1, ldb1, P, N1, N2, 0, 0, S, groups, sA0, sB0, sA1, sB1, 0, 0)
+        g = GemmTN(A0, lda0, B0, ldb0, A1, lda1, B1, ldb1, P, N1, N2, 0, 0, S, groups, sA0, sB0, sA1, sB1, 0, 0, self.bf16, 0)
         L.check(self.lib.nu_wgrad_enqueue(ctypes.byref(g), c_p(dW), ldw, c_ll(sW), c_p(db), c_ll(sDb), c_p(ws), c_ll(nb),
                                           self._rd, ctypes.byref(self._nrd), self._rd_cap, self.stream()), "nu_wgrad_enqueue")
 

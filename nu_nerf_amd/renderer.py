@@ -475,6 +475,8 @@ class NeROShapeRenderer(nn.Module):
     def train_step_rays(self, batch, step, rand=None):
         """One training forward on an explicit ray batch {'rays_o','rays_d','rgbs'} (renderer_zerothick.py:447-466)."""
         rays_o, rays_d, near, far, poses = self._process_nerf_ray_batch(batch)
+        if not self.is_nerf:    # real captures: near / far bracket the unit sphere (renderer_zerothick.py:320-327, :357)
+            near, far = self.near_far_from_sphere(rays_o, rays_d)
         outputs = self.render(rays_o, rays_d, near, far, poses, -1, self.get_anneal_val(step), is_train=True, step=step,
                               is_nerf=self.is_nerf, rand=rand)
         outputs['loss_rgb'] = self.compute_rgb_loss(outputs['ray_rgb'], batch['rgbs'])

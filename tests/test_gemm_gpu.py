@@ -139,6 +139,59 @@ def test_tn_weight_grad_operand_over_4gib(gpu):
     torch.testing.assert_close(bo.double(), bref, rtol=2e-5, atol=tol)
 
 
+def _bf(x):
+    return x.bfloat16().float()
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 1, 32), (300, 217, 256), (1000, 257, 288), (4099, 256, 96)])
+def test_bf16_nt_matches_bf16_rounded_operands(gpu, M, N, K):
+    """mlp_dtype 'bf16': operands are rounded to bf16 (RNE) on load and multiplied exactly (a bf16 x bf16 product is exact
+    in fp32), so against fp64 on the rounded operands only the fp32 accumulation order is left."""
+    from nu_nerf_amd import _lib as L
+    from nu_nerf_amd.engine import GemmNT, addr
+    lib = L.load()
+    torch.manual_seed(M + N)
+    A = torch.randn(M, K, device=gpu)
+    W = torch.randn(N, K, device=gpu) / K ** 0.5
+    B = _packB(W, K)
+    bias = torch.randn(N, device=gpu)
+    H = torch.rand(M, N, device=gpu) - 0.5
+    ref = _bf(A).double() @ _bf(W).double().t()
+    for epi, want in ((7, ref), (1, torch.relu(ref + bias.double())), (3, ref * (H > 0))):
+        C = torch.full((M, N), float("nan"), device=gpu)
+        g = GemmNT(addr(A), K, addr(B), K, M, N, K, addr(C), N, 0, 0, addr(bias), addr(H), N, 0, 0, 0, 0, 0, 0, 1.0, 1,
+                   0, 0, 0, 0, 0, 0, 0, 0, epi, 1)
+        L.check(lib.nu_gemm_nt_ex(ctypes.byref(g), L.stream()), "nu_gemm_nt_ex")
+        torch.testing.assert_close(C.double(), want, rtol=2e-5, atol=2e-5 * K ** 0.5)
+    # and it really is a different arithmetic from the fp32 path
+    exact = A.double() @ W.double().t()
+    if M * N > 1000:
+        assert (ref - exact).abs().max() > 1e-4
+
+
+@pytest.mark.parametrize("P,N1,N2,S", [(1000, 257, 256, 7), (5000, 256, 39, 16), (333, 3, 256, 4)])
+def test_bf16_tn_weight_grad(gpu, P, N1, N2, S):
+    from nu_nerf_amd import _lib as L
+    from nu_nerf_amd.engine import GemmTN, addr
+    lib = L.load()
+    lib.nu_wgrad_workspace_bytes.restype = ctypes.c_longlong
+    torch.manual_seed(P)
+    lda, ldb = (N1 + 3) // 4 * 4 + 4, (N2 + 3) // 4 * 4
+    A0, B0 = torch.randn(P, lda, device=gpu), torch.randn(P, ldb, device=gpu)
+    A1, B1 = torch.randn(P, lda, device=gpu), torch.randn(P, ldb, device=gpu)
+    wsb = lib.nu_wgrad_workspace_bytes(N1, N2, S, 1)
+    ws = torch.empty(wsb // 4, device=gpu)
+    C = torch.full((N1, N2), float("nan"), device=gpu)
+    bo = torch.full((N1,), float("nan"), device=gpu)
+    g = GemmTN(addr(A0), lda, addr(B0), ldb, addr(A1), lda, addr(B1), ldb, P, N1, N2, 0, 0, S, 1, 0, 0, 0, 0, 0, 0, 1, 0)
+    L.check(lib.nu_wgrad(ctypes.byref(g), L.ptr(C), N2, ctypes.c_longlong(0), L.ptr(bo), ctypes.c_longlong(0), L.ptr(ws),
+                         ctypes.c_longlong(wsb), L.stream()), "nu_wgrad")
+    ref = _bf(A0[:, :N1]).double().t() @ _bf(B0[:, :N2]).double() + _bf(A1[:, :N1]).double().t() @ _bf(B1[:, :N2]).double()
+    tol = 3e-5 * P ** 0.5
+    torch.testing.assert_close(C.double(), ref, rtol=2e-5, atol=tol)
+    torch.testing.assert_close(bo.double(), A0[:, :N1].double().sum(0), rtol=2e-5, atol=tol)   # bias sums stay fp32
+
+
 def test_gemm_throughput_smoke(gpu):
     """Not a pass/fail perf gate: prints achieved TFLOP/s of the 256x256 layer GEMM."""
     M, N, K = 262144, 256, 256
