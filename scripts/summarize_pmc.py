@@ -22,5 +22,8 @@ for k in f:
     res[k] = {"launches": n, "fetch_bytes_per_launch": 2.0 * 1024 * f[k][1] / n, "write_bytes_per_launch": 1024 * w[k][1] / max(w[k][0], 1),
               "note": "FETCH_SIZE x2 (gfx950 128-B request correction), KiB units; separate --pmc passes"}
     res[k]["hbm_bytes_per_launch"] = res[k]["fetch_bytes_per_launch"] + res[k]["write_bytes_per_launch"]
+    if k == 'gemm_tn_kernel':
+        res[k]["note"] += ("; this kernel reads 4 B per lane (256 B per wave instruction), a form the guide's x2 correction "
+                           "was not established for: uncorrected fetch = half the figure above")
 json.dump(res, open(out_json, 'w'), indent=1)
 print(json.dumps(res, indent=1))
