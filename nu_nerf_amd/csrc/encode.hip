@@ -133,70 +133,72 @@ extern "C" int nu_embed_j(const float* E, const float* nbar, int P, float* Q0, f
 // ------------------------------------------------------------------------------------------------
 // IDE: lane i < 36 evaluates term i.  Returns (re, im) and optionally the partials.
 // ------------------------------------------------------------------------------------------------
-struct NuIdeTerm {
-    float re, im;          // value
+// Per-lane constants of term i = lane (loaded once per kernel: the Horner loop then runs out of registers with a uniform
+// trip count -- coefficients above degree l - m are zero in the table, and leading zeros leave Horner's arithmetic unchanged)
+struct NuIdeLane {
+    float c[NU_IDE_DEG];
+    float sigma, att1;     // l(l+1)/2 and exp(-sigma) (kappa_inv = 1: the diffuse query)
+    int m;
+    bool live;
+};
+static __device__ inline NuIdeLane nu_ide_lane(int lane) {
+    NuIdeLane L;
+    const int i = lane < NU_IDE_TERMS ? lane : NU_IDE_TERMS - 1;
+#pragma unroll
+    for (int k = 0; k < NU_IDE_DEG; ++k) L.c[k] = c_ide_mat[i][k];
+    const int l = c_ide_l[i];
+    L.m = c_ide_m[i];
+    L.sigma = 0.5f * (float)l * (float)(l + 1);
+    L.att1 = expf(-L.sigma);
+    L.live = lane < NU_IDE_TERMS;
+    return L;
+}
+// Direction-dependent factors of one term, shared by every kappa the direction is queried with
+struct NuIdeDir {
     float are, aim;        // (x+iy)^m
     float pre, pim;        // (x+iy)^(m-1)   (0 for m = 0)
     float poly, dpoly;     // P(z), P'(z)
-    float att;             // exp(-sigma * kappa_inv)
-    float sigma;
-    int m;
 };
-
-static __device__ inline NuIdeTerm nu_ide_term(int i, float x, float y, float z, float kappa_inv) {
-    NuIdeTerm t;
-    const int m = c_ide_m[i], l = c_ide_l[i];
+static __device__ inline NuIdeDir nu_ide_dir(const NuIdeLane& L, float x, float y, float z) {
+    NuIdeDir t;
     float ar = 1.f, ai = 0.f, pr = 0.f, pi = 0.f;
-    for (int j = 0; j < m; ++j) {
-        pr = ar; pi = ai;
-        const float nr = ar * x - ai * y;
-        const float ni = ar * y + ai * x;
-        ar = nr; ai = ni;
+#pragma unroll
+    for (int j = 0; j < NU_IDE_DEG - 1; ++j) {
+        if (j < L.m) {
+            pr = ar; pi = ai;
+            const float nr = ar * x - ai * y;
+            const float ni = ar * y + ai * x;
+            ar = nr; ai = ni;
+        }
     }
-    // Horner over k = l-m .. 0
     float poly = 0.f, dpoly = 0.f;
-    for (int k = l - m; k >= 0; --k) {
+#pragma unroll
+    for (int k = NU_IDE_DEG - 1; k >= 0; --k) {
         dpoly = dpoly * z + poly;
-        poly = poly * z + c_ide_mat[i][k];
+        poly = poly * z + L.c[k];
     }
-    const float sigma = 0.5f * (float)l * (float)(l + 1);
-    const float att = expf(-sigma * kappa_inv);
-    t.are = ar; t.aim = ai; t.pre = pr; t.pim = pi; t.poly = poly; t.dpoly = dpoly; t.att = att; t.sigma = sigma; t.m = m;
-    t.re = ar * poly * att;
-    t.im = ai * poly * att;
+    t.are = ar; t.aim = ai; t.pre = pr; t.pim = pi; t.poly = poly; t.dpoly = dpoly;
     return t;
 }
+static __device__ inline float nu_ide_att(const NuIdeLane& L, float kinv) { return expf(-L.sigma * kinv); }
 
-// write one 72-d IDE row (+ zero pad up to `width`) starting at column c0 of a row with `width` columns after c0
-static __device__ inline void nu_ide_write(float* row, int lane, float x, float y, float z, float kinv, int padto) {
-    if (lane < 36) {
-        NuIdeTerm t = nu_ide_term(lane, x, y, z, kinv);
-        row[lane] = t.re;
-        row[36 + lane] = t.im;
+// write one 72-d IDE row (+ zero pad up to `padto` columns) given the direction factors and the attenuation
+static __device__ inline void nu_ide_store(float* row, int lane, const NuIdeLane& L, const NuIdeDir& t, float att, int padto) {
+    if (L.live) {
+        row[lane] = t.are * t.poly * att;
+        row[36 + lane] = t.aim * t.poly * att;
     }
     for (int c = 72 + lane; c < padto; c += 64) row[c] = 0.f;
 }
-
-// gradient of sum_i (gre_i * re_i + gim_i * im_i) w.r.t. (x, y, z, kappa_inv); lanes >= 36 contribute 0.
-static __device__ inline void nu_ide_grad(const float* grow, int lane, float x, float y, float z, float kinv,
-                                          float& dx, float& dy, float& dz, float& dk) {
-    float ax = 0.f, ay = 0.f, az = 0.f, ak = 0.f;
-    if (lane < 36) {
-        const float gre = grow[lane], gim = grow[36 + lane];
-        NuIdeTerm t = nu_ide_term(lane, x, y, z, kinv);
-        const float pe = t.poly * t.att;
-        // conj(g) * m * A' * P * E  ->  real part = d/dx, -imag part = d/dy
-        const float cr = (float)t.m * pe * (gre * t.pre + gim * t.pim);
-        const float ci = (float)t.m * pe * (gre * t.pim - gim * t.pre);
-        ax = cr;
-        ay = -ci;
-        az = (gre * t.are + gim * t.aim) * t.dpoly * t.att;
-        ak = -t.sigma * (gre * t.re + gim * t.im);
-    }
-    dx = nu_wave_sum(ax);
-    dy = nu_wave_sum(ay);
-    dz = nu_wave_sum(az);
-    dk = nu_wave_sum(ak);
+// per-lane partials of d/d(x, y, z) of sum_i (gre_i re_i + gim_i im_i) for gradient weights already scaled by the
+// attenuation (gre, gim = sum over rows of att_row * g_row)
+static __device__ inline void nu_ide_dir_grad(const NuIdeLane& L, const NuIdeDir& t, float gre, float gim, float& ax, float& ay,
+                                              float& az) {
+    const float cr = (float)L.m * t.poly * (gre * t.pre + gim * t.pim);
+    const float ci = (float)L.m * t.poly * (gre * t.pim - gim * t.pre);
+    ax = cr;
+    ay = -ci;
+    az = (gre * t.are + gim * t.aim) * t.dpoly;
 }
 
 __global__ __launch_bounds__(256) void ide_kernel(const float* __restrict__ dirs, const float* __restrict__ kinv, int P,
@@ -204,9 +206,11 @@ __global__ __launch_bounds__(256) void ide_kernel(const float* __restrict__ dirs
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwave = (gridDim.x * blockDim.x) >> 6;
-    for (int p = wave; p < P; p += nwave)
-        nu_ide_write(out + (long long)p * ldo, lane, dirs[p * 3LL], dirs[p * 3LL + 1], dirs[p * 3LL + 2],
-                     kinv ? kinv[p] : 0.f, ldo);
+    const NuIdeLane L = nu_ide_lane(lane);
+    for (int p = wave; p < P; p += nwave) {
+        const NuIdeDir t = nu_ide_dir(L, dirs[p * 3LL], dirs[p * 3LL + 1], dirs[p * 3LL + 2]);
+        nu_ide_store(out + (long long)p * ldo, lane, L, t, nu_ide_att(L, kinv ? kinv[p] : 0.f), ldo);
+    }
 }
 // stand-alone IDE (test entry + the per-ray colour_spec query IDE(d, 0), renderer_zerothick.py:780)
 extern "C" int nu_ide(const float* dirs, const float* kappa_inv, int P, float* out, int ldo, hipStream_t stream) {
@@ -224,10 +228,16 @@ __global__ __launch_bounds__(256) void ide_bwd_kernel(const float* __restrict__ 
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwave = (gridDim.x * blockDim.x) >> 6;
+    const NuIdeLane L = nu_ide_lane(lane);
     for (int p = wave; p < P; p += nwave) {
-        float dx, dy, dz, dkk;
-        nu_ide_grad(gout + (long long)p * ldg, lane, dirs[p * 3LL], dirs[p * 3LL + 1], dirs[p * 3LL + 2],
-                    kinv ? kinv[p] : 0.f, dx, dy, dz, dkk);
+        const NuIdeDir t = nu_ide_dir(L, dirs[p * 3LL], dirs[p * 3LL + 1], dirs[p * 3LL + 2]);
+        const float att = nu_ide_att(L, kinv ? kinv[p] : 0.f);
+        const float* grow = gout + (long long)p * ldg;
+        const float gre = L.live ? grow[lane] * att : 0.f, gim = L.live ? grow[36 + lane] * att : 0.f;
+        float ax, ay, az;
+        nu_ide_dir_grad(L, t, gre, gim, ax, ay, az);
+        const float dx = nu_wave_sum(ax), dy = nu_wave_sum(ay), dz = nu_wave_sum(az);
+        const float dkk = nu_wave_sum(-L.sigma * t.poly * (gre * t.are + gim * t.aim));
         if (lane == 0) {
             ddirs[p * 3LL] = dx; ddirs[p * 3LL + 1] = dy; ddirs[p * 3LL + 2] = dz;
             if (dk) dk[p] = dkk;
@@ -316,6 +326,7 @@ __global__ __launch_bounds__(256) void shade_encode_fwd_kernel(const float* __re
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwave = (gridDim.x * blockDim.x) >> 6;
+    const NuIdeLane IL = nu_ide_lane(lane);
     for (int p = wave; p < P; p += nwave) {
         float n[3], d[3], x[3], nh[3], vh[3], r[3], nov, inorm;
 #pragma unroll
@@ -327,25 +338,31 @@ __global__ __launch_bounds__(256) void shade_encode_fwd_kernel(const float* __re
         float* ol0 = OLin + (long long)p * ld_ol;
         float* ol1 = OLin + (long long)(P + p) * ld_ol;
         float* ol2 = OLin + (long long)(2LL * P + p) * ld_ol;
+        // two direction evaluations (n^, r) serve all five IDE rows: only the attenuation differs between them
+        const NuIdeDir tn = nu_ide_dir(IL, nh[0], nh[1], nh[2]);
+        const NuIdeDir tr = nu_ide_dir(IL, r[0], r[1], r[2]);
+        const float att_rho = nu_ide_att(IL, rho);
         if (sphere) {
             const NuSph sn = nu_sph_point(x, nh), sr = nu_sph_point(x, r);
-            nu_ide_write(ol0, lane, nh[0], nh[1], nh[2], 1.0f, 72);
-            nu_ide_write(ol0 + 72, lane, sn.s[0], sn.s[1], sn.s[2], 1.0f, ld_ol - 72);
-            nu_ide_write(ol1, lane, r[0], r[1], r[2], rho, 72);
-            nu_ide_write(ol1 + 72, lane, sr.s[0], sr.s[1], sr.s[2], rho, ld_ol - 72);
-            nu_ide_write(ol2, lane, r[0], r[1], r[2], 0.0f, 72);
-            nu_ide_write(ol2 + 72, lane, sr.s[0], sr.s[1], sr.s[2], rho, ld_ol - 72);
+            const NuIdeDir tsn = nu_ide_dir(IL, sn.s[0], sn.s[1], sn.s[2]);
+            const NuIdeDir tsr = nu_ide_dir(IL, sr.s[0], sr.s[1], sr.s[2]);
+            nu_ide_store(ol0, lane, IL, tn, IL.att1, 72);
+            nu_ide_store(ol0 + 72, lane, IL, tsn, IL.att1, ld_ol - 72);
+            nu_ide_store(ol1, lane, IL, tr, att_rho, 72);
+            nu_ide_store(ol1 + 72, lane, IL, tsr, att_rho, ld_ol - 72);
+            nu_ide_store(ol2, lane, IL, tr, 1.0f, 72);
+            nu_ide_store(ol2 + 72, lane, IL, tsr, att_rho, ld_ol - 72);
         } else {
-            nu_ide_write(ol0, lane, nh[0], nh[1], nh[2], 1.0f, ld_ol);
-            nu_ide_write(ol1, lane, r[0], r[1], r[2], rho, ld_ol);
-            nu_ide_write(ol2, lane, r[0], r[1], r[2], 0.0f, ld_ol);
+            nu_ide_store(ol0, lane, IL, tn, IL.att1, ld_ol);
+            nu_ide_store(ol1, lane, IL, tr, att_rho, ld_ol);
+            nu_ide_store(ol2, lane, IL, tr, 1.0f, ld_ol);
         }
 
         float* il0 = ILin + (long long)p * 128;
         float* il1 = ILin + (long long)(P + p) * 128;
         if (lane < 39) { il0[lane] = e; il1[lane] = e; }
-        nu_ide_write(il0 + 39, lane, r[0], r[1], r[2], rho, 128 - 39);
-        nu_ide_write(il1 + 39, lane, r[0], r[1], r[2], 0.0f, 128 - 39);
+        nu_ide_store(il0 + 39, lane, IL, tr, att_rho, 128 - 39);
+        nu_ide_store(il1 + 39, lane, IL, tr, 1.0f, 128 - 39);
 
         float* iw = IWin + (long long)p * 96;
         float* rl = RLin + (long long)p * ld_rl;
@@ -393,41 +410,51 @@ __global__ __launch_bounds__(256) void shade_encode_bwd_kernel(const float* __re
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwave = (gridDim.x * blockDim.x) >> 6;
+    const NuIdeLane IL = nu_ide_lane(lane);
     for (int p = wave; p < P; p += nwave) {
         float n[3], d[3], x[3], nh[3], vh[3], r[3], nov, inorm;
 #pragma unroll
         for (int c = 0; c < 3; ++c) { n[c] = nrm[p * 3LL + c]; d[c] = pt[(long long)p * pt_ld + 4 + c]; x[c] = pt[(long long)p * pt_ld + c]; }
         nu_shade_dirs(n, d, nh, vh, r, nov, inorm);
         const float rho = SD[(long long)p * 8 + 5];
-        float gx, gy, gz, gk;
-        float dnh[3], dr[3] = {0.f, 0.f, 0.f}, drho = 0.f;
+        float dnh[3], dr[3], drho;
         const float* g0 = dOLin + (long long)p * ld_ol;
         const float* g1 = dOLin + (long long)(P + p) * ld_ol;
         const float* g2 = dOLin + (long long)(2LL * P + p) * ld_ol;
-        nu_ide_grad(g0, lane, nh[0], nh[1], nh[2], 1.0f, gx, gy, gz, gk);
-        dnh[0] = gx; dnh[1] = gy; dnh[2] = gz;
-        nu_ide_grad(g1, lane, r[0], r[1], r[2], rho, gx, gy, gz, gk);
-        dr[0] += gx; dr[1] += gy; dr[2] += gz; drho += gk;
-        nu_ide_grad(g2, lane, r[0], r[1], r[2], 0.0f, gx, gy, gz, gk);
-        dr[0] += gx; dr[1] += gy; dr[2] += gz;
+        const float* i0 = dILin + (long long)p * 128 + 39;
+        const float* i1 = dILin + (long long)(P + p) * 128 + 39;
+        const float att_rho = nu_ide_att(IL, rho);
+        const bool lv = IL.live;
+        float ax, ay, az;
+        {   // IDE(n^, 1): one row
+            const NuIdeDir tn = nu_ide_dir(IL, nh[0], nh[1], nh[2]);
+            nu_ide_dir_grad(IL, tn, lv ? g0[lane] * IL.att1 : 0.f, lv ? g0[36 + lane] * IL.att1 : 0.f, ax, ay, az);
+            dnh[0] = nu_wave_sum(ax); dnh[1] = nu_wave_sum(ay); dnh[2] = nu_wave_sum(az);
+        }
+        {   // IDE(r, rho) feeds outer_light row 1 and inner_light row 0; IDE(r, 0) outer row 2 and inner row 1:
+            // one direction evaluation, gradient weights combined per attenuation before the wave reduction
+            const NuIdeDir tr = nu_ide_dir(IL, r[0], r[1], r[2]);
+            const float are_k = lv ? g1[lane] + i0[lane] : 0.f, aim_k = lv ? g1[36 + lane] + i0[36 + lane] : 0.f;
+            const float are_0 = lv ? g2[lane] + i1[lane] : 0.f, aim_0 = lv ? g2[36 + lane] + i1[36 + lane] : 0.f;
+            nu_ide_dir_grad(IL, tr, are_k * att_rho + are_0, aim_k * att_rho + aim_0, ax, ay, az);
+            dr[0] = nu_wave_sum(ax); dr[1] = nu_wave_sum(ay); dr[2] = nu_wave_sum(az);
+            drho = nu_wave_sum(-IL.sigma * att_rho * tr.poly * (are_k * tr.are + aim_k * tr.aim));
+        }
         if (sphere) {
             const NuSph sn = nu_sph_point(x, nh), sr = nu_sph_point(x, r);
             float ds[3];
-            nu_ide_grad(g0 + 72, lane, sn.s[0], sn.s[1], sn.s[2], 1.0f, ds[0], ds[1], ds[2], gk);
+            const NuIdeDir tsn = nu_ide_dir(IL, sn.s[0], sn.s[1], sn.s[2]);
+            nu_ide_dir_grad(IL, tsn, lv ? g0[72 + lane] * IL.att1 : 0.f, lv ? g0[108 + lane] * IL.att1 : 0.f, ax, ay, az);
+            ds[0] = nu_wave_sum(ax); ds[1] = nu_wave_sum(ay); ds[2] = nu_wave_sum(az);
             nu_sph_point_bwd(sn, nh, ds, dnh);
-            float dsr[3], t1[3];
-            nu_ide_grad(g1 + 72, lane, sr.s[0], sr.s[1], sr.s[2], rho, dsr[0], dsr[1], dsr[2], gk);
-            drho += gk;
-            nu_ide_grad(g2 + 72, lane, sr.s[0], sr.s[1], sr.s[2], rho, t1[0], t1[1], t1[2], gk);
-            drho += gk;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) dsr[c] += t1[c];
-            nu_sph_point_bwd(sr, r, dsr, dr);
+            // both specular rows encode the sphere point of r with the point's roughness (field.py:643-646)
+            const NuIdeDir tsr = nu_ide_dir(IL, sr.s[0], sr.s[1], sr.s[2]);
+            const float sre = lv ? g1[72 + lane] + g2[72 + lane] : 0.f, sim = lv ? g1[108 + lane] + g2[108 + lane] : 0.f;
+            nu_ide_dir_grad(IL, tsr, sre * att_rho, sim * att_rho, ax, ay, az);
+            ds[0] = nu_wave_sum(ax); ds[1] = nu_wave_sum(ay); ds[2] = nu_wave_sum(az);
+            drho += nu_wave_sum(-IL.sigma * att_rho * tsr.poly * (sre * tsr.are + sim * tsr.aim));
+            nu_sph_point_bwd(sr, r, ds, dr);
         }
-        nu_ide_grad(dILin + (long long)p * 128 + 39, lane, r[0], r[1], r[2], rho, gx, gy, gz, gk);
-        dr[0] += gx; dr[1] += gy; dr[2] += gz; drho += gk;
-        nu_ide_grad(dILin + (long long)(P + p) * 128 + 39, lane, r[0], r[1], r[2], 0.0f, gx, gy, gz, gk);
-        dr[0] += gx; dr[1] += gy; dr[2] += gz;
         if (lane == 0) {
             // r = 2 NoV n^ - v^ ; NoV = n^ . v^
             const float dnov = dNoV[p] + 2.0f * (dr[0] * nh[0] + dr[1] * nh[1] + dr[2] * nh[2]);
@@ -461,16 +488,18 @@ __global__ __launch_bounds__(256) void spec_encode_kernel(const float* __restric
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwave = (gridDim.x * blockDim.x) >> 6;
+    const NuIdeLane IL = nu_ide_lane(lane);
     for (int r = wave; r < R; r += nwave) {
         const float d[3] = {dirs[r * 3LL], dirs[r * 3LL + 1], dirs[r * 3LL + 2]};
         float* row = out + (long long)r * ldo;
+        const NuIdeDir td = nu_ide_dir(IL, d[0], d[1], d[2]);
         if (sphere) {
             const float xx[3] = {x[r * 3LL], x[r * 3LL + 1], x[r * 3LL + 2]};
             const NuSph s = nu_sph_point(xx, d);
-            nu_ide_write(row, lane, d[0], d[1], d[2], 0.0f, 72);
-            nu_ide_write(row + 72, lane, s.s[0], s.s[1], s.s[2], 0.0f, ldo - 72);
+            nu_ide_store(row, lane, IL, td, 1.0f, 72);
+            nu_ide_store(row + 72, lane, IL, nu_ide_dir(IL, s.s[0], s.s[1], s.s[2]), 1.0f, ldo - 72);
         } else {
-            nu_ide_write(row, lane, d[0], d[1], d[2], 0.0f, ldo);
+            nu_ide_store(row, lane, IL, td, 1.0f, ldo);
         }
     }
 }

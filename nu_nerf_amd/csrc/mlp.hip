@@ -93,32 +93,62 @@ extern "C" int nu_reduce_desc_size() { return (int)sizeof(NuReduceDesc); }
 // ------------------------------------------------------------------------------------------------
 // skinny heads: out[p, j] = sum_k H[p, k] * Ws[j, k] + b[j],  j < NO <= 8.   HBM-bound (reads H once).
 // ------------------------------------------------------------------------------------------------
-template <int NO>
-__global__ __launch_bounds__(256) void skinny_fwd_kernel(const float* __restrict__ H, int ldh, int P, int K,
+// One wave per row (K = 128: two rows per wave), head weights held in registers, two rows in flight per wave.
+template <int NO, int K>
+__global__ __launch_bounds__(256) void skinny_fwd_kernel(const float* __restrict__ H, int ldh, int P,
                                                          const float* __restrict__ Ws, int ldw,
                                                          const float* __restrict__ b, float* __restrict__ out, int ldo) {
+    constexpr int KQ = K >= 256 ? K / 256 : 1;
+    constexpr int RPW = K >= 256 ? 1 : 2;
+    constexpr int LPR = 64 / RPW;
     const int lane = threadIdx.x & 63;
+    const int sub = lane / LPR, ln = lane % LPR;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwave = (gridDim.x * blockDim.x) >> 6;
-    const int nchunk = K >> 2;  // float4 chunks per row
-    for (int p = wave; p < P; p += nwave) {
+    f32x4 w[NO][KQ];
+    float bj[NO];
+#pragma unroll
+    for (int j = 0; j < NO; ++j) {
+        bj[j] = b ? b[j] : 0.f;
+#pragma unroll
+        for (int t = 0; t < KQ; ++t) w[j][t] = *reinterpret_cast<const f32x4*>(Ws + (long long)j * ldw + 4 * ln + 256 * t);
+    }
+    // the row arithmetic is inlined three times (two rows in flight + tail): contraction off, so that a row's result does
+    // not depend on which copy ran it (ray-independence is tested bit-exactly)
+    auto finish = [&](int p, const f32x4* h) {
+#pragma clang fp contract(off)
         float acc[NO];
 #pragma unroll
-        for (int j = 0; j < NO; ++j) acc[j] = 0.f;
-        for (int c = lane; c < nchunk; c += 64) {
-            const f32x4 h = *reinterpret_cast<const f32x4*>(H + (long long)p * ldh + 4 * c);
+        for (int j = 0; j < NO; ++j) {
+            float a = 0.f;
 #pragma unroll
-            for (int j = 0; j < NO; ++j) {
-                const f32x4 w = *reinterpret_cast<const f32x4*>(Ws + (long long)j * ldw + 4 * c);
-                acc[j] += h[0] * w[0] + h[1] * w[1] + h[2] * w[2] + h[3] * w[3];
-            }
+            for (int t = 0; t < KQ; ++t) a += (h[t][0] * w[j][t][0] + h[t][1] * w[j][t][1]) + (h[t][2] * w[j][t][2] + h[t][3] * w[j][t][3]);
+#pragma unroll
+            for (int o = LPR / 2; o > 0; o >>= 1) a += __shfl_xor(a, o);
+            acc[j] = a;
         }
+        if (ln == 0) {
 #pragma unroll
-        for (int j = 0; j < NO; ++j) acc[j] = nu_wave_sum(acc[j]);
-        if (lane == 0) {
-#pragma unroll
-            for (int j = 0; j < NO; ++j) out[(long long)p * ldo + j] = acc[j] + (b ? b[j] : 0.f);
+            for (int j = 0; j < NO; ++j) out[(long long)p * ldo + j] = acc[j] + bj[j];
         }
+    };
+    const int step = nwave * RPW;
+    int p = wave * RPW + sub;
+    for (; p + step < P; p += 2 * step) {
+        f32x4 ha[KQ], hb[KQ];
+#pragma unroll
+        for (int t = 0; t < KQ; ++t) {
+            ha[t] = *reinterpret_cast<const f32x4*>(H + (long long)p * ldh + 4 * ln + 256 * t);
+            hb[t] = *reinterpret_cast<const f32x4*>(H + (long long)(p + step) * ldh + 4 * ln + 256 * t);
+        }
+        finish(p, ha);
+        finish(p + step, hb);
+    }
+    if (p < P) {
+        f32x4 ha[KQ];
+#pragma unroll
+        for (int t = 0; t < KQ; ++t) ha[t] = *reinterpret_cast<const f32x4*>(H + (long long)p * ldh + 4 * ln + 256 * t);
+        finish(p, ha);
     }
 }
 
@@ -126,44 +156,57 @@ extern "C" int nu_skinny_fwd(const float* H, int ldh, int P, int K, const float*
                              float* out, int ldo, hipStream_t stream) {
     if (P <= 0) return NU_OK;
     if ((K & 3) || (ldh & 3) || (ldw & 3)) return NU_ERR_ARG;
-    const int blocks = nu_cdiv(P, 4) < 4096 ? nu_cdiv(P, 4) : 4096;
+    const int blocks = nu_cdiv(P, 8) < 2048 ? nu_cdiv(P, 8) : 2048;
     dim3 grid(blocks), block(256);
-    switch (NO) {
-#define NU_CASE(n) case n: hipLaunchKernelGGL(skinny_fwd_kernel<n>, grid, block, 0, stream, H, ldh, P, K, Ws, ldw, b, out, ldo); break;
-        NU_CASE(1) NU_CASE(2) NU_CASE(3) NU_CASE(4) NU_CASE(6)
+#define NU_CASE(n, k) if (NO == n && K == k) { hipLaunchKernelGGL((skinny_fwd_kernel<n, k>), grid, block, 0, stream, H, ldh, P, Ws, ldw, b, out, ldo); return nu_launch_status(); }
+    NU_CASE(1, 128) NU_CASE(2, 128) NU_CASE(3, 128) NU_CASE(4, 128)
+    NU_CASE(1, 256) NU_CASE(2, 256) NU_CASE(3, 256) NU_CASE(4, 256)
+    NU_CASE(6, 1024)
 #undef NU_CASE
-        default: return NU_ERR_ARG;
-    }
-    return nu_launch_status();
+    return NU_ERR_ARG;
 }
 
 // backward of a skinny head (feeding a ReLU hidden layer):
 //   dH[p,k]   = (sum_j dy[p,j] Ws[j,k]) * (relu_mask ? H[p,k] > 0 : 1)      (written, or added to dH if accumulate)
 //   dWs[j,k]  = sum_p dy[p,j] H[p,k]      (per-block partial -> slab[blk][j][k])
 //   db[j]     = sum_p dy[p,j]             (per-block partial -> bslab[blk][j])
-template <int NO, int KT>  // KT = K / 256 columns per thread
+// One wave per row of a K-column slice (K = 256: 16 B per lane; K = 128: two rows per wave, 32 lanes each; a wider head
+// is cut into 256-column slices along grid.y -- dH and dWs are column-local), four waves per block on interleaved
+// rows, two rows in flight per wave; the four waves' weight-gradient partials are summed through LDS in a fixed order
+// before the block writes its slab.
+template <int NO, int K>
 __global__ __launch_bounds__(256) void skinny_bwd_kernel(const float* __restrict__ dy, int ldy,
                                                          const float* __restrict__ H, int ldh, int P,
                                                          const float* __restrict__ Ws, int ldw, float* __restrict__ dH,
                                                          int lddh, int relu_mask, int accumulate,
-                                                         float* __restrict__ slab, float* __restrict__ bslab) {
-    const int tid = threadIdx.x;
-    const int K = KT * 256;
+                                                         float* __restrict__ slab, float* __restrict__ bslab, int Ktot) {
+    constexpr int KQ = 1;                               // float4 chunks per lane
+    constexpr int RPW = K >= 256 ? 1 : 2;               // rows per wave per pass
+    const int cb = blockIdx.y * K;                      // first column of this block's slice
+    H += cb; Ws += cb; dH += cb;
+    constexpr int LPR = 64 / RPW;                       // lanes per row
+    __shared__ float red[4 * K];
+    __shared__ float bred[4][8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int sub = lane / LPR, ln = lane % LPR;
     int rows_per = (P + gridDim.x - 1) / gridDim.x;
     const int p0 = blockIdx.x * rows_per;
     int p1 = p0 + rows_per;
     p1 = p1 < P ? p1 : P;
-    float w[NO][KT], acc[NO][KT], bacc[NO];
+    f32x4 w[NO][KQ], acc[NO][KQ];
+    float bacc[NO];
 #pragma unroll
     for (int j = 0; j < NO; ++j) {
         bacc[j] = 0.f;
 #pragma unroll
-        for (int t = 0; t < KT; ++t) {
-            w[j][t] = Ws[(long long)j * ldw + tid + 256 * t];
-            acc[j][t] = 0.f;
+        for (int t = 0; t < KQ; ++t) {
+            w[j][t] = *reinterpret_cast<const f32x4*>(Ws + (long long)j * ldw + 4 * ln + 256 * t);
+            acc[j][t] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
-    for (int p = p0; p < p1; ++p) {
+    constexpr int STEP = 4 * RPW;                       // rows the block advances per pass
+    auto row_body = [&](int p, const f32x4* h) {
+#pragma clang fp contract(off)      // inlined three times: same rounding in every copy
         float g[NO];
 #pragma unroll
         for (int j = 0; j < NO; ++j) {
@@ -171,67 +214,68 @@ __global__ __launch_bounds__(256) void skinny_bwd_kernel(const float* __restrict
             bacc[j] += g[j];
         }
 #pragma unroll
-        for (int t = 0; t < KT; ++t) {
-            const long long o = (long long)p * ldh + tid + 256 * t;
-            const float h = H[o];
-            float d = 0.f;
+        for (int t = 0; t < KQ; ++t) {
+            f32x4 d = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int j = 0; j < NO; ++j) {
                 d += g[j] * w[j][t];
-                acc[j][t] += g[j] * h;
+                acc[j][t] += g[j] * h[t];
             }
-            if (relu_mask && !(h > 0.f)) d = 0.f;
-            const long long od = (long long)p * lddh + tid + 256 * t;
-            dH[od] = accumulate ? dH[od] + d : d;
+            if (relu_mask) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) d[e] = h[t][e] > 0.f ? d[e] : 0.f;
+            }
+            float* q = dH + (long long)p * lddh + 4 * ln + 256 * t;
+            if (accumulate) d += *reinterpret_cast<const f32x4*>(q);
+            *reinterpret_cast<f32x4*>(q) = d;
         }
+    };
+    int p = p0 + wave * RPW + sub;
+    for (; p + STEP < p1; p += 2 * STEP) {              // two rows in flight
+        f32x4 ha[KQ], hb[KQ];
+#pragma unroll
+        for (int t = 0; t < KQ; ++t) {
+            ha[t] = *reinterpret_cast<const f32x4*>(H + (long long)p * ldh + 4 * ln + 256 * t);
+            hb[t] = *reinterpret_cast<const f32x4*>(H + (long long)(p + STEP) * ldh + 4 * ln + 256 * t);
+        }
+        row_body(p, ha);
+        row_body(p + STEP, hb);
     }
+    for (; p < p1; p += STEP) {
+        f32x4 ha[KQ];
+#pragma unroll
+        for (int t = 0; t < KQ; ++t) ha[t] = *reinterpret_cast<const f32x4*>(H + (long long)p * ldh + 4 * ln + 256 * t);
+        row_body(p, ha);
+    }
+    // block reduction, one output row j at a time: red[wave][k] (for K = 128 the two half-waves add first)
 #pragma unroll
     for (int j = 0; j < NO; ++j) {
 #pragma unroll
-        for (int t = 0; t < KT; ++t) slab[((long long)blockIdx.x * NO + j) * K + tid + 256 * t] = acc[j][t];
-    }
-    if (tid == 0) {
+        for (int t = 0; t < KQ; ++t) {
+            f32x4 v = acc[j][t];
+            if (RPW == 2) {
 #pragma unroll
-        for (int j = 0; j < NO; ++j) bslab[(long long)blockIdx.x * NO + j] = bacc[j];
+                for (int e = 0; e < 4; ++e) v[e] += __shfl_xor(v[e], 32);
+            }
+            if (sub == 0) *reinterpret_cast<f32x4*>(&red[wave * K + 4 * ln + 256 * t]) = v;
+        }
+        __syncthreads();
+        for (int k = tid; k < K; k += 256)
+            slab[((long long)blockIdx.x * NO + j) * Ktot + cb + k] = (red[k] + red[K + k]) + (red[2 * K + k] + red[3 * K + k]);
+        __syncthreads();
     }
-}
-
-// K == 128 variant handled by KT=1 with 128 active columns is not needed: heads in this model have K in {128,256,1024};
-// K=128 uses a dedicated instantiation with half the block idle.
-template <int NO>
-__global__ __launch_bounds__(128) void skinny_bwd128_kernel(const float* __restrict__ dy, int ldy,
-                                                            const float* __restrict__ H, int ldh, int P,
-                                                            const float* __restrict__ Ws, int ldw, float* __restrict__ dH,
-                                                            int lddh, int relu_mask, int accumulate,
-                                                            float* __restrict__ slab, float* __restrict__ bslab) {
-    const int tid = threadIdx.x;
-    int rows_per = (P + gridDim.x - 1) / gridDim.x;
-    const int p0 = blockIdx.x * rows_per;
-    int p1 = p0 + rows_per;
-    p1 = p1 < P ? p1 : P;
-    float w[NO], acc[NO], bacc[NO];
-#pragma unroll
-    for (int j = 0; j < NO; ++j) { w[j] = Ws[(long long)j * ldw + tid]; acc[j] = 0.f; bacc[j] = 0.f; }
-    for (int p = p0; p < p1; ++p) {
-        const float h = H[(long long)p * ldh + tid];
-        float d = 0.f;
+    // bias partials: every lane of a (half-)wave holds the same sum over its rows
+    if (ln == 0) {
 #pragma unroll
         for (int j = 0; j < NO; ++j) {
-            const float g = dy[(long long)p * ldy + j];
-            bacc[j] += g;
-            d += g * w[j];
-            acc[j] += g * h;
+            float v = bacc[j];
+            if (RPW == 2) v += __shfl_xor(v, 32);
+            if (sub == 0) bred[wave][j] = v;
         }
-        if (relu_mask && !(h > 0.f)) d = 0.f;
-        const long long od = (long long)p * lddh + tid;
-        dH[od] = accumulate ? dH[od] + d : d;
     }
-#pragma unroll
-    for (int j = 0; j < NO; ++j) slab[((long long)blockIdx.x * NO + j) * 128 + tid] = acc[j];
-    if (tid == 0) {
-#pragma unroll
-        for (int j = 0; j < NO; ++j) bslab[(long long)blockIdx.x * NO + j] = bacc[j];
-    }
+    __syncthreads();
+    if (tid < NO && blockIdx.y == 0)
+        bslab[(long long)blockIdx.x * NO + tid] = (bred[0][tid] + bred[1][tid]) + (bred[2][tid] + bred[3][tid]);
 }
 
 #define NU_SKINNY_BLOCKS 1024
@@ -250,22 +294,23 @@ extern "C" int nu_skinny_bwd_enqueue(const float* dy, int ldy, const float* H, i
     blocks = blocks < NU_SKINNY_BLOCKS ? blocks : NU_SKINNY_BLOCKS;
     float* slab = (float*)workspace;
     float* bslab = slab + (long long)NU_SKINNY_BLOCKS * NO * K;
-#define NU_ARGS dy, ldy, H, ldh, P, Ws, ldw, dH, lddh, relu_mask, accumulate, slab, bslab
+#define NU_ARGS dy, ldy, H, ldh, P, Ws, ldw, dH, lddh, relu_mask, accumulate, slab, bslab, K
+    if ((ldh & 3) || (lddh & 3) || (ldw & 3)) return NU_ERR_ARG;
     if (K == 128) {
         switch (NO) {
-            case 1: hipLaunchKernelGGL(skinny_bwd128_kernel<1>, dim3(blocks), dim3(128), 0, stream, NU_ARGS); break;
-            case 3: hipLaunchKernelGGL(skinny_bwd128_kernel<3>, dim3(blocks), dim3(128), 0, stream, NU_ARGS); break;
+            case 1: hipLaunchKernelGGL((skinny_bwd_kernel<1, 128>), dim3(blocks), dim3(256), 0, stream, NU_ARGS); break;
+            case 3: hipLaunchKernelGGL((skinny_bwd_kernel<3, 128>), dim3(blocks), dim3(256), 0, stream, NU_ARGS); break;
             default: return NU_ERR_ARG;
         }
     } else if (K == 256) {
         switch (NO) {
-            case 1: hipLaunchKernelGGL((skinny_bwd_kernel<1, 1>), dim3(blocks), dim3(256), 0, stream, NU_ARGS); break;
-            case 3: hipLaunchKernelGGL((skinny_bwd_kernel<3, 1>), dim3(blocks), dim3(256), 0, stream, NU_ARGS); break;
+            case 1: hipLaunchKernelGGL((skinny_bwd_kernel<1, 256>), dim3(blocks), dim3(256), 0, stream, NU_ARGS); break;
+            case 3: hipLaunchKernelGGL((skinny_bwd_kernel<3, 256>), dim3(blocks), dim3(256), 0, stream, NU_ARGS); break;
             default: return NU_ERR_ARG;
         }
     } else if (K == 1024) {
         switch (NO) {
-            case 6: hipLaunchKernelGGL((skinny_bwd_kernel<6, 4>), dim3(blocks), dim3(256), 0, stream, NU_ARGS); break;
+            case 6: hipLaunchKernelGGL((skinny_bwd_kernel<6, 256>), dim3(blocks, 4), dim3(256), 0, stream, NU_ARGS); break;
             default: return NU_ERR_ARG;
         }
     } else {
