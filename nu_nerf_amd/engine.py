@@ -148,7 +148,7 @@ class Stage1Engine:
             self.flush_reductions()                   # stream order: later producers may then reuse the space
             if self._arena is None or n > self._arena.numel():
                 self._arena = None
-                self._arena = torch.empty(max(n, 1 << 28), dtype=torch.float32, device=self.dev)   # >= 1 GiB
+                self._arena = torch.empty(max(n, 1 << 29), dtype=torch.float32, device=self.dev)   # >= 2 GiB: one step's slabs
         off = self._arena_off
         self._arena_off += n
         return self._arena.data_ptr() + 4 * off, n * 4
