@@ -119,6 +119,7 @@ def main():
     from nu_nerf_amd.synthetic import make_rays
     from nu_nerf_amd.loss import name2loss, SPHEREPOT_LOSSES, total_loss
     from nu_nerf_amd.parallel import GradAllReducer
+    from nu_nerf_amd.train_glue import FusedAdam
 
     R = args.rays
     cfg = build_cfg(R, args.real_capture, args.mlp_dtype)
@@ -127,7 +128,8 @@ def main():
     net.load_param_dict(init_stage1_params(6033, sphere_direction=args.real_capture))       # identical replica on every rank
     net = net.to(dev)
     losses = [name2loss[n](cfg) for n in SPHEREPOT_LOSSES]
-    opt = torch.optim.Adam(net.parameters(), lr=1e-3, fused=os.environ.get('NU_BENCH_FUSED_ADAM', '1') == '1')
+    # Adam: the HIP multi-tensor kernel (nu_nerf_amd/train_glue.py; checked against torch.optim.Adam in tests/test_train_glue_gpu.py)
+    opt = FusedAdam(net.parameters(), lr=1e-3) if os.environ.get('NU_BENCH_ADAM', 'hip') == 'hip' else torch.optim.Adam(net.parameters(), lr=1e-3, fused=True)
     reducer = GradAllReducer(net, world) if world > 1 else None
 
     # device-resident ray pool; every rank draws a disjoint slice of the same seeded permutation

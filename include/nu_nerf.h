@@ -247,6 +247,21 @@ int nu_lbvh_trace(const void* bvh, int n_faces, const float* rays, int N, float 
 int nu_brute_trace(const float* V, const int* F, int n_faces, const float* rays, int N, float tmin, float tmax,
                    float* hit, int* idx, float* t_out, hipStream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * Trainer glue: torch.optim.Adam's update (train/trainer_zero.py:74-85, lr from
+ * train/lr_common_manager.py:22-46) over many parameter tensors in one launch per NU_ADAM_MAX tensors.
+ * p, g, m (exp_avg), v (exp_avg_sq): contiguous fp32 of n elements; step >= 1 is the count AFTER this update.
+ * --------------------------------------------------------------------------------------------------------- */
+#define NU_ADAM_MAX 80
+typedef struct NuAdamDesc {
+    float* p; const float* g; float* m; float* v;
+    long long n;
+    int blk_begin, pad_;                      /* filled by the library */
+} NuAdamDesc;
+int nu_adam_desc_size(void);
+int nu_adam_step(const NuAdamDesc* descs_host, int n, double lr, double beta1, double beta2, double eps, int step,
+                 hipStream_t stream);   /* hyper-parameters in double: 1 - beta and the bias corrections are formed as torch forms them */
+
 #ifdef __cplusplus
 }
 #endif

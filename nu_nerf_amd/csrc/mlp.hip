@@ -406,3 +406,67 @@ extern "C" int nu_rowscale_dsp(const float* H, int ldh, int P, int K, const floa
     hipLaunchKernelGGL(rowscale_dsp_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, H, ldh, (long long)P, K, w, D, ldd);
     return nu_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------
+// Fused Adam over many parameter tensors (train/trainer_zero.py:74-85 builds torch.optim.Adam; the update below is its
+// single-tensor formula: exp_avg.lerp_(g, 1-b1); exp_avg_sq = b2*v + (1-b2) g^2; p -= step_size * m / (sqrt(v)/sqrt(bc2) + eps)).
+// Descriptors travel in the kernel-argument block (no host -> device copy), NU_ADAM_MAX tensors per launch.
+// ------------------------------------------------------------------------------------------------
+struct NuAdamBatch {
+    NuAdamDesc d[NU_ADAM_MAX];
+    int n;
+    float lr_over_bc1, inv_sqrt_bc2, w1, beta2, w2, eps;   // w = 1 - beta, formed in double on the host like torch does
+};
+#define NU_ADAM_ELEMS 2048   // elements per block
+__global__ __launch_bounds__(256) void adam_kernel(NuAdamBatch b) {
+    int di = 0;
+    for (int i = 1; i < b.n; ++i) di = ((int)blockIdx.x >= b.d[i].blk_begin) ? i : di;
+    float* __restrict__ p = b.d[di].p;
+    const float* __restrict__ g = b.d[di].g;
+    float* __restrict__ m = b.d[di].m;
+    float* __restrict__ v = b.d[di].v;
+    const long long n = b.d[di].n;
+    const long long base = (long long)((int)blockIdx.x - b.d[di].blk_begin) * NU_ADAM_ELEMS;
+    const float w1 = b.w1, w2 = b.w2;
+#pragma unroll
+    for (int u = 0; u < NU_ADAM_ELEMS / 256; ++u) {
+        const long long i = base + u * 256 + threadIdx.x;
+        if (i >= n) break;
+        const float gi = g[i];
+        float mi = m[i], vi = v[i];
+        mi = mi + (gi - mi) * w1;
+        vi = vi * b.beta2 + (gi * gi) * w2;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) * b.inv_sqrt_bc2 + b.eps;
+        p[i] = p[i] - b.lr_over_bc1 * (mi / denom);
+    }
+}
+extern "C" int nu_adam_desc_size(void) { return (int)sizeof(NuAdamDesc); }
+extern "C" int nu_adam_step(const NuAdamDesc* descs, int n, double lr, double beta1_d, double beta2_d, double eps_d, int step,
+                            hipStream_t stream) {
+    if (n < 0 || step < 1) return NU_ERR_ARG;
+    const float beta2 = (float)beta2_d, eps = (float)eps_d;
+    const double bc1 = 1.0 - pow(beta1_d, (double)step), bc2 = 1.0 - pow(beta2_d, (double)step);
+    int i = 0;
+    while (i < n) {
+        NuAdamBatch b;
+        int blocks = 0, k = 0;
+        for (; i < n && k < NU_ADAM_MAX; ++i) {
+            if (descs[i].n <= 0) continue;
+            b.d[k] = descs[i];
+            b.d[k].blk_begin = blocks;
+            blocks += (int)nu_cdivl(descs[i].n, NU_ADAM_ELEMS);
+            ++k;
+        }
+        if (k == 0) break;
+        b.n = k;
+        b.lr_over_bc1 = (float)(lr / bc1);
+        b.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+        b.w1 = (float)(1.0 - (double)beta1_d); b.beta2 = beta2; b.w2 = (float)(1.0 - (double)beta2_d); b.eps = eps;
+        hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, stream, b);
+        const int rc = nu_launch_status();
+        if (rc) return rc;
+    }
+    return NU_OK;
+}

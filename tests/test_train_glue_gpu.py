@@ -1,0 +1,83 @@
+"""FusedAdam (csrc/mlp.hip: adam_kernel) against torch.optim.Adam: same update over several steps, ragged tensor sizes,
+parameters without gradients, resume from torch's optimizer state."""
+import copy
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _params(gpu, seed):
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    shapes = [(1,), (257,), (3, 5), (2048,), (2049,), (256, 256), (6151,), ()]
+    return [torch.nn.Parameter(torch.randn(s, generator=g).to(gpu)) for s in shapes]
+
+
+def test_fused_adam_matches_torch_adam(gpu):
+    from nu_nerf_amd.train_glue import FusedAdam
+    pa, pb = _params(gpu, 1), _params(gpu, 1)
+    extra_a, extra_b = torch.nn.Parameter(torch.ones(4, device=gpu)), torch.nn.Parameter(torch.ones(4, device=gpu))
+    oa = torch.optim.Adam(pa + [extra_a], lr=3e-3, betas=(0.9, 0.999), eps=1e-8)
+    ob = FusedAdam(pb + [extra_b], lr=3e-3, betas=(0.9, 0.999), eps=1e-8)
+    g = torch.Generator(device='cpu').manual_seed(2)
+    for it in range(6):
+        for x, y in zip(pa, pb):
+            gr = (torch.randn(x.shape, generator=g) * (10.0 if it == 3 else 1.0)).to(gpu)
+            x.grad, y.grad = gr.clone(), gr.clone()
+        for o in (oa, ob):
+            for grp in o.param_groups:
+                grp['lr'] = 3e-3 * (it + 1) / 6              # the lr manager changes it every step
+        oa.step(); ob.step()
+        for x, y in zip(pa, pb):
+            torch.testing.assert_close(y, x, rtol=2e-6, atol=1e-7)
+    assert torch.equal(extra_b, torch.ones(4, device=gpu))      # no gradient: untouched, like torch's Adam
+    sa, sb = oa.state[pa[5]], ob.state[pb[5]]
+    # moments of O(1) gradients: one fp32 rounding of difference (fused multiply-add here, lerp_ / addcmul_ in torch)
+    torch.testing.assert_close(sb['exp_avg'], sa['exp_avg'], rtol=1e-6, atol=3e-7)
+    torch.testing.assert_close(sb['exp_avg_sq'], sa['exp_avg_sq'], rtol=2e-6, atol=1e-9)
+    assert int(sb['step']) == int(sa['step']) == 6
+
+
+def test_fused_adam_resumes_from_torch_adam_state(gpu):
+    from nu_nerf_amd.train_glue import FusedAdam
+    pa, pb = _params(gpu, 3), _params(gpu, 3)
+    oa = torch.optim.Adam(pa, lr=1e-3)
+    for x in pa:
+        x.grad = torch.ones_like(x)
+    oa.step()
+    ob = FusedAdam(pb, lr=1e-3)
+    with torch.no_grad():
+        for x, y in zip(pa, pb):
+            y.copy_(x)
+    ob.load_state_dict(copy.deepcopy(oa.state_dict()))      # as after a checkpoint file (state_dict() aliases the live tensors)
+    for x, y in zip(pa, pb):
+        x.grad = torch.full_like(x, 0.5)
+        y.grad = torch.full_like(y, 0.5)
+    oa.step(); ob.step()
+    for x, y in zip(pa, pb):
+        torch.testing.assert_close(y, x, rtol=2e-6, atol=1e-7)
+
+
+def test_train_step_glue_runs_the_reference_loop_body(gpu):
+    from nu_nerf_amd.renderer import NeROShapeRenderer
+    from nu_nerf_amd.params import init_stage1_params
+    from nu_nerf_amd.synthetic import make_rays
+    from nu_nerf_amd.loss import name2loss, SPHEREPOT_LOSSES
+    from nu_nerf_amd.train_glue import FusedAdam, WarmUpCosLR, train_step
+    cfg = {'name': 't', 'network': 'shape', 'database_name': 'synthetic/64', 'is_nerf': True, 'apply_occ_loss': True,
+           'occ_loss_step': 15000, 'freeze_inv_s_step': 15000, 'n_samples': 16, 'n_importance': 16, 'n_bg_samples': 8}
+    net = NeROShapeRenderer(cfg, training=False)
+    net.load_param_dict(init_stage1_params(6033))
+    net = net.to(gpu)
+    mgr = WarmUpCosLR({})
+    opt = mgr.construct_optimizer(FusedAdam, net)
+    losses = [name2loss[n](cfg) for n in SPHEREPOT_LOSSES]
+    batch = {k: torch.from_numpy(v).to(gpu) for k, v in make_rays(64, seed=5).items() if k != 'idxs'}
+    w0 = net.sdf_network.lin2.weight_v.detach().clone()
+    t0, _, lr0 = train_step(net, opt, mgr, losses, 6000, batch)
+    t1, log, lr1 = train_step(net, opt, mgr, losses, 6001, batch)
+    assert lr0 == pytest.approx(5e-4 * mgr.factor(6000)) and lr1 < lr0
+    assert bool(torch.isfinite(t0)) and bool(torch.isfinite(t1)) and 'loss_rgb' in ''.join(log.keys())
+    assert float((net.sdf_network.lin2.weight_v - w0).abs().max()) > 0
+    assert net.color_network.iors[0].weight_v.grad is None          # dead parameters stay untouched
