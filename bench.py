@@ -151,6 +151,8 @@ def main():
             g['lr'] = lr
         opt.zero_grad(set_to_none=True)
         out = net.train_step_rays(batch_for(it), step)
+        if reducer is not None:     # eikonal mean over the union of all ranks' inner points (exact data parallelism)
+            out['gradient_error'] = out['gradient_error'] * reducer.point_weight(eng.last_ctx['P_in'], dev)
         total, _ = total_loss(out, losses, step)
         total.backward()
         if reducer is not None:
@@ -205,6 +207,9 @@ def main():
             "config": {"workload": workload,
                        "rays_per_gpu": R, "global_rays": R * world, "samples_per_ray": 160, "start_step": args.start_step,
                        "parallelism": "dp%d" % world,
+                       "grad_all_reduce": None if reducer is None else
+                       ("in place on the flat gradient buffer" if reducer.gathered_calls == 0 else
+                        "gathered (%d of %d steps)" % (reducer.gathered_calls, reducer.gathered_calls + reducer.in_place_calls)),
                        "mean_inner_points": stats['P_in'] / args.steps, "mean_outer_points": stats['P_out'] / args.steps,
                        "final_loss": float(last.detach())},
         }

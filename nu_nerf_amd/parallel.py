@@ -7,9 +7,9 @@ renders its own slice of the ray batch; only the ~2.55 M parameter gradients (10
 world size.  Parameters that never receive a gradient in stage 1 (color_network.iors.*, infinity_far_bkgr.*) are left
 out of the bucket instead of relying on unused-parameter detection.
 
-Approximation inherited from per-rank means (documented in DESIGN.md): per-point means (eikonal) are averaged per
-rank before the all-reduce, so ranks with different inner-point counts weigh points slightly differently from a
-single-process run over the union batch.
+Per-ray loss terms average exactly (equal ray counts per rank).  Per-point means (eikonal over the inner points) are
+taken per rank; `GradAllReducer.point_weight` gives the count ratio that makes them exact as well (one scalar
+all-reduce, no host sync) -- bench.py applies it to `gradient_error`.
 """
 import torch
 import torch.distributed as dist
@@ -28,34 +28,66 @@ class GradAllReducer:
         named = dict(module.named_parameters())
         self.params = [named[n] for n in stage1_trainable_names(module)]
         self.numel = sum(p.numel() for p in self.params)
-        self._flat = None
+        self.in_place_calls = 0      # how often the zero-copy path ran (reported by bench.py)
+        self.gathered_calls = 0
+
+    def _shared_flat(self):
+        """The renderer's backward hands out every gradient as a slice of ONE flat buffer (engine.grad_views order) and
+        autograd keeps those slices (it detaches, it does not copy): when the .grad tensors tile one storage range exactly,
+        the collective runs on that range in place -- no gather, no scatter."""
+        g0 = self.params[0].grad
+        if g0 is None:
+            return None
+        store = g0.untyped_storage()
+        sp = store.data_ptr()
+        lo, hi, tot = None, None, 0
+        for p in self.params:
+            g = p.grad
+            if g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.untyped_storage().data_ptr() != sp:
+                return None
+            o, n = g.storage_offset(), g.numel()
+            lo = o if lo is None else min(lo, o)
+            hi = o + n if hi is None else max(hi, o + n)
+            tot += n
+        if tot != self.numel or hi - lo != self.numel:      # gaps or overlaps: not one clean range
+            return None
+        return torch.empty(0, dtype=torch.float32, device=g0.device).set_(store, lo, (self.numel,), (1,))
 
     def all_reduce(self):
-        """Sum the gradients over ranks and divide by the world size (in place on every .grad)."""
+        """Sum the gradients over ranks and divide by the world size (in place on every .grad): one collective."""
         if self.world <= 1:
             return
-        dev = self.params[0].device
-        if self._flat is None or self._flat.device != dev:
-            self._flat = torch.zeros(self.numel, device=dev)
-        flat = self._flat
-        off = 0
+        flat = self._shared_flat()
+        if flat is not None:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            flat.div_(self.world)
+            self.in_place_calls += 1
+            return
+        self.gathered_calls += 1
+        # general case (gradients from other sources, or missing): one gather, one collective, one multi-tensor scatter
         for p in self.params:
-            n = p.numel()
-            if p.grad is not None:
-                flat[off:off + n].copy_(p.grad.reshape(-1))
-            else:
-                flat[off:off + n].zero_()
-            off += n
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+        grads = [p.grad for p in self.params]
+        flat = torch.cat([g.reshape(-1) for g in grads])
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
         flat.div_(self.world)
-        off = 0
-        for p in self.params:
-            n = p.numel()
-            if p.grad is None:
-                p.grad = flat[off:off + n].view_as(p).clone()
-            else:
-                p.grad.copy_(flat[off:off + n].view_as(p))
-            off += n
+        views, off = [], 0
+        for g in grads:
+            views.append(flat[off:off + g.numel()].view_as(g))
+            off += g.numel()
+        torch._foreach_copy_(grads, views)
+
+    def point_weight(self, n_local, device):
+        """Factor that turns a per-rank mean over n_local points into this rank's share of the mean over the union batch:
+        n_local * world / sum_r n_r (a device scalar; no host sync).  Multiply a per-point loss input by it (e.g.
+        outputs['gradient_error']) and the all-reduced gradient equals the single-process gradient over all ranks' rays."""
+        n = torch.tensor([float(n_local)], device=device)
+        if self.world <= 1:
+            return torch.ones(1, device=device)
+        tot = n.clone()
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=self.group)
+        return n * self.world / torch.clamp(tot, min=1.0)
 
 
 def shard_rays(batch, rank, world):

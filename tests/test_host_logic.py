@@ -128,6 +128,27 @@ def _dp_worker(rank, world, port, q):
     for i, n in enumerate(names):
         expect = 0.0 if i % 7 == 3 else 1.5 * (1 + (i % 5))
         ok &= bool(torch.allclose(named[n].grad, torch.full_like(named[n], expect)))
+    # the renderer's layout: every gradient a view of one flat buffer -> reduced in place, no copies
+    flat = torch.full((red.numel,), float(rank + 1))
+    off = 0
+    for n in names:
+        k = named[n].numel()
+        named[n].grad = flat[off:off + k].view_as(named[n]).detach()     # what autograd stores: same storage, no view link
+        off += k
+    sf = red._shared_flat()
+    ok &= sf is not None and sf.data_ptr() == flat.data_ptr() and sf.numel() == flat.numel()
+    before = red.in_place_calls
+    red.all_reduce()
+    ok &= bool(torch.all(flat == 1.5)) and red.in_place_calls == before + 1
+    ok &= float(named[names[5]].grad.flatten()[0]) == 1.5
+    # per-point means: ranks with 10 and 30 inner points weigh 0.5 and 1.5, so the averaged per-rank means equal the
+    # mean over all 40 points
+    w = red.point_weight(10 if rank == 0 else 30, torch.device('cpu'))
+    ok &= abs(float(w) - (0.5 if rank == 0 else 1.5)) < 1e-6
+    vals = torch.arange(10.) if rank == 0 else 10.0 + torch.arange(30.)
+    share = torch.mean(vals * w).reshape(1)
+    dist.all_reduce(share)
+    ok &= abs(float(share) / world - float(torch.arange(40.).mean())) < 1e-4
     ok &= all(p.grad is None for n, p in m.named_parameters() if n.startswith(('color_network.iors', 'infinity_far_bkgr')))
     batch = {'rays_o': torch.arange(10.)[:, None].repeat(1, 3), 'rgbs': torch.arange(10.)[:, None].repeat(1, 3)}
     sh = shard_rays(batch, rank, world)
