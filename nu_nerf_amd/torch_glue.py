@@ -14,8 +14,64 @@ import torch.nn.functional as F
 from .params import load_fg_lut  # noqa: F401
 
 
+class _EmbedFn(torch.autograd.Function):
+    """get_embedder(n_freq <= 6, 3) on the HIP kernels: forward nu_sdf_embed, backward J_emb^T (nu_embed_jt)."""
+
+    @staticmethod
+    def forward(ctx, x, n_freq):
+        from . import _lib as L
+        lib = L.load()
+        x = x.detach().contiguous()
+        P = x.shape[0]
+        E = torch.empty(P, 64, device=x.device)
+        L.check(lib.nu_sdf_embed(L.ptr(x), 3, P, L.ptr(E), None, None, L.stream()), "nu_sdf_embed")
+        ctx.E, ctx.nc = E, 3 + 6 * n_freq
+        return E[:, :ctx.nc].clone()
+
+    @staticmethod
+    def backward(ctx, dout):
+        from . import _lib as L
+        lib = L.load()
+        E = ctx.E
+        P = E.shape[0]
+        g = torch.zeros(P, 64, device=E.device)
+        g[:, :ctx.nc] = dout
+        dx = torch.empty(P, 3, device=E.device)
+        L.check(lib.nu_embed_jt(L.ptr(E), L.ptr(g), 64, None, 0, P, L.ptr(dx), L.stream()), "nu_embed_jt")
+        return dx, None
+
+
+class _IdeFn(torch.autograd.Function):
+    """72-d integrated directional encoding on the HIP kernels (nu_ide / nu_ide_bwd)."""
+
+    @staticmethod
+    def forward(ctx, xyz, kappa_inv):
+        from . import _lib as L
+        lib = L.load()
+        d = xyz.detach().contiguous()
+        k = kappa_inv.detach().reshape(-1).contiguous()
+        P = d.shape[0]
+        out = torch.empty(P, 72, device=d.device)
+        L.check(lib.nu_ide(L.ptr(d), L.ptr(k), P, L.ptr(out), 72, L.stream()), "nu_ide")
+        ctx.d, ctx.k, ctx.kshape = d, k, kappa_inv.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import _lib as L
+        lib = L.load()
+        d, k = ctx.d, ctx.k
+        P = d.shape[0]
+        g = g.contiguous()
+        dd, dk = torch.empty(P, 3, device=d.device), torch.empty(P, device=d.device)
+        L.check(lib.nu_ide_bwd(L.ptr(d), L.ptr(k), L.ptr(g), 72, P, L.ptr(dd), L.ptr(dk), L.stream()), "nu_ide_bwd")
+        return dd, dk.reshape(ctx.kshape)
+
+
 def embed(x, n_freq):
-    """network/field.py:14-61."""
+    """network/field.py:14-61.  CUDA tensors [P,3] with n_freq <= 6 run on the HIP kernels."""
+    if x.is_cuda and x.dim() == 2 and x.shape[1] == 3 and n_freq <= 6 and x.shape[0] > 0:
+        return _EmbedFn.apply(x, n_freq)
     out = [x]
     for k in range(n_freq):
         f = float(2 ** k)
@@ -42,7 +98,10 @@ def _ide_tables(device):
 
 
 def ide(xyz, kappa_inv):
-    """utils/ref_utils.py:84-114 in real arithmetic: (x+iy)^m by repeated multiplication, polynomial in z, vMF attenuation."""
+    """utils/ref_utils.py:84-114 in real arithmetic: (x+iy)^m by repeated multiplication, polynomial in z, vMF attenuation.
+    CUDA tensors [P,3] / [P,1] run on the HIP kernels."""
+    if xyz.is_cuda and xyz.dim() == 2 and xyz.shape[0] > 0:
+        return _IdeFn.apply(xyz, kappa_inv.expand(xyz.shape[0], 1))
     m, l, mat = _ide_tables(xyz.device)
     x, y, z = xyz[..., 0:1], xyz[..., 1:2], xyz[..., 2:3]
     zp = torch.cat([torch.ones_like(z)] + [z ** i for i in range(1, 17)], -1)
