@@ -141,6 +141,9 @@ __global__ __launch_bounds__(256, NT_WPC) void gemm_nt_kernel(NuGemmNT g) {
     const float* __restrict__ Cadd = g.Cadd ? g.Cadd + (long long)z * g.sCadd : nullptr;
     const int zero_to = g.zero_to > g.N ? g.zero_to : g.N;
     const int act_cols = g.act_cols > 0 ? g.act_cols : 0x7fffffff;
+    constexpr bool kMaskW = (EPI == NU_EPI_BIAS_RELU);                                  // writes ReLU sign bits
+    constexpr bool kMaskR = (EPI == NU_EPI_MUL_DRELU || EPI == NU_EPI_B_RELU);          // reads them instead of H
+    unsigned long long* __restrict__ mask = (kMaskW || kMaskR) ? g.mask : nullptr;
     constexpr bool kNeedH = (EPI == NU_EPI_MUL_DRELU || EPI == NU_EPI_MUL_DSP || EPI == NU_EPI_Q_SP ||
                              EPI == NU_EPI_B_SP || EPI == NU_EPI_B_RELU);
     constexpr bool kNeedD = (EPI == NU_EPI_Q_SP);
@@ -157,6 +160,15 @@ __global__ __launch_bounds__(256, NT_WPC) void gemm_nt_kernel(NuGemmNT g) {
         const int jn = next_valid(j + gridDim.x, mtn, ntnx);
         const bool has_next = jn < nslots;
         const int m0 = mt * TBM, n0 = nt * TBN;
+        // ReLU sign bits of this wave's 64x64 slab: 64 ballot words [tm][i][e], one per lane.  The reader fetches its word
+        // here, a whole main loop ahead of the epilogue (the point of the exercise: no load latency left in the epilogue)
+        const int ct = z * ntn + nt;
+        unsigned long long* mwave = (mask && ct < g.mask_nct)
+                                        ? mask + ((((long long)mt * g.mask_nct + ct) * 4 + wid) * 64) : nullptr;
+        unsigned long long mword = 0;
+        if (kMaskR && mwave) mword = mwave[lane];
+        const unsigned mlo = (unsigned)mword, mhi = (unsigned)(mword >> 32);
+        unsigned wlo = 0, whi = 0;      // writer: lane l accumulates word l
 
         f32x16 acc[2][2];
 #pragma unroll
@@ -233,11 +245,21 @@ __global__ __launch_bounds__(256, NT_WPC) void gemm_nt_kernel(NuGemmNT g) {
                     const int rl = i * 4 + (lane >> 4);
                     const int row = m0 + wr * 64 + tm * 32 + rl;
                     const f32x4 v4 = *reinterpret_cast<const f32x4*>(&scr[rl * EPI_LDS + colq]);
-                    if (row >= g.M) continue;
+                    bool pos[4] = {false, false, false, false};     // ReLU output > 0 (rows past M and non-vector lanes: false)
+                    if (row < g.M) {
                     if (full) {
                         f32x4 h4 = {0.f, 0.f, 0.f, 0.f}, d4 = h4, c4v = h4, o4, o24;
                         const bool plain = gcol >= act_cols;
-                        if (kNeedH && !plain) h4 = *reinterpret_cast<const f32x4*>(H + (long long)row * g.ldh + gcol);
+                        if (kMaskR && mwave) {
+                            if (!plain) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    const int src = (tm * 8 + i) * 4 + e;           // wave-uniform
+                                    const unsigned lo = __builtin_amdgcn_readlane(mlo, src), hi = __builtin_amdgcn_readlane(mhi, src);
+                                    h4[e] = (((lane < 32 ? lo : hi) >> (lane & 31)) & 1u) ? 1.0f : 0.0f;
+                                }
+                            }
+                        } else if (kNeedH && !plain) h4 = *reinterpret_cast<const f32x4*>(H + (long long)row * g.ldh + gcol);
                         if (kNeedD && !plain) d4 = *reinterpret_cast<const f32x4*>(D + (long long)row * g.ldd + gcol);
                         if (kNeedAdd && !plain) c4v = *reinterpret_cast<const f32x4*>(Cadd + (long long)row * g.ldadd + gcol);
 #pragma unroll
@@ -249,6 +271,10 @@ __global__ __launch_bounds__(256, NT_WPC) void gemm_nt_kernel(NuGemmNT g) {
                         }
                         *reinterpret_cast<f32x4*>(C + (long long)row * g.ldc + gcol) = o4;
                         if (kNeedD) *reinterpret_cast<f32x4*>(C2 + (long long)row * g.ldc2 + gcol) = o24;
+                        if (kMaskW) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) pos[e] = o4[e] > 0.f;
+                        }
                     } else {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
@@ -270,9 +296,20 @@ __global__ __launch_bounds__(256, NT_WPC) void gemm_nt_kernel(NuGemmNT g) {
                             if (kNeedD) C2[(long long)row * g.ldc2 + col] = out2;
                         }
                     }
+                    }
+                    if (kMaskW && mwave) {      // every lane of the slab is here (N % 64 == 0 for a writer): ballots are complete
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const unsigned long long bits = __ballot(pos[e]);
+                            const bool mine = lane == (tm * 8 + i) * 4 + e;
+                            wlo = mine ? (unsigned)bits : wlo;
+                            whi = mine ? (unsigned)(bits >> 32) : whi;
+                        }
+                    }
                 }
             }
         }
+        if (kMaskW && mwave) mwave[lane] = ((unsigned long long)whi << 32) | wlo;
         if (!has_next) break;
         __syncthreads();   // every wave is done with the scratch
         store_regs();
@@ -290,6 +327,13 @@ int nu_gemm_nt_launch(const NuGemmNT& g, hipStream_t stream) {
     const long long nslots = (long long)nu_rup(nu_cdiv(g.M, TBM), 8) * ntn;
     if (nslots > 0x7fffffffLL) return NU_ERR_ARG;
     const int groups = g.groups > 0 ? g.groups : 1;
+    if (g.mask && (g.epi == NU_EPI_BIAS_RELU || g.epi == NU_EPI_MUL_DRELU || g.epi == NU_EPI_B_RELU)) {
+        // the sign-bit path lives in the 16-byte epilogue only: every lane's 4 columns inside N, matrices aligned
+        if ((g.N & 3) || (g.ldc & 3) || ((uintptr_t)g.C & 15) || g.mask_nct <= 0) return NU_ERR_ARG;
+        if (g.epi == NU_EPI_B_RELU && ((g.ldadd & 3) || ((uintptr_t)g.Cadd & 15))) return NU_ERR_ARG;
+        if (g.epi == NU_EPI_BIAS_RELU && ((long long)groups * ntn > g.mask_nct || (g.N & 63))) return NU_ERR_ARG;
+        if (g.act_cols > 0 && (g.act_cols & 63)) return NU_ERR_ARG;
+    }
     // persistent: NT_WPC workgroups per CU (256 CUs) shared over the groups, a multiple of 8 so the XCD grouping holds
     static const int grid_target = getenv("NU_NT_GRID") ? atoi(getenv("NU_NT_GRID")) : 256 * NT_WPC;
     long long per = nu_rup(nu_cdiv(grid_target, groups), 8);

@@ -19,6 +19,7 @@ Buffer conventions (all fp32 row-major; leading dims are multiples of 32 with ze
     lights: OLin [3P+R, 96], ILin [2P,128], IWin [P,96], RLin [P,96] -> 3 hidden [rows,256] -> raw heads
 """
 import ctypes
+import os
 import math
 
 import numpy as np
@@ -36,7 +37,8 @@ class GemmNT(ctypes.Structure):
                 ("C", c_p), ("ldc", c_int), ("C2", c_p), ("ldc2", c_int), ("bias", c_p), ("H", c_p), ("ldh", c_int),
                 ("D", c_p), ("ldd", c_int), ("Cadd", c_p), ("ldadd", c_int), ("zero_to", c_int), ("act_cols", c_int),
                 ("alpha", c_f), ("groups", c_int), ("sA", c_ll), ("sB", c_ll), ("sC", c_ll), ("sC2", c_ll),
-                ("sBias", c_ll), ("sH", c_ll), ("sD", c_ll), ("sCadd", c_ll), ("epi", c_int), ("bf16", c_int)]
+                ("sBias", c_ll), ("sH", c_ll), ("sD", c_ll), ("sCadd", c_ll), ("epi", c_int), ("bf16", c_int),
+                ("mask", c_p), ("mask_nct", c_int), ("pad_", c_int)]
 
 
 class GemmTN(ctypes.Structure):
@@ -140,6 +142,18 @@ class Stage1Engine:
 
     def stream(self):
         return c_p(torch.cuda.current_stream(self.dev).cuda_stream)
+
+    def relu_mask(self, act, rows, ncols):
+        """Sign-bit buffer for a [rows, ncols] ReLU activation (2 KB per 128x128 tile): written by the BIAS_RELU GEMM that
+        produces `act`, read by the backward GEMMs instead of `act` itself.  Rides on the activation tensor so that it lives
+        exactly as long."""
+        if os.environ.get('NU_RELU_MASK', '1') == '0':     # development switch: A/B against reading the activation
+            return None
+        nct = (ncols + 127) // 128
+        m = torch.empty(((rows + 127) // 128) * nct * 256, dtype=torch.int64, device=self.dev)
+        m._nu_nct = nct
+        act._nu_mask = m
+        return m
 
     def _arena_take(self, nbytes):
         """Device address of `nbytes` of slab space that stays untouched until the next flush_reductions()."""
@@ -337,13 +351,14 @@ class Stage1Engine:
     # ------------------------------------------------------------------ raw launches
     def nt(self, A, lda, B, ldb, M, N, K, C, ldc, epi, *, C2=0, ldc2=0, bias=0, H=0, ldh=0, D=0, ldd=0, Cadd=0,
            ldadd=0, zero_to=0, act_cols=0, alpha=1.0, groups=1, sA=0, sB=0, sC=0, sC2=0, sBias=0, sH=0, sD=0, sCadd=0,
-           ktrue=None, ntrue=None):
+           ktrue=None, ntrue=None, mask=None):
         """C = epi(A . B^T) on the fp32-MFMA kernel.  ktrue/ntrue: unpadded extents, used only for the algorithmic
         FLOP count of the roofline report."""
         if M <= 0:
             return
         g = GemmNT(A, lda, B, ldb, M, N, K, C, ldc, C2, ldc2, bias, H, ldh, D, ldd, Cadd, ldadd, zero_to, act_cols,
-                   alpha, groups, sA, sB, sC, sC2, sBias, sH, sD, sCadd, epi, self.bf16)
+                   alpha, groups, sA, sB, sC, sC2, sBias, sH, sD, sCadd, epi, self.bf16,
+                   mask.data_ptr() if mask is not None else 0, mask._nu_nct if mask is not None else 0, 0)
         kt = self._ktime if self.ktime_on else None
         if kt is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -546,7 +561,8 @@ class Stage1Engine:
         for j in range(3):
             lay = layers[j]
             Hn = self.empty(rows, 256)
-            self.nt(addr(src), lds, addr(*lay.Wp), lay.Kp, rows, 256, lay.Kp, addr(Hn), 256, EPI_BIAS_RELU, bias=addr(lay.b))
+            self.nt(addr(src), lds, addr(*lay.Wp), lay.Kp, rows, 256, lay.Kp, addr(Hn), 256, EPI_BIAS_RELU, bias=addr(lay.b),
+                    mask=self.relu_mask(Hn, rows, 256))
             Hs.append(Hn)
             src, lds = Hn, 256
         return Hs
@@ -561,7 +577,7 @@ class Stage1Engine:
             if j > 0:
                 nxt = self.empty(rows, 256)
                 self.nt(addr(dA), 256, addr(*lay.WpT), lay.ldT, rows, 256, 256, addr(nxt), 256, EPI_MUL_DRELU,
-                        H=addr(Hs[j - 1]), ldh=256)
+                        H=addr(Hs[j - 1]), ldh=256, mask=getattr(Hs[j - 1], '_nu_mask', None))
                 dA = nxt
             elif dX is not None:
                 self.nt(addr(dA), 256, addr(*lay.WpT), lay.ldT, rows, dx_cols, 256, addr(dX), lddx, EPI_PLAIN)
@@ -577,10 +593,11 @@ class Stage1Engine:
         YX = a['YX']
         # materials: layer 0 batched (N=1024), layers 1-2 grouped x4, block-diagonal 6-wide head
         M1, M2, M3 = e(P, 1024), e(P, 1024), e(P, 1024)
-        self.nt(addr(YX), 288, addr(self.WpM0), 288, P, 1024, 288, addr(M1), 1024, EPI_BIAS_RELU, bias=addr(self.bM0))
+        self.nt(addr(YX), 288, addr(self.WpM0), 288, P, 1024, 288, addr(M1), 1024, EPI_BIAS_RELU, bias=addr(self.bM0),
+                mask=self.relu_mask(M1, P, 1024))
         for j, (src, dst) in ((1, (M1, M2)), (2, (M2, M3))):
             self.nt(addr(src), 1024, addr(self.WpM[j]), 256, P, 256, 256, addr(dst), 1024, EPI_BIAS_RELU,
-                    bias=addr(self.bM[j]), groups=4, sA=256, sB=65536, sC=256, sBias=256)
+                    bias=addr(self.bM[j]), groups=4, sA=256, sB=65536, sC=256, sBias=256, mask=self.relu_mask(dst, P, 1024))
         Mraw = e(P, 8)
         self.skinny_fwd(addr(M3), 1024, P, 1024, addr(self.Ws6), 1024, addr(self.b6), 6, addr(Mraw), 8)
         s.update(M1=M1, M2=M2, M3=M3, Mraw=Mraw)
@@ -662,7 +679,7 @@ class Stage1Engine:
                        groups=4, sA0=256, sB0=256, sW=65536, sDb=256)
             nxt = e(P, 1024)
             self.nt(addr(dA), 1024, addr(self.WpTM[j]), 256, P, 256, 256, addr(nxt), 1024, EPI_MUL_DRELU,
-                    H=addr(Hin), ldh=1024, groups=4, sA=256, sB=65536, sC=256, sH=256)
+                    H=addr(Hin), ldh=1024, groups=4, sA=256, sB=65536, sC=256, sH=256, mask=getattr(Hin, '_nu_mask', None))
             dA = nxt
         self.wgrad(addr(dA), 1024, addr(a['YX']), 288, P, 1024, 288, addr(self.dWpM0), 288, addr(flat, db0))
         dYX = e(P, 288)
@@ -684,7 +701,8 @@ class Stage1Engine:
             lay = self.nerf[i]
             dst = U5 if i == 4 else e(P, 256)
             ldc = 352 if i == 4 else 256
-            self.nt(addr(src), lds, addr(*lay.Wp), lay.Kp, P, 256, lay.Kp, addr(dst), ldc, EPI_BIAS_RELU, bias=addr(lay.b))
+            self.nt(addr(src), lds, addr(*lay.Wp), lay.Kp, P, 256, lay.Kp, addr(dst), ldc, EPI_BIAS_RELU, bias=addr(lay.b),
+                    mask=self.relu_mask(dst, P, 256))
             H.append(dst)
             src, lds = dst, ldc
         b['H'] = H  # H[i] = input of layer i (H[5] = U5, ld 352), H[8] = last hidden
@@ -732,7 +750,7 @@ class Stage1Engine:
                         addr(*self.nerf_alpha.dWp), 256, addr(flat, self.nerf_alpha.db_off))
         dA = e(P, 256)
         self.nt(addr(dF), ldf, addr(*self.nerf_feat.WpT), self.nerf_feat.ldT, P, 256, 256, addr(dA), 256, EPI_B_RELU,
-                H=addr(H[8]), ldh=256, Cadd=addr(dH8a), ldadd=256)
+                H=addr(H[8]), ldh=256, Cadd=addr(dH8a), ldadd=256, mask=getattr(H[8], '_nu_mask', None))
         # trunk, layers 7..0 ; dA = d pre-activation of layer i (row stride lda)
         dskip, lda = None, 256
         for i in range(7, -1, -1):
@@ -744,13 +762,13 @@ class Stage1Engine:
                     # columns 256..339 of the layer-5 input are the re-concatenated embedding: keep their plain gradient
                     nxt = e(P, 352)
                     self.nt(addr(dA), lda, addr(*lay.WpT), lay.ldT, P, 340, 256, addr(nxt), 352, EPI_MUL_DRELU,
-                            H=addr(H[i]), ldh=ldu, act_cols=256, zero_to=352)
+                            H=addr(H[i]), ldh=ldu, act_cols=256, zero_to=352, mask=getattr(H[i], '_nu_mask', None))
                     dskip = nxt
                     dA, lda = nxt, 352
                 else:
                     nxt = e(P, 256)
                     self.nt(addr(dA), lda, addr(*lay.WpT), lay.ldT, P, 256, 256, addr(nxt), 256, EPI_MUL_DRELU,
-                            H=addr(H[i]), ldh=ldu)
+                            H=addr(H[i]), ldh=ldu, mask=getattr(H[i], '_nu_mask', None))
                     dA, lda = nxt, 256
             elif want_in:
                 dE4 = e(P, 96)

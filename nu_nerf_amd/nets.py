@@ -130,10 +130,11 @@ class MaterialsFn(torch.autograd.Function):
         YX[:, 257:260] = x.detach()
         e = eng.empty
         M1, M2, M3 = e(P, 1024), e(P, 1024), e(P, 1024)
-        eng.nt(addr(YX), 288, addr(eng.WpM0), 288, P, 1024, 288, addr(M1), 1024, EPI_BIAS_RELU, bias=addr(eng.bM0))
+        eng.nt(addr(YX), 288, addr(eng.WpM0), 288, P, 1024, 288, addr(M1), 1024, EPI_BIAS_RELU, bias=addr(eng.bM0),
+               mask=eng.relu_mask(M1, P, 1024))
         for j, (src, dst) in ((1, (M1, M2)), (2, (M2, M3))):
             eng.nt(addr(src), 1024, addr(eng.WpM[j]), 256, P, 256, 256, addr(dst), 1024, EPI_BIAS_RELU,
-                   bias=addr(eng.bM[j]), groups=4, sA=256, sB=65536, sC=256, sBias=256)
+                   bias=addr(eng.bM[j]), groups=4, sA=256, sB=65536, sC=256, sBias=256, mask=eng.relu_mask(dst, P, 1024))
         Mraw = e(P, 8)
         eng.skinny_fwd(addr(M3), 1024, P, 1024, addr(eng.Ws6), 1024, addr(eng.b6), 6, addr(Mraw), 8)
         ctx.eng, ctx.s, ctx.names = eng, dict(YX=YX, M1=M1, M2=M2, M3=M3), names
@@ -160,7 +161,7 @@ class MaterialsFn(torch.autograd.Function):
                       groups=4, sA0=256, sB0=256, sW=65536, sDb=256)
             nxt = e(P, 1024)
             eng.nt(addr(dA), 1024, addr(eng.WpTM[j]), 256, P, 256, 256, addr(nxt), 1024, EPI_MUL_DRELU,
-                   H=addr(Hin), ldh=1024, groups=4, sA=256, sB=65536, sC=256, sH=256)
+                   H=addr(Hin), ldh=1024, groups=4, sA=256, sB=65536, sC=256, sH=256, mask=getattr(Hin, '_nu_mask', None))
             dA = nxt
         eng.wgrad(addr(dA), 1024, addr(s['YX']), 288, P, 1024, 288, addr(eng.dWpM0), 288, addr(flat, db0))
         dYX = e(P, 288)

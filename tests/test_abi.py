@@ -40,8 +40,8 @@ def test_struct_layouts_match_python_mirrors(lib):
     from nu_nerf_amd.engine import PackDesc, GemmNT, GemmTN
     assert lib.nu_pack_desc_size() == ctypes.sizeof(PackDesc)
     # natural-alignment sizes of the C structs in include/nu_nerf.h
-    assert ctypes.sizeof(GemmNT) == 216 and ctypes.sizeof(GemmTN) == 152
-    assert lib.nu_gemm_nt_size() == 216 and lib.nu_gemm_tn_size() == 152 and lib.nu_reduce_desc_size() == 64
+    assert ctypes.sizeof(GemmNT) == 232 and ctypes.sizeof(GemmTN) == 152
+    assert lib.nu_gemm_nt_size() == 232 and lib.nu_gemm_tn_size() == 152 and lib.nu_reduce_desc_size() == 64
 
 
 def test_workspace_queries_are_pure_host_functions(lib):

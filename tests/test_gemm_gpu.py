@@ -139,6 +139,60 @@ def test_tn_weight_grad_operand_over_4gib(gpu):
     torch.testing.assert_close(bo.double(), bref, rtol=2e-5, atol=tol)
 
 
+def test_relu_sign_bits_replace_the_activation_in_the_backward_epilogues(gpu):
+    """BIAS_RELU writes one ballot word per (4-row group, column quad); MUL_DRELU / B_RELU read those instead of H (the H
+    pointer handed to them here is poisoned with NaN to prove it).  Also the writer-ungrouped / reader-grouped pairing of the
+    batched material predictors, a ragged M, and a plain-column tail (act_cols)."""
+    from nu_nerf_amd import _lib as L
+    from nu_nerf_amd.engine import GemmNT, addr
+    lib = L.load()
+    torch.manual_seed(5)
+    M, K, N = 1000, 96, 512
+    A = torch.randn(M, K, device=gpu)
+    W = torch.randn(N, K, device=gpu) / K ** 0.5
+    bias = torch.randn(N, device=gpu) * 0.3
+    Hout = torch.full((M, N), float("nan"), device=gpu)
+    nct = N // 128
+    mask = torch.zeros(((M + 127) // 128) * nct * 256, dtype=torch.int64, device=gpu)
+    g = GemmNT(addr(A), K, addr(_packB(W, K)), K, M, N, K, addr(Hout), N, 0, 0, addr(bias), 0, 0, 0, 0, 0, 0, 0, 0, 1.0, 1,
+               0, 0, 0, 0, 0, 0, 0, 0, 1, 0, mask.data_ptr(), nct, 0)
+    L.check(lib.nu_gemm_nt_ex(ctypes.byref(g), L.stream()), "fwd")
+    ref_h = torch.relu(A.double() @ W.double().t() + bias.double())
+    torch.testing.assert_close(Hout.double(), ref_h, rtol=2e-5, atol=2e-5)
+    # backward, grouped x2 over the two 256-column halves (the material predictors' pairing), H poisoned
+    dA = torch.randn(M, N, device=gpu)
+    W2 = torch.randn(2, 256, 256, device=gpu) / 16
+    out = torch.full((M, N), float("nan"), device=gpu)
+    poison = torch.full((M, N), float("nan"), device=gpu)
+    g = GemmNT(addr(dA), N, addr(W2), 256, M, 256, 256, addr(out), N, 0, 0, 0, addr(poison), N, 0, 0, 0, 0, 0, 0, 1.0, 2,
+               256, 65536, 256, 0, 0, 256, 0, 0, 3, 0, mask.data_ptr(), nct, 0)
+    L.check(lib.nu_gemm_nt_ex(ctypes.byref(g), L.stream()), "bwd")
+    for z in range(2):
+        v = dA[:, 256 * z:256 * (z + 1)].double() @ W2[z].double().t()
+        torch.testing.assert_close(out[:, 256 * z:256 * (z + 1)].double(), v * (Hout[:, 256 * z:256 * (z + 1)] > 0), rtol=2e-5, atol=2e-5)
+    # B_RELU with Cadd, and MUL_DRELU with plain columns past act_cols (first 256 columns masked, next 84 plain)
+    Cadd = torch.randn(M, 256, device=gpu)
+    out2 = torch.full((M, 256), float("nan"), device=gpu)
+    m256 = torch.zeros(((M + 127) // 128) * 2 * 256, dtype=torch.int64, device=gpu)
+    H256 = torch.full((M, 256), float("nan"), device=gpu)
+    g = GemmNT(addr(A), K, addr(_packB(W[:256], K)), K, M, 256, K, addr(H256), 256, 0, 0, addr(bias), 0, 0, 0, 0, 0, 0, 0, 0, 1.0, 1,
+               0, 0, 0, 0, 0, 0, 0, 0, 1, 0, m256.data_ptr(), 2, 0)
+    L.check(lib.nu_gemm_nt_ex(ctypes.byref(g), L.stream()), "fwd256")
+    g = GemmNT(addr(dA), N, addr(W2), 256, M, 256, 256, addr(out2), 256, 0, 0, 0, addr(poison), N, 0, 0, addr(Cadd), 256, 0, 0, 1.0, 1,
+               0, 0, 0, 0, 0, 0, 0, 0, 8, 0, m256.data_ptr(), 2, 0)
+    L.check(lib.nu_gemm_nt_ex(ctypes.byref(g), L.stream()), "b_relu")
+    v = dA[:, :256].double() @ W2[0].double().t()
+    torch.testing.assert_close(out2.double(), v * (H256 > 0) + Cadd.double(), rtol=2e-5, atol=2e-5)
+    W3 = torch.randn(384, 256, device=gpu) / 16
+    out3 = torch.full((M, 352), float("nan"), device=gpu)
+    g = GemmNT(addr(dA), N, addr(W3), 256, M, 340, 256, addr(out3), 352, 0, 0, 0, addr(poison), N, 0, 0, 0, 0, 352, 256, 1.0, 1,
+               0, 0, 0, 0, 0, 0, 0, 0, 3, 0, m256.data_ptr(), 2, 0)
+    L.check(lib.nu_gemm_nt_ex(ctypes.byref(g), L.stream()), "plain tail")
+    v = dA[:, :256].double() @ W3[:340].double().t()
+    want = torch.cat([v[:, :256] * (H256 > 0), v[:, 256:], torch.zeros(M, 12, dtype=torch.float64, device=gpu)], 1)
+    torch.testing.assert_close(out3.double(), want, rtol=2e-5, atol=2e-5)
+
+
 def _bf(x):
     return x.bfloat16().float()
 
