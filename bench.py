@@ -8,13 +8,14 @@ parameter gradients.
 A step = ray fetch (device-resident pool) -> sampler -> render_core forward -> loss -> backward -> [all-reduce]
 -> Adam.  Rank 0 prints ONE JSON line.  Extra objects:
   roofline     : the fp32-MFMA GEMM kernels (gemm_nt_kernel*, the dominant kernel): algorithmic FLOPs of every
-                 launch / summed launch durations (HIP events on the launch stream, on every --time-every-th step of
-                 the timed region: the event pairs themselves cost ~4 ms/step) vs the 157.3 TFLOP/s fp32-MFMA peak
+                 launch / summed launch durations (HIP events on the launch stream, on one step in the middle of
+                 the timed region by default: the ~330 event pairs cost that step a few ms) vs the 157.3 TFLOP/s fp32-MFMA peak
                  of MI355X_MICROARCH.md.
   cpu_baseline : the CPU oracle (oracle/stage1_oracle.py, a port of the reference's PyTorch path) timed on this
                  box's host cores on a bounded sample of the same workload (rank 0, N=1 only).
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -93,8 +94,9 @@ def main():
     ap.add_argument('--real-capture', action='store_true',
                     help='real-capture code path (is_nerf False, sphere_direction True): BASELINE config 4 with --rays 8192 --mlp-dtype bf16')
     ap.add_argument('--no-kernel-timing', action='store_true')
-    ap.add_argument('--time-every', type=int, default=4,
-                    help='bracket the GEMM launches with HIP events on every Nth timed step (the event pairs cost ~4 ms/step)')
+    ap.add_argument('--time-every', type=int, default=0,
+                    help='bracket the GEMM launches with HIP events on every Nth step of the timed region; 0 (default): on ONE '
+                         'step in the middle of it (the ~330 event pairs cost that step 2-4 ms)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -170,19 +172,28 @@ def main():
     torch.cuda.synchronize()
     stats['P_in'] = stats['P_out'] = 0
     if not args.no_kernel_timing:
-        eng.begin_kernel_timing()
+        bracketed = [args.steps // 2] if args.time_every <= 0 else [i for i in range(args.steps) if i % args.time_every == 0]
+        eng.begin_kernel_timing(reserve=2 * 200 * len(bracketed))
+    gc.collect()
+    gc.disable()          # no collector pause inside the timed region (a full collection stalls the launch thread)
     t0 = time.perf_counter()
     last = None
     timed_steps = 0
+    step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    step_ev[0].record()
+    seg_count = [torch.cuda.memory_stats(dev).get('segment.all.allocated', 0)]
     for it in range(args.warmup, args.warmup + args.steps):
-        eng.ktime_on = (it - args.warmup) % max(1, args.time_every) == 0
+        eng.ktime_on = (not args.no_kernel_timing) and (it - args.warmup) in bracketed
         timed_steps += int(eng.ktime_on)
         last = one_step(it)
+        step_ev[it - args.warmup + 1].record()
+        seg_count.append(torch.cuda.memory_stats(dev).get('segment.all.allocated', 0))
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -211,7 +222,9 @@ def main():
                        ("in place on the flat gradient buffer" if reducer.gathered_calls == 0 else
                         "gathered (%d of %d steps)" % (reducer.gathered_calls, reducer.gathered_calls + reducer.in_place_calls)),
                        "mean_inner_points": stats['P_in'] / args.steps, "mean_outer_points": stats['P_out'] / args.steps,
-                       "final_loss": float(last.detach())},
+                       "final_loss": float(last.detach()),
+                       "step_ms": [round(step_ev[i].elapsed_time(step_ev[i + 1]), 2) for i in range(args.steps)],
+                       "new_device_segments_per_step": [seg_count[i + 1] - seg_count[i] for i in range(args.steps)]},
         }
         if ktime is not None:
             tf = ktime['flops'] / max(ktime['seconds'], 1e-12) / 1e12

@@ -124,15 +124,44 @@ class Stage1Engine:
         self._ptr_sig = None
         self._ktime = None
         self.ktime_on = True
+        self._ev_pool = []
+        self._cap_classes = []
         self.last_ctx = None
         self._build_layers()
 
     # ------------------------------------------------------------------ buffers
+    # Point counts change a little from step to step; the caching allocator only reuses a block that is large enough, so
+    # every new record size used to cost a burst of hipMalloc calls (one of them now and then 50 ms).  Large per-point
+    # buffers are therefore allocated from a few CAPACITY CLASSES and handed out as a prefix view: a request reuses an
+    # existing class up to 1.6x its size, otherwise a new class with 25 % headroom (multiple of 16384 rows) is opened --
+    # the inner / outer point counts of a scene move by +-10 % between batches.  After the first step every allocation
+    # repeats a size the allocator already holds (sized for 288 GB: the step's 11 GB of activations become ~15 GB).
+    _ROW_QUANTUM = 16384
+
+    def _capacity(self, shape):
+        if not (len(shape) >= 1 and isinstance(shape[0], int) and shape[0] > 4 * self._ROW_QUANTUM):
+            return None
+        n = shape[0]
+        for c in self._cap_classes:
+            if n <= c <= 1.6 * n:
+                return c
+        q = self._ROW_QUANTUM
+        c = (int(n * 1.25) + q - 1) // q * q
+        self._cap_classes.append(c)
+        self._cap_classes.sort()
+        return c
+
     def zeros(self, *shape, dtype=torch.float32):
-        return torch.zeros(*shape, dtype=dtype, device=self.dev)
+        cap = self._capacity(shape)
+        if cap is None:
+            return torch.zeros(*shape, dtype=dtype, device=self.dev)
+        return torch.zeros(cap, *shape[1:], dtype=dtype, device=self.dev)[:shape[0]]
 
     def empty(self, *shape, dtype=torch.float32):
-        return torch.empty(*shape, dtype=dtype, device=self.dev)
+        cap = self._capacity(shape)
+        if cap is None:
+            return torch.empty(*shape, dtype=dtype, device=self.dev)
+        return torch.empty(cap, *shape[1:], dtype=dtype, device=self.dev)[:shape[0]]
 
     def workspace(self, nbytes):
         n = (int(nbytes) + 3) // 4
@@ -150,7 +179,8 @@ class Stage1Engine:
         if os.environ.get('NU_RELU_MASK', '1') == '0':     # development switch: A/B against reading the activation
             return None
         nct = (ncols + 127) // 128
-        m = torch.empty(((rows + 127) // 128) * nct * 256, dtype=torch.int64, device=self.dev)
+        rows_q = self._capacity((rows,)) or rows
+        m = torch.empty(((rows_q + 127) // 128) * nct * 256, dtype=torch.int64, device=self.dev)
         m._nu_nct = nct
         act._nu_mask = m
         return m
@@ -361,7 +391,7 @@ class Stage1Engine:
                    mask.data_ptr() if mask is not None else 0, mask._nu_nct if mask is not None else 0, 0)
         kt = self._ktime if self.ktime_on else None
         if kt is not None:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0, e1 = self._event_pair()
             e0.record()
         L.check(self.lib.nu_gemm_nt_ex(ctypes.byref(g), self.stream()), "nu_gemm_nt_ex")
         if kt is not None:
@@ -370,11 +400,23 @@ class Stage1Engine:
             abytes = 4.0 * groups * (M * (ktrue or K) + M * (ntrue or N) * nmat + N * (ktrue or K))
             kt['nt'].append((e0, e1, 2.0 * M * (ntrue or N) * (ktrue or K) * groups, abytes))
 
-    def begin_kernel_timing(self):
+    def begin_kernel_timing(self, reserve=0):
         """Bracket every GEMM launch with HIP events on the launch stream (bench.py's roofline leg).  The event pairs cost
         about 4 ms per step (two queue barriers per launch), so the bench switches `ktime_on` per step to sample."""
         self._ktime = {'nt': [], 'tn': []}
         self.ktime_on = True
+        # events are created here, outside the timed region: torch makes the HIP event at the first record(), and creating
+        # the ~650 events of one bracketed step used to cost that step 70 ms
+        self._ev_pool = [torch.cuda.Event(enable_timing=True) for _ in range(int(reserve))]
+        for ev in self._ev_pool:
+            ev.record()
+        torch.cuda.synchronize(self.dev)
+
+    def _event_pair(self):
+        pool = self._ev_pool
+        if len(pool) >= 2:
+            return pool.pop(), pool.pop()
+        return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
     def end_kernel_timing(self):
         kt, self._ktime = self._ktime, None
@@ -391,7 +433,7 @@ class Stage1Engine:
               sA1=0, sB1=0, sW=0, sDb=0, n2true=None):
         kt = self._ktime if self.ktime_on else None
         if kt is not None:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0, e1 = self._event_pair()
             e0.record()
         self._wgrad(A0, lda0, B0, ldb0, P, N1, N2, dW, ldw, db, A1, lda1, B1, ldb1, groups, sA0, sB0, sA1, sB1, sW, sDb)
         if kt is not None:
