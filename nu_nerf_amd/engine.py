@@ -396,7 +396,8 @@ class Stage1Engine:
         L.check(self.lib.nu_gemm_nt_ex(ctypes.byref(g), self.stream()), "nu_gemm_nt_ex")
         if kt is not None:
             e1.record()
-            nmat = 1 + (1 if C2 else 0) + (1 if H else 0) + (1 if D else 0) + (1 if Cadd else 0)
+            reads_h = bool(H) and not (mask is not None and epi in (EPI_MUL_DRELU, EPI_B_RELU))   # sign bits replace H
+            nmat = 1 + (1 if C2 else 0) + (1 if reads_h else 0) + (1 if D else 0) + (1 if Cadd else 0)
             abytes = 4.0 * groups * (M * (ktrue or K) + M * (ntrue or N) * nmat + N * (ktrue or K))
             kt['nt'].append((e0, e1, 2.0 * M * (ntrue or N) * (ktrue or K) * groups, abytes))
 
