@@ -81,9 +81,71 @@ def cpu_baseline(rays_cpu, step0, budget_s=20.0):
                       f"{ms:.0f} ms/iter, torch CPU fp32, os.cpu_count()={os.cpu_count()}"}
 
 
+def main_stage2(args):
+    """BASELINE.json configs[2]: stage-2 training step (refraction through the stage-1 mesh, learned IoR, 3 bounces) on ONE
+    GPU: 4096 rays, icosphere(r=0.5) with 20480 faces standing in for the stage-1 mesh, segment samples 256/128/256.  A parity
+    case of the build, not its headline: printed in the same JSON format on request (--workload stage2)."""
+    from nu_nerf_amd.stage2 import Stage2Renderer
+    from nu_nerf_amd.params import init_stage1_params, init_stage2_params
+    from nu_nerf_amd.lbvh import icosphere
+    from nu_nerf_amd.synthetic import make_rays, make_object_rays
+    from nu_nerf_amd.loss import name2loss, total_loss
+    from nu_nerf_amd.train_glue import FusedAdam
+    dev = torch.device('cuda:0')
+    s1 = init_stage1_params(6033)
+    p2 = init_stage2_params(6033, 7044, {'sphere_direction': False})
+    for k, v in s1.items():
+        p2['stage1_network.' + k] = v
+        p2['color_network.stage1_network.' + k] = v
+    cfg = {'name': 's2', 'network': 'stage2', 'is_nerf': True, 'shader_config': {'sphere_direction': False, 'human_light': False},
+           'eikonal_weight': 0.02, 'freeze_inv_s_step': 5000,
+           'stage1_cfg': {'is_nerf': True, 'apply_occ_loss': True, 'occ_loss_step': 15000, 'freeze_inv_s_step': 15000},
+           'stage1_mesh_arrays': icosphere(5, 0.5)}
+    net = Stage2Renderer(cfg, training=False)
+    net.load_param_dict(p2)
+    net = net.to(dev)
+    losses = [name2loss[n](cfg) for n in ('eikonal', 'std', 'nerf_render')]
+    opt = FusedAdam([p for p in net.parameters() if p.requires_grad], lr=1e-3)
+    R, n = args.rays, args.steps + args.warmup
+    pool = (make_object_rays if args.object_rays else make_rays)(R * n, seed=6033)
+    pool = {k: torch.from_numpy(v).to(dev) for k, v in pool.items() if k in ('rays_o', 'rays_d', 'rgbs')}
+    entered = []
+
+    def step(i):
+        b = {k: v[i * R:(i + 1) * R] for k, v in pool.items()}
+        opt.zero_grad(set_to_none=True)
+        out = net.train_step_rays(b, 6000 + i)
+        total, _ = total_loss(out, losses, 6000 + i)
+        total.backward()
+        opt.step()
+        entered.append(float(len(out['_paths']) > 1 and out['_paths'][1].shape[0]) / R)
+        return total
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    entered.clear()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, n):
+        last = step(i)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    print(json.dumps({
+        "metric": "train rays/sec", "value": R / dt, "unit": "rays/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "stage-2 train step, %d rays, icosphere 20480 faces (HIP LBVH), 3 bounces, segment samples "
+                               "256/128/256, fp32 (BASELINE.json configs[2])" % R,
+                   "rays": "object-aimed" if args.object_rays else "Spherepot-shaped cameras",
+                   "frac_rays_entering_object": float(np.mean(entered)), "final_loss": float(last.detach()),
+                   "max_mem_GB": torch.cuda.max_memory_allocated() / 2 ** 30}}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--workload', default='stage1', choices=['stage1', 'stage2'],
+                    help="'stage1' = the headline (BASELINE configs[1]); 'stage2' = configs[2] on one GPU (a parity case, see DESIGN 9)")
+    ap.add_argument('--object-rays', action='store_true', help='stage2 only: aim every ray at the object (all three bounces)')
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--rays', type=int, default=4096, help='rays per GPU per step')
@@ -98,6 +160,10 @@ def main():
                     help='bracket the GEMM launches with HIP events on every Nth step of the timed region; 0 (default): on ONE '
                          'step in the middle of it (the ~330 event pairs cost that step 2-4 ms)')
     args = ap.parse_args()
+    if args.workload == 'stage2':
+        if int(os.environ.get('WORLD_SIZE', 1)) != 1:
+            raise SystemExit("--workload stage2 runs on one GPU")
+        return main_stage2(args)
 
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))

@@ -171,3 +171,23 @@ def test_grad_all_reduce_two_ranks_gloo():
         p.join(timeout=60)
     assert all(ok for _, ok, _ in res)
     assert res[0][2] == 2552665                         # params that receive gradients in stage 1
+
+
+def test_capacity_classes_make_allocation_sizes_repeat():
+    """Per-point buffers are allocated from a few capacity classes (engine._capacity): point counts that wander by +-10 %
+    between steps must map to ONE size after the first request, small buffers stay exact."""
+    from types import SimpleNamespace
+    from nu_nerf_amd.engine import Stage1Engine
+    eng = SimpleNamespace(_cap_classes=[], _ROW_QUANTUM=Stage1Engine._ROW_QUANTUM)
+    cap = lambda *shape: Stage1Engine._capacity(eng, shape)
+    assert cap(4096, 3) is None and cap(65536, 256) is None            # small: exact allocation
+    first = cap(527000, 256)
+    assert first % 16384 == 0 and 1.25 * 527000 <= first < 1.25 * 527000 + 16384
+    for n in (520000, 545000, 500001, 560000, int(first)):              # the scene's outer-point counts
+        assert cap(n, 256) == first
+    inner = cap(128000, 288)
+    assert inner != first and all(cap(n, 64) == inner for n in (115000, 135000, 150000))
+    assert cap(3 * 128000 + 4096, 96) not in (None, inner)             # the row-batched outer_light input: its own class
+    assert len(eng._cap_classes) == 3
+    bigger = cap(int(first) + 1, 256)                                    # a record: a new class, once
+    assert bigger > first and cap(int(first) + 5000, 256) == bigger
