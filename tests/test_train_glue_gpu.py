@@ -81,3 +81,55 @@ def test_train_step_glue_runs_the_reference_loop_body(gpu):
     assert bool(torch.isfinite(t0)) and bool(torch.isfinite(t1)) and 'loss_rgb' in ''.join(log.keys())
     assert float((net.sdf_network.lin2.weight_v - w0).abs().max()) > 0
     assert net.color_network.iors[0].weight_v.grad is None          # dead parameters stay untouched
+
+
+def test_four_optimizer_steps_track_the_cpu_oracle(gpu):
+    """The whole loop -- HIP forward + backward, FusedAdam, WarmUpCos -- against the CPU oracle driven by torch.optim.Adam on
+    the same rays and jitter: the loss trajectories must coincide step after step (an error in any gradient or in the update
+    shows up from the second step on).  Large lr on purpose, so that four steps move the loss visibly."""
+    import numpy as np
+    from helpers import oracle_cfg
+    from oracle import stage1_oracle as O
+    from nu_nerf_amd.renderer import NeROShapeRenderer
+    from nu_nerf_amd.params import init_stage1_params
+    from nu_nerf_amd.synthetic import make_rays, make_jitter
+    from nu_nerf_amd.loss import name2loss, SPHEREPOT_LOSSES, total_loss
+    from nu_nerf_amd.train_glue import FusedAdam
+    cfg = {'name': 't', 'network': 'shape', 'database_name': 'synthetic/64', 'is_nerf': True, 'apply_occ_loss': True,
+           'occ_loss_step': 15000, 'freeze_inv_s_step': 15000, 'eikonal_weight': 0.1,
+           'n_samples': 32, 'n_importance': 32, 'n_bg_samples': 16}
+    net = NeROShapeRenderer(cfg, training=False)
+    net.load_param_dict(init_stage1_params(6033))
+    net = net.to(gpu)
+    opt = FusedAdam(net.parameters(), lr=1.0)
+    losses = [name2loss[n](cfg) for n in SPHEREPOT_LOSSES]
+    params = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in init_stage1_params(6033).items()}
+    for k, v in params.items():
+        if not k.endswith('FG_LUT') and not k.startswith('infinity') and '.iors.' not in k:
+            v.requires_grad_(True)
+    oopt = torch.optim.Adam([p for p in params.values() if p.requires_grad], lr=1.0)
+    ocfg = oracle_cfg(eikonal_weight=0.1)          # helpers' golden config: 32 + 32 + 16 samples, occ loss from step 15000
+    R, step0 = 32, 6000
+    hist = []
+    for it in range(4):
+        rays = make_rays(R, seed=40 + it)
+        u1, u2 = make_jitter(R, 16, seed=50 + it)
+        lr = 2e-3 * (it + 1) / 4
+        for o in (opt, oopt):
+            for g in o.param_groups:
+                g['lr'] = lr
+        batch = {k: torch.from_numpy(rays[k]).to(gpu) for k in ('rays_o', 'rays_d', 'rgbs')}
+        opt.zero_grad(set_to_none=True)
+        out = net.train_step_rays(batch, step0 + it, rand=(torch.from_numpy(u1).to(gpu), torch.from_numpy(u2).to(gpu)))
+        total, _ = total_loss(out, losses, step0 + it)
+        total.backward()
+        opt.step()
+        oopt.zero_grad(set_to_none=True)
+        ototal, _, _ = O.train_step(params, ocfg, torch.from_numpy(rays['rays_o']), torch.from_numpy(rays['rays_d']),
+                                    torch.from_numpy(rays['rgbs']), step0 + it, rand=(torch.from_numpy(u1), torch.from_numpy(u2)))
+        ototal.backward()
+        oopt.step()
+        hist.append((float(total.detach()), float(ototal.detach())))
+    for it, (a, b) in enumerate(hist):
+        assert abs(a - b) <= 2e-4 * abs(b) * (1 + it), (it, hist)          # step 0: forward parity; later: the update too
+    assert abs(hist[0][1] - hist[3][1]) > 1e-3                             # the parameters really moved
