@@ -63,7 +63,8 @@ typedef struct NuGemmNT {      /* C[M,N] = epi(A[M,K] . B[N,K]^T);  K % 32 == 0,
     int groups;                /* grouped launch; element strides per group follow */
     long long sA, sB, sC, sC2, sBias, sH, sD, sCadd;
     int epi;                   /* enum NuEpi */
-    int bf16;                  /* 0: exact fp32 MFMA (default).  1: operands rounded to bf16 on load, bf16 MFMA, fp32 accumulate */
+    int bf16;                  /* 0: exact fp32 MFMA (default).  1: operands rounded to bf16 on load, bf16 MFMA, fp32 accumulate.
+                                  2: exact 3-way bf16 split of both operands, the six partial products >= 2^-16 (fp32-equivalent) */
     /* ReLU sign bits (optional): NU_EPI_BIAS_RELU writes, NU_EPI_MUL_DRELU / NU_EPI_B_RELU read them INSTEAD of H -- 2 KB per
      * 128x128 tile in place of 64 KB of activations.  Layout is private to the kernel (wave ballots per 4-row group):
      * cdiv(M,128) * mask_nct * 256 words, mask_nct = column tiles of the activation matrix as the WRITER saw it

@@ -51,12 +51,22 @@ __device__ unsigned long long nu_dbg_clk[2];
 // v_cvt_pk_bf16_f32) on their way into LDS and multiplied on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.
 // Activations and weights stay fp32 in HBM, so this build is bound by streaming them (HBM / L1), not by the
 // matrix pipe: 16x the MFMA rate buys ~3x on the K = 256 layers.
-template <int EPI, bool BF16>
-__global__ __launch_bounds__(256, NT_WPC) void gemm_nt_kernel(NuGemmNT g) {
-    __shared__ __attribute__((aligned(16))) float smem[2][TBM * NT_LDS];   // 36864 B; epilogue scratch aliases it
+//
+// PREC = 2 (mlp_dtype 'bf16x6'): fp32-equivalent products on the bf16 pipe.  Each fp32 operand is split EXACTLY into three
+// bf16 pieces (x = x1 + x2 + x3, 8 significant bits each); the six partial products of order >= 2^-16 (11, 12, 21, 13, 31,
+// 22) are exact in fp32 and are summed smallest first into the fp32 accumulator; the three dropped ones are below 2^-23
+// of |x||y|, i.e. at the level of ONE fp32 rounding of the product.  6 x 32 cycles replace 8 x 64 cycles of
+// v_mfma_f32_32x32x2_f32 per 16-deep k-step.
+template <int EPI, int PREC>
+__global__ __launch_bounds__(256, PREC == 2 ? 2 : NT_WPC) void gemm_nt_kernel(NuGemmNT g) {
+    constexpr bool BF16 = PREC == 1;
+    constexpr bool SPLIT = PREC == 2;
+    constexpr int kPlane = TBM * NT_LDSH;                       // bf16 elements of one [128][32 (+8 pad)] image
+    // fp32: 2 x 128 x 36 floats (36864 B).  bf16: 2 images.  split: 6 images (61440 B).  The epilogue scratch aliases it.
+    __shared__ __attribute__((aligned(16))) float smem[SPLIT ? 1 : 2][SPLIT ? 3 * kPlane : TBM * NT_LDS];
     // bf16 image: [128 rows][32 k] per operand, rows padded to NT_LDSH elements (80 B: b128 reads stay conflict-free)
     __bf16* const hA = reinterpret_cast<__bf16*>(&smem[0][0]);
-    __bf16* const hB = hA + TBM * NT_LDSH;
+    __bf16* const hB = hA + (SPLIT ? 3 : 1) * kPlane;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -118,12 +128,25 @@ __global__ __launch_bounds__(256, NT_WPC) void gemm_nt_kernel(NuGemmNT g) {
     auto store_regs = [&]() {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            if (BF16) {
+            if (SPLIT) {
+                bf16x4 p1, p2, p3;
+                nu_split3(ra4[i], p1, p2, p3);
+                __bf16* q = &hA[(r0 + 32 * i) * NT_LDSH + 4 * c4];
+                *reinterpret_cast<bf16x4*>(q) = p1;
+                *reinterpret_cast<bf16x4*>(q + kPlane) = p2;
+                *reinterpret_cast<bf16x4*>(q + 2 * kPlane) = p3;
+                nu_split3(rb4[i], p1, p2, p3);
+                q = &hB[(r0 + 32 * i) * NT_LDSH + 4 * c4];
+                *reinterpret_cast<bf16x4*>(q) = p1;
+                *reinterpret_cast<bf16x4*>(q + kPlane) = p2;
+                *reinterpret_cast<bf16x4*>(q + 2 * kPlane) = p3;
+            } else if (BF16) {
                 *reinterpret_cast<bf16x4*>(&hA[(r0 + 32 * i) * NT_LDSH + 4 * c4]) = nu_to_bf16x4(ra4[i]);
                 *reinterpret_cast<bf16x4*>(&hB[(r0 + 32 * i) * NT_LDSH + 4 * c4]) = nu_to_bf16x4(rb4[i]);
             } else {
-                *reinterpret_cast<f32x4*>(&smem[0][(r0 + 32 * i) * NT_LDS + 4 * c4]) = ra4[i];
-                *reinterpret_cast<f32x4*>(&smem[1][(r0 + 32 * i) * NT_LDS + 4 * c4]) = rb4[i];
+                float* s0 = &smem[0][0];
+                *reinterpret_cast<f32x4*>(&s0[(r0 + 32 * i) * NT_LDS + 4 * c4]) = ra4[i];
+                *reinterpret_cast<f32x4*>(&s0[TBM * NT_LDS + (r0 + 32 * i) * NT_LDS + 4 * c4]) = rb4[i];
             }
         }
     };
@@ -185,7 +208,32 @@ __global__ __launch_bounds__(256, NT_WPC) void gemm_nt_kernel(NuGemmNT g) {
                 set_ptrs(mtn, ntnx);
                 load_regs(0);
             }
-            if (BF16) {
+            if (SPLIT) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    bf16x8 a[2][3], b[2][3];
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int p = 0; p < 3; ++p) {
+                            a[t][p] = *reinterpret_cast<const bf16x8*>(&hA[p * kPlane + ah_off + 32 * t * NT_LDSH + 16 * ks]);
+                            b[t][p] = *reinterpret_cast<const bf16x8*>(&hB[p * kPlane + bh_off + 32 * t * NT_LDSH + 16 * ks]);
+                        }
+#pragma unroll
+                    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                        for (int tn = 0; tn < 2; ++tn) {
+                            f32x16 c = acc[tm][tn];
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][2], b[tn][0], c, 0, 0, 0);   // 2^-16 terms
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[tn][2], c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][1], b[tn][1], c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][1], b[tn][0], c, 0, 0, 0);   // 2^-8 terms
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[tn][1], c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[tn][0], c, 0, 0, 0);   // leading term
+                            acc[tm][tn] = c;
+                        }
+                }
+            } else if (BF16) {
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(&hA[ah_off + 16 * ks]);
@@ -198,8 +246,8 @@ __global__ __launch_bounds__(256, NT_WPC) void gemm_nt_kernel(NuGemmNT g) {
                     acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
                 }
             } else {
-                const float* As = smem[0];
-                const float* Bs = smem[1];
+                const float* As = &smem[0][0];
+                const float* Bs = As + TBM * NT_LDS;
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
                     f32x4 a0 = *reinterpret_cast<const f32x4*>(&As[a_off + kk * 8]);
@@ -335,13 +383,15 @@ int nu_gemm_nt_launch(const NuGemmNT& g, hipStream_t stream) {
         if (g.act_cols > 0 && (g.act_cols & 63)) return NU_ERR_ARG;
     }
     // persistent: NT_WPC workgroups per CU (256 CUs) shared over the groups, a multiple of 8 so the XCD grouping holds
-    static const int grid_target = getenv("NU_NT_GRID") ? atoi(getenv("NU_NT_GRID")) : 256 * NT_WPC;
+    static const int grid_env = getenv("NU_NT_GRID") ? atoi(getenv("NU_NT_GRID")) : 0;
+    const int grid_target = grid_env ? grid_env : 256 * (g.bf16 == 2 ? 2 : NT_WPC);   // workgroups the build keeps resident
     long long per = nu_rup(nu_cdiv(grid_target, groups), 8);
     if (per > nslots) per = nslots;
     dim3 grid((unsigned)per, 1, groups), block(256);
     switch (g.epi) {
-#define NU_CASE(E) case E: if (g.bf16) hipLaunchKernelGGL((gemm_nt_kernel<E, true>), grid, block, 0, stream, g); \
-                           else hipLaunchKernelGGL((gemm_nt_kernel<E, false>), grid, block, 0, stream, g); break;
+#define NU_CASE(E) case E: if (g.bf16 == 2) hipLaunchKernelGGL((gemm_nt_kernel<E, 2>), grid, block, 0, stream, g); \
+                           else if (g.bf16 == 1) hipLaunchKernelGGL((gemm_nt_kernel<E, 1>), grid, block, 0, stream, g); \
+                           else hipLaunchKernelGGL((gemm_nt_kernel<E, 0>), grid, block, 0, stream, g); break;
         NU_CASE(NU_EPI_BIAS_NONE)
         NU_CASE(NU_EPI_BIAS_RELU)
         NU_CASE(NU_EPI_BIAS_SOFTPLUS)
@@ -365,11 +415,14 @@ int nu_gemm_nt_launch(const NuGemmNT& g, hipStream_t stream) {
 // inner loop is exactly the NT kernel's (one ds_read_b128 feeds four MFMA k-steps) and nothing consumes a global
 // load before the hand-over to LDS -- the loads stay in flight under the 64 MFMAs of the current chunk.
 // BIG = operands of 4 GiB or more (64-bit element offsets instead of one uniform base + a 32-bit byte offset).
-template <bool BIG, bool BF16>
+template <bool BIG, int PREC>
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(NuGemmTN g) {
-    __shared__ __attribute__((aligned(16))) float smem[2][128 * NT_LDS];
-    __bf16* const hA = reinterpret_cast<__bf16*>(&smem[0][0]);      // bf16 image, as in the NT kernel
-    __bf16* const hB = hA + 128 * NT_LDSH;
+    constexpr bool BF16 = PREC == 1;
+    constexpr bool SPLIT = PREC == 2;                 // exact three-way bf16 split, six partial products (see the NT kernel)
+    constexpr int kPlane = 128 * NT_LDSH;
+    __shared__ __attribute__((aligned(16))) float smem[SPLIT ? 1 : 2][SPLIT ? 3 * kPlane : 128 * NT_LDS];
+    __bf16* const hA = reinterpret_cast<__bf16*>(&smem[0][0]);      // bf16 image(s), as in the NT kernel
+    __bf16* const hB = hA + (SPLIT ? 3 : 1) * kPlane;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -452,12 +505,25 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(NuGemmTN g) {
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            if (BF16) {
+            if (SPLIT) {
+                bf16x4 p1, p2, p3;
+                nu_split3(ra4[i], p1, p2, p3);
+                __bf16* q = &hA[c * NT_LDSH + kg * 16 + 4 * i];
+                *reinterpret_cast<bf16x4*>(q) = p1;
+                *reinterpret_cast<bf16x4*>(q + kPlane) = p2;
+                *reinterpret_cast<bf16x4*>(q + 2 * kPlane) = p3;
+                nu_split3(rb4[i], p1, p2, p3);
+                q = &hB[c * NT_LDSH + kg * 16 + 4 * i];
+                *reinterpret_cast<bf16x4*>(q) = p1;
+                *reinterpret_cast<bf16x4*>(q + kPlane) = p2;
+                *reinterpret_cast<bf16x4*>(q + 2 * kPlane) = p3;
+            } else if (BF16) {
                 *reinterpret_cast<bf16x4*>(&hA[c * NT_LDSH + kg * 16 + 4 * i]) = nu_to_bf16x4(ra4[i]);
                 *reinterpret_cast<bf16x4*>(&hB[c * NT_LDSH + kg * 16 + 4 * i]) = nu_to_bf16x4(rb4[i]);
             } else {
-                *reinterpret_cast<f32x4*>(&smem[0][c * NT_LDS + kg * 16 + 4 * i]) = ra4[i];
-                *reinterpret_cast<f32x4*>(&smem[1][c * NT_LDS + kg * 16 + 4 * i]) = rb4[i];
+                float* s0 = &smem[0][0];
+                *reinterpret_cast<f32x4*>(&s0[c * NT_LDS + kg * 16 + 4 * i]) = ra4[i];
+                *reinterpret_cast<f32x4*>(&s0[128 * NT_LDS + c * NT_LDS + kg * 16 + 4 * i]) = rb4[i];
             }
         }
     };
@@ -475,7 +541,32 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(NuGemmTN g) {
     const int bh_off = (wc * 64 + li) * NT_LDSH + 8 * lh;
     for (int t = 0; t < total; ++t) {
         if (t + 1 < total) load_tile(t + 1);
-        if (BF16) {
+        if (SPLIT) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 a[2][3], b[2][3];
+#pragma unroll
+                for (int t2_ = 0; t2_ < 2; ++t2_)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) {
+                        a[t2_][p] = *reinterpret_cast<const bf16x8*>(&hA[p * kPlane + ah_off + 32 * t2_ * NT_LDSH + 16 * ks]);
+                        b[t2_][p] = *reinterpret_cast<const bf16x8*>(&hB[p * kPlane + bh_off + 32 * t2_ * NT_LDSH + 16 * ks]);
+                    }
+#pragma unroll
+                for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < 2; ++tn) {
+                        f32x16 cacc = acc[tm][tn];
+                        cacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][2], b[tn][0], cacc, 0, 0, 0);
+                        cacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[tn][2], cacc, 0, 0, 0);
+                        cacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][1], b[tn][1], cacc, 0, 0, 0);
+                        cacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][1], b[tn][0], cacc, 0, 0, 0);
+                        cacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[tn][1], cacc, 0, 0, 0);
+                        cacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[tn][0], cacc, 0, 0, 0);
+                        acc[tm][tn] = cacc;
+                    }
+            }
+        } else if (BF16) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(&hA[ah_off + 16 * ks]);
@@ -490,10 +581,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(NuGemmTN g) {
         } else {
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
-                const f32x4 a0 = *reinterpret_cast<const f32x4*>(&smem[0][a_off + kk * 8]);
-                const f32x4 a1 = *reinterpret_cast<const f32x4*>(&smem[0][a_off + 32 * NT_LDS + kk * 8]);
-                const f32x4 b0 = *reinterpret_cast<const f32x4*>(&smem[1][b_off + kk * 8]);
-                const f32x4 b1 = *reinterpret_cast<const f32x4*>(&smem[1][b_off + 32 * NT_LDS + kk * 8]);
+                const float* As = &smem[0][0];
+                const float* Bs = As + 128 * NT_LDS;
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(&As[a_off + kk * 8]);
+                const f32x4 a1 = *reinterpret_cast<const f32x4*>(&As[a_off + 32 * NT_LDS + kk * 8]);
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(&Bs[b_off + kk * 8]);
+                const f32x4 b1 = *reinterpret_cast<const f32x4*>(&Bs[b_off + 32 * NT_LDS + kk * 8]);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b0[e], acc[0][0], 0, 0, 0);
@@ -538,10 +631,15 @@ int nu_gemm_tn_launch(const NuGemmTN& g, hipStream_t stream) {
     const long long max_ld = (g.lda0 > g.ldb0 ? g.lda0 : g.ldb0) > (g.A1 ? (g.lda1 > g.ldb1 ? g.lda1 : g.ldb1) : 0)
                                  ? (g.lda0 > g.ldb0 ? g.lda0 : g.ldb0) : (g.lda1 > g.ldb1 ? g.lda1 : g.ldb1);
     const bool big = (long long)g.P * max_ld * 4 >= (1LL << 32);
-    if (big && g.bf16) hipLaunchKernelGGL((gemm_tn_kernel<true, true>), grid, block, 0, stream, g);
-    else if (big) hipLaunchKernelGGL((gemm_tn_kernel<true, false>), grid, block, 0, stream, g);
-    else if (g.bf16) hipLaunchKernelGGL((gemm_tn_kernel<false, true>), grid, block, 0, stream, g);
-    else hipLaunchKernelGGL((gemm_tn_kernel<false, false>), grid, block, 0, stream, g);
+    if (big) {
+        if (g.bf16 == 2) hipLaunchKernelGGL((gemm_tn_kernel<true, 2>), grid, block, 0, stream, g);
+        else if (g.bf16 == 1) hipLaunchKernelGGL((gemm_tn_kernel<true, 1>), grid, block, 0, stream, g);
+        else hipLaunchKernelGGL((gemm_tn_kernel<true, 0>), grid, block, 0, stream, g);
+    } else {
+        if (g.bf16 == 2) hipLaunchKernelGGL((gemm_tn_kernel<false, 2>), grid, block, 0, stream, g);
+        else if (g.bf16 == 1) hipLaunchKernelGGL((gemm_tn_kernel<false, 1>), grid, block, 0, stream, g);
+        else hipLaunchKernelGGL((gemm_tn_kernel<false, 0>), grid, block, 0, stream, g);
+    }
     return nu_launch_status();
 }
 
@@ -722,8 +820,8 @@ extern "C" int nu_wgrad(const NuGemmTN* gin, float* dW, int ldw, long long sW, f
 // development aid: occupancy query for the two GEMM kernels (blocks per CU)
 extern "C" int nu_debug_occupancy(int which) {
     int n = -1;
-    if (which == 0) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (gemm_nt_kernel<NU_EPI_BIAS_SOFTPLUS, false>), 256, 0);
-    else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (gemm_tn_kernel<false, false>), 256, 0);
+    if (which == 0) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (gemm_nt_kernel<NU_EPI_BIAS_SOFTPLUS, 0>), 256, 0);
+    else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (gemm_tn_kernel<false, 0>), 256, 0);
     return n;
 }
 

@@ -21,6 +21,18 @@ static __device__ inline bf16x4 nu_to_bf16x4(f32x4 v) {
     o[0] = (__bf16)v[0]; o[1] = (__bf16)v[1]; o[2] = (__bf16)v[2]; o[3] = (__bf16)v[3];
     return o;
 }
+// exact three-way split of fp32 into bf16 pieces: v = p1 + p2 + p3 (each subtraction below is exact in fp32)
+static __device__ inline void nu_split3(f32x4 v, bf16x4& p1, bf16x4& p2, bf16x4& p3) {
+#pragma clang fp contract(off)
+    p1 = nu_to_bf16x4(v);
+    f32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = v[e] - (float)p1[e];
+    p2 = nu_to_bf16x4(r);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = r[e] - (float)p2[e];
+    p3 = nu_to_bf16x4(r);
+}
 
 // ceil-div / round-up helpers (host + device)
 static __host__ __device__ inline int nu_cdiv(int a, int b) { return (a + b - 1) / b; }

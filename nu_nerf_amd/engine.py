@@ -109,10 +109,11 @@ class Stage1Engine:
         assert lib.nu_gemm_nt_size() == ctypes.sizeof(GemmNT) and lib.nu_gemm_tn_size() == ctypes.sizeof(GemmTN), "GEMM ABI mismatch"
         # MLP arithmetic: 'fp32' = exact fp32 MFMA (the reference's precision); 'bf16' = operands rounded to bf16 on their
         # way into LDS, bf16 MFMA with fp32 accumulation (BASELINE config 4; no reference counterpart, tolerance in the tests)
-        md = str(cfg.get('mlp_dtype', 'fp32')).lower()
-        if md not in ('fp32', 'f32', 'float32', 'bf16', 'bfloat16'):
-            raise ValueError(f"mlp_dtype {md!r}: expected 'fp32' or 'bf16'")
-        self.bf16 = 1 if md.startswith('b') else 0
+        md = str(cfg.get('mlp_dtype', os.environ.get('NU_MLP_DTYPE', 'fp32'))).lower()   # env: run a whole test suite in one mode
+        if md not in ('fp32', 'f32', 'float32', 'bf16', 'bfloat16', 'bf16x6'):
+            raise ValueError(f"mlp_dtype {md!r}: expected 'fp32', 'bf16' or 'bf16x6'")
+        # 'bf16x6': fp32-equivalent products on the bf16 pipe (exact 3-way split of both operands, six partial products)
+        self.bf16 = 2 if md == 'bf16x6' else (1 if md.startswith('b') else 0)
         # deferred split reductions (weight gradients, skinny heads, column sums): partial slabs live in a bump arena
         # until flush_reductions() sums them all in a few batched launches (before unpack_grads reads the results)
         self._rd_cap = 1024

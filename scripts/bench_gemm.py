@@ -63,13 +63,13 @@ if __name__ == "__main__":
     tn(131072, 1024, 288, 1, 32)
 
 
-def nt_bf16(M, N, K, epi):
+def nt_bf16(M, N, K, epi, prec=1):
     A = torch.randn(M, K, device=dev)
     B = torch.randn((N + 127) // 128 * 128, K, device=dev) / K ** 0.5
     C = torch.empty(M, N, device=dev); C2 = torch.empty(M, N, device=dev)
     H = torch.rand(M, N, device=dev) * 0.02; D = torch.randn(M, N, device=dev); b = torch.randn(N, device=dev)
     g = GemmNT(addr(A), K, addr(B), K, M, N, K, addr(C), N, addr(C2), N, addr(b), addr(H), N, addr(D), N, addr(D), N,
-               0, 0, 1.0, 1, 0, 0, 0, 0, 0, 0, 0, 0, epi, 1)
+               0, 0, 1.0, 1, 0, 0, 0, 0, 0, 0, 0, 0, epi, prec)
     ms = time_it(lambda: L.check(lib.nu_gemm_nt_ex(ctypes.byref(g), L.stream()), "nt"))
     byts = 4.0 * (M * K + M * N * (2 if epi in (3, 4, 6, 8) else 1))
-    print(f"NT bf16 M={M:7d} N={N:4d} K={K:4d} epi={epi}: {ms*1e3:8.1f} us  {2.0*M*N*K/ms/1e9:6.1f} TFLOP/s  {byts/ms/1e9:5.2f} TB/s algorithmic")
+    print(f"NT prec{prec} M={M:7d} N={N:4d} K={K:4d} epi={epi}: {ms*1e3:8.1f} us  {2.0*M*N*K/ms/1e9:6.1f} TFLOP/s  {byts/ms/1e9:5.2f} TB/s algorithmic")

@@ -246,6 +246,58 @@ def test_bf16_tn_weight_grad(gpu, P, N1, N2, S):
     torch.testing.assert_close(bo.double(), A0[:, :N1].double().sum(0), rtol=2e-5, atol=tol)   # bias sums stay fp32
 
 
+@pytest.mark.parametrize("M,N,K", [(1, 1, 32), (300, 217, 256), (1000, 257, 288), (4099, 256, 96), (2048, 256, 1024)])
+def test_bf16x6_nt_is_fp32_equivalent(gpu, M, N, K):
+    """mlp_dtype 'bf16x6': exact 3-way bf16 split of both operands, six partial products.  Against fp64 on the UNROUNDED
+    operands it must be as accurate as the fp32-MFMA kernel (same tolerance as test_nt_bias_epilogues), and its distance to
+    the fp32-MFMA result must stay at the level of fp32 summation noise -- wide dynamic range included."""
+    from nu_nerf_amd import _lib as L
+    from nu_nerf_amd.engine import GemmNT, addr
+    lib = L.load()
+    torch.manual_seed(M + N + K)
+    A = torch.randn(M, K, device=gpu) * torch.exp(3 * torch.randn(M, 1, device=gpu))      # rows spanning ~5 decades
+    W = torch.randn(N, K, device=gpu) / K ** 0.5
+    B = _packB(W, K)
+    bias = torch.randn(N, device=gpu)
+    ref = A.double() @ W.double().t() + bias.double()
+    scale = (A.double().abs() @ W.double().abs().t()) + bias.double().abs()                # |a|.|b| + |bias| mass of every output
+    out = {}
+    for prec in (0, 2):
+        C = torch.full((M, N), float("nan"), device=gpu)
+        g = GemmNT(addr(A), K, addr(B), K, M, N, K, addr(C), N, 0, 0, addr(bias), 0, 0, 0, 0, 0, 0, 0, 0, 1.0, 1,
+                   0, 0, 0, 0, 0, 0, 0, 0, 0, prec)
+        L.check(lib.nu_gemm_nt_ex(ctypes.byref(g), L.stream()), "nu_gemm_nt_ex")
+        out[prec] = C.double()
+        err = ((C.double() - ref).abs() / (scale + 1e-30)).max()
+        assert float(err) < 4e-7 * max(1.0, K ** 0.5 / 4), (prec, float(err))             # ~ a few fp32 ulps of the mass
+    rel = ((out[2] - out[0]).abs() / (scale + 1e-30)).max()
+    assert float(rel) < 4e-7 * max(1.0, K ** 0.5 / 4), float(rel)
+
+
+@pytest.mark.parametrize("P,N1,N2,S", [(1000, 257, 256, 7), (5000, 256, 39, 16), (70000, 128, 288, 32)])
+def test_bf16x6_tn_is_fp32_equivalent(gpu, P, N1, N2, S):
+    from nu_nerf_amd import _lib as L
+    from nu_nerf_amd.engine import GemmTN, addr
+    lib = L.load()
+    lib.nu_wgrad_workspace_bytes.restype = ctypes.c_longlong
+    torch.manual_seed(P)
+    lda, ldb = (N1 + 3) // 4 * 4 + 4, (N2 + 3) // 4 * 4
+    A0, B0 = torch.randn(P, lda, device=gpu), torch.randn(P, ldb, device=gpu) * torch.exp(2 * torch.randn(P, 1, device=gpu))
+    wsb = lib.nu_wgrad_workspace_bytes(N1, N2, S, 1)
+    ws = torch.empty(wsb // 4, device=gpu)
+    ref = A0[:, :N1].double().t() @ B0[:, :N2].double()
+    scale = A0[:, :N1].double().abs().t() @ B0[:, :N2].double().abs()
+    for prec in (0, 2):
+        C = torch.full((N1, N2), float("nan"), device=gpu)
+        bo = torch.full((N1,), float("nan"), device=gpu)
+        g = GemmTN(addr(A0), lda, addr(B0), ldb, 0, 0, 0, 0, P, N1, N2, 0, 0, S, 1, 0, 0, 0, 0, 0, 0, prec, 0)
+        L.check(lib.nu_wgrad(ctypes.byref(g), L.ptr(C), N2, ctypes.c_longlong(0), L.ptr(bo), ctypes.c_longlong(0), L.ptr(ws),
+                             ctypes.c_longlong(wsb), L.stream()), "nu_wgrad")
+        err = ((C.double() - ref).abs() / (scale + 1e-30)).max()
+        assert float(err) < 2e-6, (prec, float(err))
+        torch.testing.assert_close(bo.double(), A0[:, :N1].double().sum(0), rtol=2e-5, atol=3e-5 * P ** 0.5)
+
+
 def test_gemm_throughput_smoke(gpu):
     """Not a pass/fail perf gate: prints achieved TFLOP/s of the 256x256 layer GEMM."""
     M, N, K = 262144, 256, 256

@@ -118,15 +118,19 @@ def test_sampler_matches_oracle(net, gpu):
         np.testing.assert_allclose(z[:, :1].numpy(), zr[:, :1].numpy(), rtol=1e-6)   # first coarse sample: exact formula
 
 
+@pytest.mark.parametrize("mlp_dtype", ["fp32", "bf16x6"])
 @pytest.mark.parametrize("name", ["train_step0_r48.npz", "train_step20000_r48.npz", "train_step500_r32_noperturb.npz"])
-def test_full_train_step_vs_reference_golden(gpu, name):
+def test_full_train_step_vs_reference_golden(gpu, name, mlp_dtype):
+    """mlp_dtype 'fp32' = exact fp32 MFMA (the default, the headline).  'bf16x6' = the fp32-equivalent split mode (exact
+    3-way bf16 split of both operands, six partial products): held to the SAME reference vectors and the SAME tolerances."""
     from nu_nerf_amd.loss import name2loss, SPHEREPOT_LOSSES, total_loss
     g = golden(name)
     step = int(g['step'])
-    cfg = dict(CFG)
+    cfg = dict(CFG, mlp_dtype=mlp_dtype)
     if 'noperturb' in name:
         cfg['perturb'] = 0.0
     net = make_net(gpu, cfg)
+    assert net.engine().bf16 == (2 if mlp_dtype == 'bf16x6' else 0)
     batch = {k: torch.from_numpy(g[k]).to(gpu) for k in ('rays_o', 'rays_d', 'rgbs')}
     rand = (torch.from_numpy(g['u1']).to(gpu), torch.from_numpy(g['u2']).to(gpu))
     out = net.train_step_rays(batch, step, rand=rand)
