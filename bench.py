@@ -220,7 +220,7 @@ def main():
         opt.zero_grad(set_to_none=True)
         out = net.train_step_rays(batch_for(it), step)
         if reducer is not None:     # eikonal mean over the union of all ranks' inner points (exact data parallelism)
-            out['gradient_error'] = out['gradient_error'] * reducer.point_weight(eng.last_ctx['P_in'], dev)
+            out['gradient_error'] = out['gradient_error'] * reducer.point_weight(eng.last_ctx['P_in_dev'], dev)
         total, _ = total_loss(out, losses, step)
         total.backward()
         if reducer is not None:

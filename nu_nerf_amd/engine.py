@@ -892,7 +892,7 @@ class Stage1Engine:
                                        c_p(addr(idx_in)), c_p(addr(pt_out)), c_p(addr(idx_out)), c_p(addr(inner_rm)), S_),
                 "nu_partition_write")
         alpha_rm, color_rm = e(R * S), e(R * S, 4)
-        ctx = dict(R=R, S=S, P_in=P_in, P_out=P_out, pt_in=pt_in, idx_in=idx_in, pt_out=pt_out, idx_out=idx_out,
+        ctx = dict(R=R, S=S, P_in=P_in, P_out=P_out, P_in_dev=tot[:1], pt_in=pt_in, idx_in=idx_in, pt_out=pt_out, idx_out=idx_out,
                    inner_rm=inner_rm, alpha_rm=alpha_rm, color_rm=color_rm, anneal=float(anneal))
         if P_out > 0:
             ctx['nerf'] = self.nerf_forward(pt_out, idx_out, P_out, alpha_rm, color_rm)

@@ -82,7 +82,10 @@ class GradAllReducer:
         """Factor that turns a per-rank mean over n_local points into this rank's share of the mean over the union batch:
         n_local * world / sum_r n_r (a device scalar; no host sync).  Multiply a per-point loss input by it (e.g.
         outputs['gradient_error']) and the all-reduced gradient equals the single-process gradient over all ranks' rays."""
-        n = torch.tensor([float(n_local)], device=device)
+        if torch.is_tensor(n_local):       # a device-resident count (engine ctx['P_in_dev']): no host -> device copy at all
+            n = n_local.reshape(-1)[:1].to(device=device, dtype=torch.float32)
+        else:
+            n = torch.tensor([float(n_local)], device=device)
         if self.world <= 1:
             return torch.ones(1, device=device)
         tot = n.clone()

@@ -145,6 +145,8 @@ def _dp_worker(rank, world, port, q):
     # mean over all 40 points
     w = red.point_weight(10 if rank == 0 else 30, torch.device('cpu'))
     ok &= abs(float(w) - (0.5 if rank == 0 else 1.5)) < 1e-6
+    w2 = red.point_weight(torch.tensor([10 if rank == 0 else 30, 7], dtype=torch.int32), torch.device('cpu'))   # device-count form
+    ok &= abs(float(w2) - float(w)) < 1e-6
     vals = torch.arange(10.) if rank == 0 else 10.0 + torch.arange(30.)
     share = torch.mean(vals * w).reshape(1)
     dist.all_reduce(share)
