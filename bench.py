@@ -3,7 +3,8 @@ synthetic workload (BASELINE.json configs[1]: 4096 rays/batch, 64 coarse + 64 im
 samples, fp32), one process per GPU, ray batches sharded data-parallel with an RCCL all-reduce of the
 parameter gradients.
 
-    python bench.py --gpus N --steps K --warmup W            (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W            (N>1: under torch.distributed.run, or bare -- it then starts
+                                                              the N ranks itself and refuses to run on fewer GPUs)
 
 A step = ray fetch (device-resident pool) -> sampler -> render_core forward -> loss -> backward -> [all-reduce]
 -> Adam.  Rank 0 prints ONE JSON line.  Extra objects:
@@ -81,6 +82,38 @@ def cpu_baseline(rays_cpu, step0, budget_s=20.0):
                       f"{ms:.0f} ms/iter, torch CPU fp32, os.cpu_count()={os.cpu_count()}"}
 
 
+def spawn_ranks_or_die(args):
+    """Fail-closed multi-GPU launch.  `--gpus N` must mean N ranks on N GPUs:
+      * launched by torch.distributed.run (WORLD_SIZE set): WORLD_SIZE must equal --gpus, otherwise exit 2;
+      * launched bare with --gpus N > 1: this process has made no GPU call yet, so it starts
+        `python -m torch.distributed.run --nproc-per-node N ... bench.py <same args>` as a CHILD process (no exec) and exits
+        with its code; if the box shows fewer than N devices it exits 2 with a message instead of measuring one GPU.
+    NU_BENCH_DEVICE / NU_BENCH_BACKEND=gloo (all ranks on one card) exist to rehearse the multi-process path on a one-GPU box."""
+    world_env = os.environ.get('WORLD_SIZE')
+    if world_env is not None:
+        if int(world_env) != args.gpus:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world_env}: refusing to report a {args.gpus}-GPU number "
+                  f"from {world_env} rank(s)", file=sys.stderr, flush=True)
+            raise SystemExit(2)
+        return
+    if args.gpus == 1:
+        return
+    n_dev = torch.cuda.device_count()            # counting devices does not initialise the GPU runtime on this image
+    rehearsal = 'NU_BENCH_DEVICE' in os.environ
+    if n_dev < args.gpus and not rehearsal:
+        print(f"bench.py: --gpus {args.gpus} needs {args.gpus} visible GPUs, this box shows {n_dev}: refusing to run",
+              file=sys.stderr, flush=True)
+        raise SystemExit(2)
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd))
+
+
 def main_stage2(args):
     """BASELINE.json configs[2]: stage-2 training step (refraction through the stage-1 mesh, learned IoR, 3 bounces) on ONE
     GPU: 4096 rays, icosphere(r=0.5) with 20480 faces standing in for the stage-1 mesh, segment samples 256/128/256.  A parity
@@ -145,9 +178,10 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--workload', default='stage1', choices=['stage1', 'stage2'],
                     help="'stage1' = the headline (BASELINE configs[1]); 'stage2' = configs[2] on one GPU (a parity case, see DESIGN 9)")
-    ap.add_argument('--object-rays', action='store_true', help='stage2 only: aim every ray at the object (all three bounces)')
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--object-rays', action='store_true',
+                    help='aim every ray at the object: stage 1 -> inner-point share ~0.5 (the shading stack dominates); stage 2 -> all three bounces')
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--rays', type=int, default=4096, help='rays per GPU per step')
     ap.add_argument('--start-step', type=int, default=20000, help='training-step index of the first iteration')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -161,10 +195,11 @@ def main():
                          'step in the middle of it (the ~330 event pairs cost that step 2-4 ms)')
     args = ap.parse_args()
     if args.workload == 'stage2':
-        if int(os.environ.get('WORLD_SIZE', 1)) != 1:
+        if int(os.environ.get('WORLD_SIZE', 1)) != 1 or args.gpus != 1:
             raise SystemExit("--workload stage2 runs on one GPU")
         return main_stage2(args)
 
+    spawn_ranks_or_die(args)        # --gpus N without a launcher: start the N ranks ourselves (never returns in the parent)
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
@@ -180,11 +215,14 @@ def main():
             dist.init_process_group('nccl', device_id=dev)
         else:
             dist.init_process_group(backend)
-    assert world == args.gpus or world == 1, (world, args.gpus)
+    rccl_ranks = dist.get_world_size() if world > 1 else 1
+    if rccl_ranks != args.gpus:
+        raise SystemExit(f"bench.py: process group has {rccl_ranks} rank(s), --gpus {args.gpus}")
+    coll_backend = dist.get_backend() if world > 1 else None
 
     from nu_nerf_amd.renderer import NeROShapeRenderer
     from nu_nerf_amd.params import init_stage1_params
-    from nu_nerf_amd.synthetic import make_rays
+    from nu_nerf_amd.synthetic import make_rays, make_object_rays
     from nu_nerf_amd.loss import name2loss, SPHEREPOT_LOSSES, total_loss
     from nu_nerf_amd.parallel import GradAllReducer
     from nu_nerf_amd.train_glue import FusedAdam
@@ -202,7 +240,9 @@ def main():
 
     # device-resident ray pool; every rank draws a disjoint slice of the same seeded permutation
     n_iter = args.steps + args.warmup
-    pool = make_rays(R * world * min(n_iter, 16), seed=6033)
+    # --object-rays: every ray aimed at the unit sphere's interior (inner-point share ~0.5, the survey's 8.1 TFLOP/iter case:
+    # SURVEY 8(d)) instead of full camera frusta (share ~0.19: most image rays miss the sphere)
+    pool = (make_object_rays if args.object_rays else make_rays)(R * world * min(n_iter, 16), seed=6033)
     pool_dev = {k: torch.from_numpy(v).to(dev) for k, v in pool.items() if k != 'idxs'}
 
     def batch_for(it):
@@ -269,6 +309,7 @@ def main():
     if rank == 0:
         ms = 1e3 * elapsed / args.steps
         value = R * world * args.steps / elapsed
+        step_ms = np.array([step_ev[i].elapsed_time(step_ev[i + 1]) for i in range(args.steps)])   # rank 0's stream
         if args.real_capture or args.mlp_dtype != 'fp32':
             workload = ("stage-1 train step, %s code path, %d rays/GPU x (64 + 64 + 32) samples, %s MLP GEMMs (fp32 accumulate), "
                         "synthetic cameras (BASELINE.json configs[3] when --real-capture --rays 8192 --mlp-dtype bf16)"
@@ -279,18 +320,21 @@ def main():
                         "samples, fp32, synthetic cameras (BASELINE.json configs[1])" % R)
         res = {
             "metric": "train rays/sec", "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+            "warmup": args.warmup, "ms_per_step": ms, "median_ms_per_step": float(np.median(step_ms)),
+            "p10_ms_per_step": float(np.percentile(step_ms, 10)), "p90_ms_per_step": float(np.percentile(step_ms, 90)),
+            "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": {"fp32": "f32", "bf16": "bf16", "bf16x6": "bf16x6 (exact 3-way split, fp32-equivalent)"}[args.mlp_dtype],
             "data": "synthetic",
             "config": {"workload": workload,
                        "rays_per_gpu": R, "global_rays": R * world, "samples_per_ray": 160, "start_step": args.start_step,
-                       "parallelism": "dp%d" % world,
+                       "parallelism": "dp%d" % world, "rccl_ranks": rccl_ranks, "collective_backend": coll_backend,
+                       "rays": "object-aimed (make_object_rays)" if args.object_rays else "Spherepot-shaped camera frusta",
                        "grad_all_reduce": None if reducer is None else
                        ("in place on the flat gradient buffer" if reducer.gathered_calls == 0 else
                         "gathered (%d of %d steps)" % (reducer.gathered_calls, reducer.gathered_calls + reducer.in_place_calls)),
                        "mean_inner_points": stats['P_in'] / args.steps, "mean_outer_points": stats['P_out'] / args.steps,
                        "final_loss": float(last.detach()),
-                       "step_ms": [round(step_ev[i].elapsed_time(step_ev[i + 1]), 2) for i in range(args.steps)],
+                       "step_ms": [round(float(v), 2) for v in step_ms],
                        "new_device_segments_per_step": [seg_count[i + 1] - seg_count[i] for i in range(args.steps)]},
         }
         if ktime is not None:

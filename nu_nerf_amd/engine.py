@@ -933,11 +933,13 @@ class Stage1Engine:
         R, S, P_in, P_out = ctx['R'], ctx['S'], ctx['P_in'], ctx['P_out']
         flat = self.zeros(self.n_grad)
         dalpha_rm, dcolor_rm = e(R * S), e(R * S, 4)
+        # contiguous copies are named locals: they must outlive the launches that read them (a temporary inside the argument
+        # list dies as soon as addr() returns and its block may be handed to the next allocation)
+        d_rgb, d_acc, d_rgb_bg, d_nrm_sum, d_gerr = (None if t is None else t.contiguous()
+                                                     for t in (d_rgb, d_acc, d_rgb_bg, d_nrm_sum, d_gerr))
         L.check(lib.nu_composite_bwd(c_p(addr(ctx['alpha_rm'])), c_p(addr(ctx['color_rm'])), c_p(addr(ctx['inner_rm'])),
-                                     R, S, c_p(addr(d_rgb.contiguous())), c_p(addr(d_acc.contiguous()) if d_acc is not None else 0),
-                                     c_p(addr(d_rgb_bg.contiguous()) if d_rgb_bg is not None else 0),
-                                     c_p(addr(d_nrm_sum.contiguous()) if d_nrm_sum is not None else 0), c_p(addr(dalpha_rm)),
-                                     c_p(addr(dcolor_rm)), S_), "nu_composite_bwd")
+                                     R, S, c_p(addr(d_rgb)), c_p(addr(d_acc)), c_p(addr(d_rgb_bg)), c_p(addr(d_nrm_sum)),
+                                     c_p(addr(dalpha_rm)), c_p(addr(dcolor_rm)), S_), "nu_composite_bwd")
         if P_out > 0:
             self.nerf_backward(ctx['nerf'], ctx['pt_out'], ctx['idx_out'], dalpha_rm, dcolor_rm, flat)
         else:
@@ -953,7 +955,7 @@ class Stage1Engine:
             var = self.p['deviation_network.variance']
             L.check(lib.nu_neus_alpha_bwd(c_p(addr(a['YX'])), 288, c_p(addr(a['n'])), c_p(addr(ctx['pt_in'])),
                                           c_p(addr(ctx['idx_in'])), P_in, c_p(addr(var)), c_f(ctx['anneal']),
-                                          c_p(addr(dalpha_rm)), c_p(addr(d_gerr.contiguous()) if d_gerr is not None else 0),
+                                          c_p(addr(dalpha_rm)), c_p(addr(d_gerr)),
                                           c_p(addr(dn)), c_p(addr(dcolor_rm) if d_nrm_sum is not None else 0), c_p(addr(dYX)), 288,
                                           c_p(addr(nbar)),
                                           c_p(addr(flat, self.var_off) if train_inv_s else 0), S_), "nu_neus_alpha_bwd")

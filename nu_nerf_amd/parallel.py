@@ -33,28 +33,34 @@ class GradAllReducer:
 
     def _shared_flat(self):
         """The renderer's backward hands out every gradient as a slice of ONE flat buffer (engine.grad_views order) and
-        autograd keeps those slices (it detaches, it does not copy): when the .grad tensors tile one storage range exactly,
-        the collective runs on that range in place -- no gather, no scatter."""
-        g0 = self.params[0].grad
-        if g0 is None:
+        autograd keeps those slices (it detaches, it does not copy): when the .grad tensors tile one storage range, the
+        collective runs on that range in place -- no gather, no scatter.  A parameter WITHOUT a gradient this step
+        (deviation_network.variance while step < freeze_inv_s_step: every rank alike, the step decides) may leave a hole of
+        at most its own size inside the range: the hole is part of the same zero-initialised buffer, is reduced along with the
+        rest and stays unobserved -- .grad stays None, so Adam creates no state for it (as in the 1-GPU run)."""
+        live = [p.grad for p in self.params if p.grad is not None]
+        if not live:
             return None
+        missing = sum(p.numel() for p in self.params if p.grad is None)
+        g0 = live[0]
         store = g0.untyped_storage()
         sp = store.data_ptr()
         lo, hi, tot = None, None, 0
-        for p in self.params:
-            g = p.grad
-            if g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.untyped_storage().data_ptr() != sp:
+        for g in live:
+            if g.dtype != torch.float32 or not g.is_contiguous() or g.untyped_storage().data_ptr() != sp:
                 return None
             o, n = g.storage_offset(), g.numel()
             lo = o if lo is None else min(lo, o)
             hi = o + n if hi is None else max(hi, o + n)
             tot += n
-        if tot != self.numel or hi - lo != self.numel:      # gaps or overlaps: not one clean range
+        if tot + missing != self.numel or not (tot <= hi - lo <= tot + missing):     # overlaps, or gaps nobody owns
             return None
-        return torch.empty(0, dtype=torch.float32, device=g0.device).set_(store, lo, (self.numel,), (1,))
+        return torch.empty(0, dtype=torch.float32, device=g0.device).set_(store, lo, (hi - lo,), (1,))
 
     def all_reduce(self):
-        """Sum the gradients over ranks and divide by the world size (in place on every .grad): one collective."""
+        """Sum the gradients over ranks and divide by the world size (in place on every .grad): one collective.
+        Parameters whose .grad is None are left alone (no zero gradient is materialised for them): which parameters have a
+        gradient is decided by the step index and the loss set, identically on every rank."""
         if self.world <= 1:
             return
         flat = self._shared_flat()
@@ -64,11 +70,10 @@ class GradAllReducer:
             self.in_place_calls += 1
             return
         self.gathered_calls += 1
-        # general case (gradients from other sources, or missing): one gather, one collective, one multi-tensor scatter
-        for p in self.params:
-            if p.grad is None:
-                p.grad = torch.zeros_like(p)
-        grads = [p.grad for p in self.params]
+        # general case (gradients from several sources): one gather, one collective, one multi-tensor scatter
+        grads = [p.grad for p in self.params if p.grad is not None]
+        if not grads:
+            return
         flat = torch.cat([g.reshape(-1) for g in grads])
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
         flat.div_(self.world)
@@ -96,5 +101,7 @@ class GradAllReducer:
 def shard_rays(batch, rank, world):
     """Contiguous slice of a ray batch for this rank (rays are independent: no data-path collective)."""
     n = next(iter(batch.values())).shape[0]
-    per = (n + world - 1) // world
+    if n % world:
+        raise ValueError(f"shard_rays: {n} rays do not divide over {world} ranks (per-ray loss means would not average exactly)")
+    per = n // world
     return {k: v[rank * per:(rank + 1) * per] for k, v in batch.items()}

@@ -338,14 +338,15 @@ class NeROShapeRenderer(nn.Module):
     # ---- hot path -----------------------------------------------------------------------------------
     def sample_ray(self, rays_o, rays_d, near, far, perturb, rand=None):
         eng = self.engine()
-        u1, u2 = rand if rand is not None else (None, None)
+        u1, u2 = rand[:2] if rand is not None else (None, None)
         return eng.sample_ray(rays_o.contiguous(), rays_d.contiguous(), near.reshape(-1).contiguous(),
                               far.reshape(-1).contiguous(), perturb, u1, u2)
 
     def render(self, rays_o, rays_d, near, far, human_poses=None, perturb_overwrite=-1, cos_anneal_ratio=0.0,
                is_train=True, step=None, is_nerf=False, rand=None):
         """Same contract as the reference `render` (renderer_zerothick.py:614-634).  `rand` optionally injects the
-        sampler's two uniform draws (parity tests)."""
+        sampler's two uniform draws, and as an optional third element the permutation of the occlusion-loss subsample
+        (renderer_zerothick.py:710) -- parity tests."""
         perturb = self.cfg['perturb']
         if perturb_overwrite >= 0:
             perturb = perturb_overwrite
@@ -354,10 +355,11 @@ class NeROShapeRenderer(nn.Module):
         with torch.no_grad():
             z_vals = self.sample_ray(rays_o, rays_d, near, far, perturb, rand)
         return self.render_core(rays_o, rays_d, z_vals, human_poses, cos_anneal_ratio=cos_anneal_ratio, step=step,
-                                is_train=is_train, is_nerf=is_nerf, _packed=True)
+                                is_train=is_train, is_nerf=is_nerf, _packed=True,
+                                occ_perm=rand[2] if rand is not None and len(rand) > 2 else None)
 
     def render_core(self, rays_o, rays_d, z_vals, human_poses=None, cos_anneal_ratio=0.0, step=None, is_train=True,
-                    is_nerf=False, _packed=False):
+                    is_nerf=False, _packed=False, occ_perm=None):
         eng = self.engine()
         if not _packed:
             eng.pack()
@@ -379,7 +381,11 @@ class NeROShapeRenderer(nn.Module):
         self._extra_outputs(outputs, nrm_sum)
         var = self.deviation_network.variance
         inv_s = torch.exp(var * 10.0).clip(1e-6, 1e6)
-        outputs['std'] = (1.0 / inv_s).detach() if gerr.numel() else torch.zeros(1, device=rgb.device)
+        # std = mean(1 / inv_s) over the inner points = 1 / inv_s (one value); the gradient to the variance stays attached
+        # once inv_s is trainable (renderer_zerothick.py:664-668, :795-798), so StdRecorder's optional loss_std trains it
+        if frozen:
+            inv_s = inv_s.detach()
+        outputs['std'] = (1.0 / inv_s) if gerr.numel() else torch.zeros(1, device=rgb.device)
         c = eng.last_ctx
         P_in = c['P_in']
         if P_in > 0:
@@ -390,7 +396,7 @@ class NeROShapeRenderer(nn.Module):
             outputs['sdf_pts'], outputs['sdf_vals'] = self._init_reg_points(eng, c, sdf_in)
         if cfg['apply_occ_loss']:
             if P_in > 0:
-                outputs['loss_occ'] = self.compute_occ_loss(eng, c, occ_raw, step)
+                outputs['loss_occ'] = self.compute_occ_loss(eng, c, occ_raw, step, perm=occ_perm)
             else:
                 outputs['loss_occ'] = torch.zeros(1, device=rgb.device)
         if not is_train:
@@ -453,11 +459,36 @@ class NeROShapeRenderer(nn.Module):
         return F.l1_loss(occ_prob[:, None], occ_gt[:, None])
 
     def forward(self, data):
+        """trainer protocol (renderer_zerothick.py:822-844): {'step'} -> train_step; {'index','eval','step'} (the
+        ValidationEvaluator's call, train/train_valid.py:25-29, first made at step 0) -> test_step."""
         is_train = 'eval' not in data
         step = data['step']
         if not is_train:
-            raise NotImplementedError("validation rendering (test_step) needs an image database: out of scope")
+            index = data['index']
+            index = int(index.reshape(-1)[0]) if torch.is_tensor(index) else int(np.asarray(index).reshape(-1)[0])
+            return self.test_step(index, step)
         return self.train_step(step)
+
+    def test_step(self, index, step):
+        """Full-image validation render of camera `index` (renderer_zerothick.py:397-445) for the ray-pool datasets of this
+        build: every pixel of the (down-sampled) synthetic camera, chunks of cfg['test_ray_num'] rays, no jitter, cos_anneal
+        0, is_train=False; same output keys and image shapes as the reference (gt_depth / gt_mask are empty scenes' zeros:
+        a synthetic pool has no depth maps)."""
+        if not hasattr(self, 'train_batch'):
+            raise RuntimeError("test_step needs the module's ray store: construct with training=True")
+        from .validation import render_eval
+        hw = int(self.cfg.get('synthetic_hw', 800))
+        ratio = float(self.cfg['downsample_ratio']) if self.cfg['test_downsample_ratio'] else 1.0
+        rays, h, w = synthetic.make_image_rays(index, hw=hw, seed=int(self.cfg.get('ray_seed', 6033)), downsample=ratio)
+        dev = self.deviation_network.variance.device
+        batch = {k: torch.from_numpy(v).to(dev) for k, v in rays.items()}
+        outputs = render_eval(self, batch, step)
+        outputs['gt_rgb'] = batch['rgbs'].reshape(h, w, 3)
+        outputs['ray_rgb'] = outputs['ray_rgb'].reshape(h, w, 3)
+        outputs['gt_depth'] = torch.zeros(h, w, 1)
+        outputs['gt_mask'] = torch.zeros(h, w, 1, dtype=torch.int32)
+        self.zero_grad()
+        return outputs
 
     def train_step(self, step):
         rn = self.cfg['train_ray_num']

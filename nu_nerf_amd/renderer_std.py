@@ -65,6 +65,8 @@ class NeROShapeRenderer(_ZeroThickRenderer):
             rays_o, rays_d, near, far, hp = self._process_ray_batch(batch, poses)
         else:
             rays_o, rays_d, near, far, hp = self._process_nerf_ray_batch(batch)
+            if not self.is_nerf:    # explicit rays of a real capture: bracket the unit sphere like the base class does
+                near, far = self.near_far_from_sphere(rays_o, rays_d)
         outputs = self.render(rays_o, rays_d, near, far, hp, -1, self.get_anneal_val(step), is_train=True, step=step,
                               is_nerf=self.is_nerf, rand=rand)
         outputs['loss_rgb'] = self.compute_rgb_loss(outputs['ray_rgb'], batch['rgbs'])

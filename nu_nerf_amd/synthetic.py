@@ -72,3 +72,20 @@ def make_object_rays(n_rays, seed=6033, cam_radius=4.0, aim_radius=0.7):
     d = d / np.linalg.norm(d, axis=1, keepdims=True)
     rgbs = g.uniform(0, 1, (n_rays, 3))
     return {'rays_o': o.astype(np.float32), 'rays_d': d.astype(np.float32), 'rgbs': rgbs.astype(np.float32)}
+
+
+def make_image_rays(cam_index, hw=800, seed=6033, n_cam=100, camera_angle_x=0.6911, radius=4.0, downsample=1.0):
+    """All rays of ONE synthetic camera, row-major over the (down-sampled) image -- the validation counterpart of
+    make_rays (renderer_zerothick.py:222-254 with is_train=False; imgs_info_downsample scales the intrinsics).
+    Returns (dict rays_o/rays_d/rgbs [h*w,3], h, w); target colours are U[0,1) like the training pool's."""
+    poses = make_cameras(n_cam, radius, seed)
+    pose = poses[int(cam_index) % n_cam]
+    h = w = int(downsample * hw)
+    focal = 0.5 * hw / math.tan(0.5 * camera_angle_x) * (w / hw)
+    j, i = np.meshgrid(np.arange(h, dtype=np.float32), np.arange(w, dtype=np.float32), indexing='ij')
+    i, j = i.reshape(-1), j.reshape(-1)
+    dirs = np.stack([(i - 0.5 * w) / focal, -(j - 0.5 * h) / focal, -np.ones_like(i)], -1).astype(np.float32)
+    rays_d = (dirs @ pose[:, :3].T).astype(np.float32)
+    rays_o = np.broadcast_to(pose[:, 3], rays_d.shape).astype(np.float32).copy()
+    rgbs = np.random.Generator(np.random.PCG64(seed + 3 + int(cam_index))).uniform(0, 1, (h * w, 3)).astype(np.float32)
+    return {'rays_o': rays_o, 'rays_d': rays_d, 'rgbs': rgbs}, h, w

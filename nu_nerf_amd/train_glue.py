@@ -63,8 +63,8 @@ class AdamDesc(ctypes.Structure):
 
 class FusedAdam(torch.optim.Optimizer):
     """Adam (no weight decay, no amsgrad: what the reference trains with) on the HIP multi-tensor kernel.  Parameters
-    without a gradient are skipped like torch.optim.Adam does; every parameter group keeps its own lr / betas / eps / step
-    count.  There is no CPU fallback: `step()` on non-CUDA parameters raises."""
+    without a gradient are skipped like torch.optim.Adam does; every parameter group keeps its own lr / betas / eps and
+    every PARAMETER its own step count (bias correction), as torch.optim.Adam does.  There is no CPU fallback: `step()` on non-CUDA parameters raises."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
@@ -88,10 +88,12 @@ class FusedAdam(torch.optim.Optimizer):
             ps = [p for p in group['params'] if p.grad is not None]
             if not ps:
                 continue
-            if self._descs is None or len(self._descs) < len(ps):
-                self._descs = (AdamDesc * max(len(ps), 256))()
-            steps = set()
-            for i, p in enumerate(ps):
+            # Adam's bias correction is per parameter (torch.optim.Adam keeps one step count per tensor): parameters that
+            # start receiving gradients later (deviation_network.variance at freeze_inv_s_step) or that were restored from a
+            # checkpoint with their own counts form their own bucket -- one launch per distinct step count (normally one).
+            buckets = {}
+            keep = []               # contiguous copies of gradients stay alive until every launch is enqueued
+            for p in ps:
                 L.require_cuda(p)
                 if p.dtype != torch.float32 or not p.is_contiguous():
                     raise TypeError("FusedAdam: contiguous fp32 parameters only")
@@ -101,15 +103,21 @@ class FusedAdam(torch.optim.Optimizer):
                     st['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 st['step'] += 1
-                steps.add(int(st['step']))
-                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                d = self._descs[i]
-                d.p, d.g, d.m, d.v, d.n = p.data_ptr(), g.data_ptr(), st['exp_avg'].data_ptr(), st['exp_avg_sq'].data_ptr(), p.numel()
-            if len(steps) != 1:     # parameters that joined later: Adam's bias correction is per parameter
-                raise RuntimeError("FusedAdam: parameters of one group must share a step count")
+                g = p.grad
+                if not g.is_contiguous():
+                    g = g.contiguous()
+                    keep.append(g)
+                buckets.setdefault(int(st['step']), []).append((p, g, st))
             b1, b2 = group['betas']
-            L.check(lib.nu_adam_step(self._descs, len(ps), ctypes.c_double(group['lr']), ctypes.c_double(b1), ctypes.c_double(b2),
-                                     ctypes.c_double(group['eps']), steps.pop(), L.stream()), "nu_adam_step")
+            for step_count, items in buckets.items():
+                if self._descs is None or len(self._descs) < len(items):
+                    self._descs = (AdamDesc * max(len(items), 256))()
+                for i, (p, g, st) in enumerate(items):
+                    d = self._descs[i]
+                    d.p, d.g, d.m, d.v, d.n = p.data_ptr(), g.data_ptr(), st['exp_avg'].data_ptr(), st['exp_avg_sq'].data_ptr(), p.numel()
+                L.check(lib.nu_adam_step(self._descs, len(items), ctypes.c_double(group['lr']), ctypes.c_double(b1),
+                                         ctypes.c_double(b2), ctypes.c_double(group['eps']), step_count, L.stream()), "nu_adam_step")
+            del keep
         return loss
 
 
@@ -134,6 +142,11 @@ def train_step(network, optimizer, lr_manager, losses, step, batch=None, reducer
     lr = lr_manager(optimizer, step)
     optimizer.zero_grad(set_to_none=True)
     outputs = network({'step': step}) if batch is None else network.train_step_rays(batch, step)
+    if reducer is not None and reducer.world > 1:
+        # per-point means (eikonal) become this rank's share of the mean over the union of all ranks' inner points, so the
+        # all-reduced gradient equals the single-process gradient on the global batch (parallel.GradAllReducer.point_weight)
+        eng = network.engine()
+        outputs['gradient_error'] = outputs['gradient_error'] * reducer.point_weight(eng.last_ctx['P_in_dev'], outputs['gradient_error'].device)
     log_info = {}
     for loss in losses:
         log_info.update(loss(outputs, {'step': step}, step))

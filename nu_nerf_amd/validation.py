@@ -67,6 +67,8 @@ def render_eval(renderer, batch, step, chunk=None):
     for ri in range(0, n, trn):
         cur = {k: v[ri:ri + trn] for k, v in batch.items()}
         rays_o, rays_d, near, far, hp = renderer._process_nerf_ray_batch(cur)
+        if not is_nerf:         # real captures: near / far bracket the unit sphere (renderer_zerothick.py:357)
+            near, far = renderer.near_far_from_sphere(rays_o, rays_d)
         o = renderer.render(rays_o, rays_d, near, far, hp, 0, 0, is_train=False, step=step, is_nerf=is_nerf)
         for k in _EVAL_KEYS:
             outs[k].append(o[k].detach())

@@ -121,13 +121,15 @@ def _dp_worker(rank, world, port, q):
     names = stage1_trainable_names(m)
     named = dict(m.named_parameters())
     for i, n in enumerate(names):
-        if i % 7 != 3:                     # leave some grads None: the reducer must zero-fill them
+        if i % 7 != 3:                     # some grads None (on every rank alike): they must STAY None -- no Adam state is born
             named[n].grad = torch.full_like(named[n], float(rank + 1) * (1 + (i % 5)))
     red.all_reduce()
-    ok = True
+    ok = red.gathered_calls == 1
     for i, n in enumerate(names):
-        expect = 0.0 if i % 7 == 3 else 1.5 * (1 + (i % 5))
-        ok &= bool(torch.allclose(named[n].grad, torch.full_like(named[n], expect)))
+        if i % 7 == 3:
+            ok &= named[n].grad is None
+        else:
+            ok &= bool(torch.allclose(named[n].grad, torch.full_like(named[n], 1.5 * (1 + (i % 5)))))
     # the renderer's layout: every gradient a view of one flat buffer -> reduced in place, no copies
     flat = torch.full((red.numel,), float(rank + 1))
     off = 0
@@ -141,6 +143,18 @@ def _dp_worker(rank, world, port, q):
     red.all_reduce()
     ok &= bool(torch.all(flat == 1.5)) and red.in_place_calls == before + 1
     ok &= float(named[names[5]].grad.flatten()[0]) == 1.5
+    # step < freeze_inv_s_step: the variance has no gradient; its slot is a hole inside the flat range.  Still in place,
+    # and .grad stays None (the gathered path used to zero-fill it, which gave Adam a state 15000 steps early)
+    flat.fill_(float(rank + 1))
+    named['deviation_network.variance'].grad = None
+    sf = red._shared_flat()
+    ok &= sf is not None and sf.numel() == flat.numel()
+    before = red.in_place_calls
+    red.all_reduce()
+    ok &= red.in_place_calls == before + 1 and bool(torch.all(flat == 1.5)) and named['deviation_network.variance'].grad is None
+    # a gradient that lives elsewhere (accumulated from two autograd paths): no clean range -> gathered path
+    named[names[0]].grad = named[names[0]].grad.clone()
+    ok &= red._shared_flat() is None
     # per-point means: ranks with 10 and 30 inner points weigh 0.5 and 1.5, so the averaged per-rank means equal the
     # mean over all 40 points
     w = red.point_weight(10 if rank == 0 else 30, torch.device('cpu'))
@@ -155,6 +169,11 @@ def _dp_worker(rank, world, port, q):
     batch = {'rays_o': torch.arange(10.)[:, None].repeat(1, 3), 'rgbs': torch.arange(10.)[:, None].repeat(1, 3)}
     sh = shard_rays(batch, rank, world)
     ok &= sh['rays_o'].shape[0] == 5 and float(sh['rays_o'][0, 0]) == 5.0 * rank
+    try:
+        shard_rays({'rays_o': torch.zeros(9, 3)}, rank, world)
+        ok = False
+    except ValueError:
+        pass
     q.put((rank, ok, red.numel))
     dist.barrier()
     dist.destroy_process_group()
@@ -193,3 +212,48 @@ def test_capacity_classes_make_allocation_sizes_repeat():
     assert len(eng._cap_classes) == 3
     bigger = cap(int(first) + 1, 256)                                    # a record: a new class, once
     assert bigger > first and cap(int(first) + 5000, 256) == bigger
+
+
+# ---------------------------------------------------------------------------------------------------------
+# real-capture ray construction: network/renderer.py:346-378
+# ---------------------------------------------------------------------------------------------------------
+def test_process_ray_batch_and_human_poses_vs_reference_fixture():
+    """tests/golden/ray_batch_std.npz comes from the reference's own methods (oracle/gen_golden_r2.py).  Under torch 2.10 the
+    reference's get_human_coordinate_poses raises for more than one pose (in-place write into an expanded tensor,
+    renderer.py:354-355), so the generator called it pose by pose; _process_ray_batch ends in that call, so its ray part
+    (renderer.py:367-376: plain arithmetic on the inputs + the reference's near_far_from_sphere) was evaluated line by line
+    -- the fixture says so in `process_ray_batch_restated`."""
+    from helpers import golden
+    from nu_nerf_amd.renderer_std import NeROShapeRenderer as StdRenderer
+    g = golden("ray_batch_std.npz")
+    poses = torch.from_numpy(g['poses'])
+    for fixed, key in ((False, 'human_poses_free'), (True, 'human_poses_fixed')):
+        net = StdRenderer({'is_nerf': False, 'fixed_camera': fixed, 'shader_config': {'sphere_direction': True}}, training=False)
+        hp = net.get_human_coordinate_poses(poses.clone())
+        np.testing.assert_allclose(hp.numpy(), g[key], rtol=1e-6, atol=1e-6)
+        assert torch.equal(poses, torch.from_numpy(g['poses']))                       # the input is not modified
+    net = StdRenderer({'is_nerf': False, 'shader_config': {'sphere_direction': True}}, training=False)
+    ro, rd, near, far, hpr = net._process_ray_batch({'dirs': torch.from_numpy(g['dirs']), 'idxs': torch.from_numpy(g['idxs'])}, poses)
+    np.testing.assert_allclose(ro.numpy(), g['rays_o'], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(rd.numpy(), g['rays_d'], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(near.numpy(), g['near'], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(far.numpy(), g['far'], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(hpr.numpy(), g['human_poses_rays'], rtol=1e-6, atol=1e-6)
+    assert float(near.min()) >= 1e-3 and bool((far - near <= 2.0 + 1e-6).all())
+
+
+def test_forward_routes_eval_requests_to_test_step_cpu_side():
+    """forward({'index','eval','step'}) is the ValidationEvaluator's call (train/train_valid.py:25-29), first made at step 0
+    (trainer_zero.py:174): it must reach test_step, not raise.  (The render itself needs the GPU: tests/test_eval_gpu.py.)"""
+    from nu_nerf_amd.renderer import name2renderer
+    from nu_nerf_amd.synthetic import make_image_rays, make_rays
+    net = name2renderer['shape']({'database_name': 'synthetic/64', 'is_nerf': True}, training=True)
+    seen = {}
+    net.test_step = lambda index, step: seen.update(index=index, step=step) or {'ok': True}
+    assert net({'index': torch.tensor([3]), 'eval': True, 'step': 0}) == {'ok': True} and seen == {'index': 3, 'step': 0}
+    rays, h, w = make_image_rays(5, hw=16, downsample=0.5)
+    assert (h, w) == (8, 8) and rays['rays_d'].shape == (64, 3) and np.allclose(rays['rays_o'], rays['rays_o'][0])
+    # the image rays are the training pool's construction: pixel (i, j) of the full-resolution camera gives the same ray
+    full, _, _ = make_image_rays(5, hw=16, downsample=1.0)
+    dn = full['rays_d'] / np.linalg.norm(full['rays_d'], axis=1, keepdims=True)
+    assert np.all(dn @ (-full['rays_o'][0] / np.linalg.norm(full['rays_o'][0])) > 0.85)       # looking at the origin (corner pixels: cos 0.89)

@@ -136,3 +136,37 @@ def test_train_step_standard_renderer_sphere_direction():
     for k in g:
         if k.startswith('grad__'):
             assert rel_err(params[k[6:]].grad, g[k]) < 1e-2, k     # element-wise: sensitive to the shifted samples
+
+
+@pytest.mark.parametrize("tag", ["step0_r48", "step20000_r48", "step500_r32_noperturb"])
+def test_oracle_per_sample_weights_alpha_colour_vs_reference(tag, params):
+    """Per-SAMPLE pinning (round 2): the reference's alpha, sampled colour and composite weights
+    (renderer_zerothick.py:748-779, captured by oracle/gen_golden_r2.py) at the reference's own z_vals."""
+    g, c = golden(f"train_{tag}.npz"), golden(f"core_{tag}.npz")
+    o = torch.from_numpy(g['rays_o'])
+    dn = torch.nn.functional.normalize(torch.from_numpy(g['rays_d']), dim=-1)
+    step = int(g['step'])
+    cfg = oracle_cfg()
+    with torch.no_grad():
+        out = O.render_core(params, cfg, o, dn, torch.from_numpy(c['z_vals']), step, O.get_anneal_val(cfg, step), True)
+    assert np.array_equal(out['inner_mask'].numpy().astype(np.uint8), c['inner_mask'])
+    # alpha = (s_prev - s_next + 1e-5) / (s_prev + 1e-5) subtracts two sigmoids near 1: its ABSOLUTE error floor is a few ulp of
+    # 1.0 (1.2e-7 each) however small alpha is -- hence atol 5e-7 next to the relative bound
+    np.testing.assert_allclose(out['alpha'].numpy(), c['alpha'], rtol=1e-5, atol=5e-7)
+    np.testing.assert_allclose(out['sampled_color'].numpy(), c['sampled_color'], rtol=3e-5, atol=1e-6)   # 2 of 7680 at 1.3e-5
+    np.testing.assert_allclose(out['weights'].numpy(), c['weights'], rtol=1e-5, atol=5e-7)
+    np.testing.assert_allclose(out['gradient_error'].numpy(), c['gradient_error'], rtol=1e-5, atol=1e-7)
+
+
+def test_oracle_occ_loss_subsample_branch_vs_reference(params):
+    """occ_loss_max_pn below the candidate count: the randperm subsample of renderer_zerothick.py:708-714, with the
+    permutation the reference drew."""
+    g = golden("occ_cap_step20000_r48.npz")
+    cfg = oracle_cfg(occ_loss_max_pn=int(g['occ_loss_max_pn']))
+    o = torch.from_numpy(g['rays_o'])
+    dn = torch.nn.functional.normalize(torch.from_numpy(g['rays_d']), dim=-1)
+    step = int(g['step'])
+    with torch.no_grad():
+        out = O.render_core(params, cfg, o, dn, torch.from_numpy(g['z_vals']), step, O.get_anneal_val(cfg, step), True,
+                            occ_perm=torch.from_numpy(g['perm']))
+    np.testing.assert_allclose(float(out['loss_occ']), float(g['out_loss_occ']), rtol=1e-5)

@@ -133,3 +133,82 @@ def test_four_optimizer_steps_track_the_cpu_oracle(gpu):
     for it, (a, b) in enumerate(hist):
         assert abs(a - b) <= 2e-4 * abs(b) * (1 + it), (it, hist)          # step 0: forward parity; later: the update too
     assert abs(hist[0][1] - hist[3][1]) > 1e-3                             # the parameters really moved
+
+
+def test_fused_adam_keeps_per_parameter_step_counts(gpu):
+    """torch.optim.Adam counts steps per parameter: one that starts receiving gradients later (deviation_network.variance at
+    freeze_inv_s_step) gets its own bias correction.  FusedAdam must follow, not raise."""
+    from nu_nerf_amd.train_glue import FusedAdam
+    pa, pb = _params(gpu, 7), _params(gpu, 7)
+    oa, ob = torch.optim.Adam(pa, lr=2e-3), FusedAdam(pb, lr=2e-3)
+    g = torch.Generator(device='cpu').manual_seed(8)
+    for it in range(7):
+        for i, (x, y) in enumerate(zip(pa, pb)):
+            if i in (0, 3) and it < 4:            # two late joiners: no gradient during the first four steps
+                x.grad = y.grad = None
+                continue
+            gr = torch.randn(x.shape, generator=g).to(gpu)
+            x.grad, y.grad = gr.clone(), gr.clone()
+        oa.step(); ob.step()
+        for x, y in zip(pa, pb):
+            torch.testing.assert_close(y, x, rtol=2e-6, atol=1e-7)
+    assert int(ob.state[pb[0]]['step']) == int(oa.state[pa[0]]['step']) == 3
+    assert int(ob.state[pb[1]]['step']) == int(oa.state[pa[1]]['step']) == 7
+
+
+def test_fused_adam_resumes_state_with_differing_step_counts(gpu):
+    """A reference optimizer state saved after freeze_inv_s_step has variance.step = N - 15000 next to step = N."""
+    from nu_nerf_amd.train_glue import FusedAdam
+    pa, pb = _params(gpu, 9), _params(gpu, 9)
+    oa = torch.optim.Adam(pa, lr=1e-3)
+    for it in range(5):
+        for i, x in enumerate(pa):
+            x.grad = None if (i == 2 and it < 3) else torch.full_like(x, 0.1 * (it + 1))
+        oa.step()
+    ob = FusedAdam(pb, lr=1e-3)
+    with torch.no_grad():
+        for x, y in zip(pa, pb):
+            y.copy_(x)
+    ob.load_state_dict(copy.deepcopy(oa.state_dict()))
+    for x, y in zip(pa, pb):
+        x.grad = torch.full_like(x, -0.3)
+        y.grad = torch.full_like(y, -0.3)
+    oa.step(); ob.step()
+    for x, y in zip(pa, pb):
+        torch.testing.assert_close(y, x, rtol=2e-6, atol=1e-7)
+
+
+def test_train_steps_across_freeze_inv_s_step(gpu):
+    """Steps 14999 / 15000 / 15001 with freeze_inv_s_step = 15000: the variance parameter has no gradient, then joins
+    the optimizer with its own step count.  FusedAdam and torch.optim.Adam on two replicas of the HIP renderer agree."""
+    from nu_nerf_amd.renderer import NeROShapeRenderer
+    from nu_nerf_amd.params import init_stage1_params
+    from nu_nerf_amd.synthetic import make_rays, make_jitter
+    from nu_nerf_amd.loss import name2loss, SPHEREPOT_LOSSES, total_loss
+    from nu_nerf_amd.train_glue import FusedAdam
+    cfg = {'name': 't', 'network': 'shape', 'database_name': 'synthetic/64', 'is_nerf': True, 'apply_occ_loss': True,
+           'occ_loss_step': 15000, 'freeze_inv_s_step': 15000, 'n_samples': 16, 'n_importance': 16, 'n_bg_samples': 8}
+    nets, opts = [], []
+    for kind in (FusedAdam, torch.optim.Adam):
+        net = NeROShapeRenderer(cfg, training=False)
+        net.load_param_dict(init_stage1_params(6033))
+        nets.append(net.to(gpu))
+        opts.append(kind(nets[-1].parameters(), lr=1e-3))
+    losses = [name2loss[n](cfg) for n in SPHEREPOT_LOSSES]
+    var_hist = []
+    for it, step in enumerate((14999, 15000, 15001)):
+        rays = make_rays(48, seed=90 + it)
+        u1, u2 = make_jitter(48, 8, seed=95 + it)
+        batch = {k: torch.from_numpy(rays[k]).to(gpu) for k in ('rays_o', 'rays_d', 'rgbs')}
+        rand = (torch.from_numpy(u1).to(gpu), torch.from_numpy(u2).to(gpu))
+        for net, opt in zip(nets, opts):
+            opt.zero_grad(set_to_none=True)
+            total, _ = total_loss(net.train_step_rays(batch, step, rand=rand), losses, step)
+            total.backward()
+            opt.step()
+        var_hist.append((float(nets[0].deviation_network.variance), nets[0].deviation_network.variance.grad is not None))
+    assert var_hist[0] == (pytest.approx(0.3), False) and var_hist[1][1] and var_hist[1][0] != pytest.approx(0.3, abs=1e-7)
+    assert int(opts[0].state[nets[0].deviation_network.variance]['step']) == 2
+    assert int(opts[0].state[nets[0].sdf_network.lin0.bias]['step']) == 3
+    for (n, a), (_, b) in zip(nets[0].named_parameters(), nets[1].named_parameters()):
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=2e-6, msg=lambda m: f"{n}: {m}")
