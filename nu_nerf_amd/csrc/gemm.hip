@@ -42,6 +42,15 @@ static __device__ inline float nu_epi_apply(float v, float bv, float h, float d,
 // development aid: {shader cycles, 100 MHz wall ticks} of block 0 of the last mfma_peak launch
 __device__ unsigned long long nu_dbg_clk[2];
 
+#ifdef NU_LAB   // scripts/gemm_lab.hip only (never defined for libnunerf.so): per-workgroup phase stamps and ablation switches
+#define NU_LAB_TILES 6
+__device__ unsigned long long nu_lab_trace[1024][NU_LAB_TILES][3];   // [wg][tile]{main-loop start, main-loop end, epilogue end} 100 MHz
+__device__ unsigned nu_lab_hwid[1024][2];
+__device__ int nu_lab_skip_epi;      // 1: store nothing in the epilogue (pure main loop + tile switch)
+__device__ int nu_lab_epi_prio;      // wave priority inside the epilogue (0..3)
+static int nu_lab_grid = 0;          // persistent grid size override (0: default)
+#endif
+
 // One LDS buffer (36.9 KB per workgroup) -> 3 workgroups per CU.  The next k-chunk travels global -> registers
 // under the MFMAs; only the register -> LDS hand-over sits between two barriers, and the other resident workgroups
 // keep the matrix pipe busy meanwhile (measured: +5..12 % over a double-buffered 2-workgroup build on the K = 256
@@ -151,6 +160,14 @@ __global__ __launch_bounds__(256, PREC == 2 ? 2 : NT_WPC) void gemm_nt_kernel(Nu
         }
     };
 
+#ifdef NU_LAB
+    int lab_tile = 0;
+    const unsigned long long lab_c0 = clock64(), lab_w0 = wall_clock64();
+    if (tid == 0 && blockIdx.x < 1024) {
+        nu_lab_hwid[blockIdx.x][0] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);     // HW_ID
+        nu_lab_hwid[blockIdx.x][1] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20);    // XCC_ID
+    }
+#endif
     set_ptrs(mt, nt);
     load_regs(0);
     store_regs();
@@ -201,6 +218,9 @@ __global__ __launch_bounds__(256, PREC == 2 ? 2 : NT_WPC) void gemm_nt_kernel(Nu
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.0f;
 
+#ifdef NU_LAB
+        if (tid == 0 && blockIdx.x < 1024 && lab_tile < NU_LAB_TILES) nu_lab_trace[blockIdx.x][lab_tile][0] = wall_clock64();
+#endif
         for (int kt = 0; kt < nk; ++kt) {
             if (kt + 1 < nk) {
                 load_regs((kt + 1) * TBK);
@@ -270,6 +290,15 @@ __global__ __launch_bounds__(256, PREC == 2 ? 2 : NT_WPC) void gemm_nt_kernel(Nu
             }
         }
 
+#ifdef NU_LAB
+        if (tid == 0 && blockIdx.x < 1024 && lab_tile < NU_LAB_TILES) nu_lab_trace[blockIdx.x][lab_tile][1] = wall_clock64();
+        const bool lab_skip = nu_lab_skip_epi != 0;
+        if (nu_lab_epi_prio == 1) __builtin_amdgcn_s_setprio(1);
+        if (nu_lab_epi_prio == 2) __builtin_amdgcn_s_setprio(2);
+        if (nu_lab_epi_prio == 3) __builtin_amdgcn_s_setprio(3);
+#else
+        constexpr bool lab_skip = false;
+#endif
         // ---- epilogue: accumulators -> wave-private LDS scratch (32 rows at a time) -> row-contiguous float4 ----
         float* scr = &smem[0][0] + wid * (32 * EPI_LDS);
         const int colq = (lane & 15) * 4;
@@ -280,6 +309,23 @@ __global__ __launch_bounds__(256, PREC == 2 ? 2 : NT_WPC) void gemm_nt_kernel(Nu
             for (int e = 0; e < 4; ++e) bv[e] = (gcol + e < g.N) ? bias[gcol + e] : 0.f;
         }
         const bool full = vec_ok && (gcol + 3 < g.N) && (gcol + 3 < act_cols || gcol >= act_cols);
+        // the wave's whole 64 x 64 slab is interior and on one side of act_cols (wave-uniform): the fast path below
+        const int wcol0 = n0 + wc * 64, wrow0 = m0 + wr * 64;
+        const bool slab_full = vec_ok && (wrow0 + 64 <= g.M) && (wcol0 + 64 <= g.N) && (wcol0 + 64 <= act_cols || wcol0 >= act_cols);
+        const bool slab_plain = kNeedH && wcol0 >= act_cols;
+        // fast-path addressing: one wave-uniform base per matrix (SGPRs; the wave id is made provably uniform) + a 32-bit
+        // per-lane byte offset, so no 64-bit per-lane pointer lives in VGPRs
+        const int uwid = __builtin_amdgcn_readfirstlane(wid);
+        const long long urow0 = m0 + (uwid >> 1) * 64, ucol0 = n0 + (uwid & 1) * 64;
+        const unsigned lrow = lane >> 4;
+        char* const Cu = reinterpret_cast<char*>(C + urow0 * g.ldc + ucol0);
+        char* const C2u = kNeedD ? reinterpret_cast<char*>(C2 + urow0 * g.ldc2 + ucol0) : nullptr;
+        const char* const Hu = kNeedH ? reinterpret_cast<const char*>(H + urow0 * g.ldh + ucol0) : nullptr;
+        const char* const Du = kNeedD ? reinterpret_cast<const char*>(D + urow0 * g.ldd + ucol0) : nullptr;
+        const char* const Au = kNeedAdd ? reinterpret_cast<const char*>(Cadd + urow0 * g.ldadd + ucol0) : nullptr;
+        const unsigned oC = (lrow * (unsigned)g.ldc + (unsigned)colq) * 4u, oC2 = (lrow * (unsigned)g.ldc2 + (unsigned)colq) * 4u;
+        const unsigned oH = (lrow * (unsigned)g.ldh + (unsigned)colq) * 4u, oD = (lrow * (unsigned)g.ldd + (unsigned)colq) * 4u;
+        const unsigned oA = (lrow * (unsigned)g.ldadd + (unsigned)colq) * 4u;
 #pragma unroll
         for (int tm = 0; tm < 2; ++tm) {
 #pragma unroll
@@ -287,7 +333,56 @@ __global__ __launch_bounds__(256, PREC == 2 ? 2 : NT_WPC) void gemm_nt_kernel(Nu
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     scr[((r & 3) + 8 * (r >> 2) + 4 * lh) * EPI_LDS + tn * 32 + li] = acc[tm][tn][r];
-            if (gcol < zero_to) {
+            if (lab_skip) {
+                if (acc[tm][0][0] == 123.456f) C[0] = acc[tm][1][3];      // keeps the accumulators live
+            } else if (slab_full) {
+                // wave-uniform fast path (every interior tile): straight-line code, no per-lane guards; the auxiliary loads of
+                // four row groups are in flight together; the activation math is branch-free (nu_common.h)
+                constexpr int NB = kNeedH ? 2 : 4;           // row groups in flight (register budget: 168 VGPRs at 3 waves / SIMD)
+#pragma unroll
+                for (int hb = 0; hb < 8 / NB; ++hb) {
+                    f32x4 v4[NB], h4[NB], d4[NB], c4v[NB];
+#pragma unroll
+                    for (int ii = 0; ii < NB; ++ii) {
+                        const int i = hb * NB + ii;
+                        const long long roff = (long long)(tm * 32 + i * 4);
+                        v4[ii] = *reinterpret_cast<const f32x4*>(&scr[(i * 4 + (lane >> 4)) * EPI_LDS + colq]);
+                        if (kNeedH && !slab_plain && !(kMaskR && mwave)) h4[ii] = *reinterpret_cast<const f32x4*>(Hu + roff * g.ldh * 4 + oH);
+                        if (kNeedD && !slab_plain) d4[ii] = *reinterpret_cast<const f32x4*>(Du + roff * g.ldd * 4 + oD);
+                        if (kNeedAdd && !slab_plain) c4v[ii] = *reinterpret_cast<const f32x4*>(Au + roff * g.ldadd * 4 + oA);
+                    }
+#pragma unroll
+                    for (int ii = 0; ii < NB; ++ii) {
+                        const int i = hb * NB + ii;
+                        const long long roff = (long long)(tm * 32 + i * 4);
+                        f32x4 o4, o24;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float h = 0.f, o2 = 0.f;
+                            if (kMaskR && mwave) {
+                                const int src = (tm * 8 + i) * 4 + e;           // wave-uniform
+                                const unsigned lo = __builtin_amdgcn_readlane(mlo, src), hi = __builtin_amdgcn_readlane(mhi, src);
+                                h = (((lane < 32 ? lo : hi) >> (lane & 31)) & 1u) ? 1.0f : 0.0f;
+                            } else if (kNeedH && !slab_plain) h = h4[ii][e];
+                            const float v = g.alpha * v4[ii][e];
+                            o4[e] = slab_plain ? v : nu_epi_apply<EPI>(v, bv[e], h, (kNeedD && !slab_plain) ? d4[ii][e] : 0.f,
+                                                                       (kNeedAdd && !slab_plain) ? c4v[ii][e] : 0.f, o2);
+                            o24[e] = o2;
+                        }
+                        *reinterpret_cast<f32x4*>(Cu + roff * g.ldc * 4 + oC) = o4;
+                        if (kNeedD) *reinterpret_cast<f32x4*>(C2u + roff * g.ldc2 * 4 + oC2) = o24;
+                        if (kMaskW && mwave) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const unsigned long long bits = __ballot(o4[e] > 0.f);
+                                const bool mine = lane == (tm * 8 + i) * 4 + e;
+                                wlo = mine ? (unsigned)bits : wlo;
+                                whi = mine ? (unsigned)(bits >> 32) : whi;
+                            }
+                        }
+                    }
+                }
+            } else if (gcol < zero_to) {
 #pragma unroll 4
                 for (int i = 0; i < 8; ++i) {
                     const int rl = i * 4 + (lane >> 4);
@@ -358,6 +453,12 @@ __global__ __launch_bounds__(256, PREC == 2 ? 2 : NT_WPC) void gemm_nt_kernel(Nu
             }
         }
         if (kMaskW && mwave) mwave[lane] = ((unsigned long long)whi << 32) | wlo;
+#ifdef NU_LAB
+        __builtin_amdgcn_s_setprio(0);
+        if (tid == 0 && blockIdx.x < 1024 && lab_tile < NU_LAB_TILES) nu_lab_trace[blockIdx.x][lab_tile][2] = wall_clock64();
+        ++lab_tile;
+        if (!has_next && tid == 0 && blockIdx.x == 0) { nu_dbg_clk[0] = clock64() - lab_c0; nu_dbg_clk[1] = wall_clock64() - lab_w0; }
+#endif
         if (!has_next) break;
         __syncthreads();   // every wave is done with the scratch
         store_regs();
@@ -383,7 +484,11 @@ int nu_gemm_nt_launch(const NuGemmNT& g, hipStream_t stream) {
         if (g.act_cols > 0 && (g.act_cols & 63)) return NU_ERR_ARG;
     }
     // persistent: NT_WPC workgroups per CU (256 CUs) shared over the groups, a multiple of 8 so the XCD grouping holds
+#ifdef NU_LAB
+    const int grid_env = nu_lab_grid;
+#else
     static const int grid_env = getenv("NU_NT_GRID") ? atoi(getenv("NU_NT_GRID")) : 0;
+#endif
     const int grid_target = grid_env ? grid_env : 256 * (g.bf16 == 2 ? 2 : NT_WPC);   // workgroups the build keeps resident
     long long per = nu_rup(nu_cdiv(grid_target, groups), 8);
     if (per > nslots) per = nslots;

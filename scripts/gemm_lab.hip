@@ -1,0 +1,189 @@
+// Development aid (not part of the library): stand-alone timing lab for the NT GEMM kernel -- no Python, starts in a second.
+// Compiles csrc/gemm.hip into this binary with -DNU_LAB, which adds per-workgroup phase stamps and a start-up stagger.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DNU_LAB -Inu_nerf_amd/csrc -Iinclude scripts/gemm_lab.hip -o scripts/gemm_lab
+//   ./scripts/gemm_lab [sweep|trace]
+#include "../nu_nerf_amd/csrc/gemm.hip"
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+__global__ void fill_kernel(float* p, long long n, unsigned seed, float scale, float shift) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        unsigned x = (unsigned)(i * 2654435761u) ^ seed;
+        x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+        p[i] = ((float)(x & 0xffffff) / 16777216.0f - 0.5f) * scale + shift;
+    }
+}
+static float* dalloc(long long n, unsigned seed, float scale, float shift = 0.f) {
+    float* p;
+    CK(hipMalloc(&p, n * sizeof(float)));
+    hipLaunchKernelGGL(fill_kernel, dim3(2048), dim3(256), 0, 0, p, n, seed, scale, shift);
+    return p;
+}
+
+// bare matrix-pipe loops on random operands held in registers: what each f32 MFMA shape delivers, and at which clock
+__device__ unsigned long long lab_clk[4];
+template <int SHAPE>
+__global__ __launch_bounds__(256) void bare_mfma_kernel(const float* __restrict__ src, float* out, int iters) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    float x[8], y[8];
+    for (int i = 0; i < 8; ++i) { x[i] = src[(t * 8 + i) & 0xfffff]; y[i] = src[(t * 8 + i + 77777) & 0xfffff]; }
+    const unsigned long long c0 = clock64(), w0 = wall_clock64();
+    float s = 0.f;
+    if (SHAPE == 32) {
+        f32x16 a0 = {}, a1 = {}, a2 = {}, a3 = {};
+        for (int i = 0; i < iters; ++i) {
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) {
+                a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x[j], y[j], a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x[j], y[j + 1], a1, 0, 0, 0);
+                a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(x[j + 1], y[j], a2, 0, 0, 0);
+                a3 = __builtin_amdgcn_mfma_f32_32x32x2f32(x[j + 1], y[j + 1], a3, 0, 0, 0);
+            }
+        }
+        for (int r = 0; r < 16; ++r) s += a0[r] + a1[r] + a2[r] + a3[r];
+    } else {
+        f32x4 a[16] = {};
+        for (int i = 0; i < iters; ++i) {
+#pragma unroll
+            for (int j = 0; j < 8; j += 4) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q)
+                    a[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[j + (q >> 2)], y[j + (q & 3)], a[q], 0, 0, 0);
+            }
+        }
+        for (int q = 0; q < 16; ++q) s += a[q][0] + a[q][1] + a[q][2] + a[q][3];
+    }
+    if (s == 123.456f) out[0] = s;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { lab_clk[0] = clock64() - c0; lab_clk[1] = wall_clock64() - w0; }
+}
+
+struct Bufs { float *A, *B, *C, *C2, *H, *D, *bias; int M, N, K; };
+
+static double time_nt(const Bufs& b, int epi, int iters) {
+    NuGemmNT g = {};
+    g.A = b.A; g.lda = b.K; g.B = b.B; g.ldb = b.K; g.M = b.M; g.N = b.N; g.K = b.K; g.C = b.C; g.ldc = b.N; g.C2 = b.C2; g.ldc2 = b.N;
+    g.bias = b.bias; g.H = b.H; g.ldh = b.N; g.D = b.D; g.ldd = b.N; g.Cadd = b.D; g.ldadd = b.N; g.alpha = 1.f; g.groups = 1; g.epi = epi;
+    for (int i = 0; i < 2; ++i) if (nu_gemm_nt_launch(g, 0)) { printf("launch failed\n"); exit(1); }
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < iters; ++i) nu_gemm_nt_launch(g, 0);
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    return ms / iters;
+}
+
+#define set_int(sym, val) do { int v_ = (val); CK(hipMemcpyToSymbol(HIP_SYMBOL(sym), &v_, sizeof(int))); } while (0)
+
+int main(int argc, char** argv) {
+    const char* mode = argc > 1 ? argv[1] : "sweep";
+    const int M = 540672;   // the step's outer-point count (4224 row tiles)
+    Bufs b256 = {dalloc((long long)M * 256, 1, 1.f), dalloc(256 * 256, 2, 0.12f), dalloc((long long)M * 256, 3, 0.f), dalloc((long long)M * 256, 4, 0.f),
+                 dalloc((long long)M * 256, 5, 0.02f, 0.01f), dalloc((long long)M * 256, 6, 1.f), dalloc(256, 7, 0.1f), M, 256, 256};
+    Bufs b1024 = b256;
+    b1024.M = M / 4; b1024.K = 1024; b1024.B = dalloc(256 * 1024, 8, 0.06f);
+    CK(hipDeviceSynchronize());
+    set_int(nu_lab_epi_prio, 0);
+    set_int(nu_lab_skip_epi, 0);
+    auto tf = [](const Bufs& b, double ms) { return 2.0 * b.M * b.N * b.K / ms / 1e9; };
+    if (!strcmp(mode, "sweep")) {
+        // warm the clocks
+        for (int i = 0; i < 3; ++i) time_nt(b256, NU_EPI_PLAIN, 10);
+        for (int grid : {256, 512, 768}) {
+            nu_lab_grid = grid;
+            const double ms = time_nt(b256, NU_EPI_BIAS_SOFTPLUS, 20), ms2 = time_nt(b256, NU_EPI_PLAIN, 20), ms3 = time_nt(b1024, NU_EPI_PLAIN, 20);
+            printf("grid %4d : K=256 softplus %6.1f  K=256 plain %6.1f  K=1024 plain %6.1f TFLOP/s\n", grid, tf(b256, ms), tf(b256, ms2), tf(b1024, ms3));
+        }
+        nu_lab_grid = 0;
+        for (int skip = 0; skip < 2; ++skip) {
+            set_int(nu_lab_skip_epi, skip);
+            for (int epi : {NU_EPI_PLAIN, NU_EPI_BIAS_RELU, NU_EPI_BIAS_SOFTPLUS, NU_EPI_MUL_DSP, NU_EPI_Q_SP}) {
+                const double ms = time_nt(b256, epi, 20);
+                printf("K=256  epi=%d skip_epi=%d : %7.1f us  %6.1f TFLOP/s\n", epi, skip, ms * 1e3, tf(b256, ms));
+            }
+            const double ms = time_nt(b1024, NU_EPI_PLAIN, 20);
+            printf("K=1024 epi=7 skip_epi=%d : %7.1f us  %6.1f TFLOP/s\n", skip, ms * 1e3, tf(b1024, ms));
+        }
+        set_int(nu_lab_skip_epi, 0);
+        Bufs bin = b256;
+        bin.M = 114048;                       // the step's inner-point count: 891 row tiles, 2.3 tiles per workgroup
+        for (int pass = 0; pass < 2; ++pass)
+        for (int prio = 0; prio < 4; ++prio) {
+            set_int(nu_lab_epi_prio, prio);
+            double r[8];
+            int i = 0;
+            for (int epi : {NU_EPI_PLAIN, NU_EPI_BIAS_SOFTPLUS, NU_EPI_MUL_DSP, NU_EPI_Q_SP}) r[i++] = tf(b256, time_nt(b256, epi, 20));
+            r[i++] = tf(b1024, time_nt(b1024, NU_EPI_PLAIN, 20));
+            for (int epi : {NU_EPI_PLAIN, NU_EPI_BIAS_SOFTPLUS}) r[i++] = tf(bin, time_nt(bin, epi, 40));
+            printf("epilogue prio %d : M=540k K=256 plain %6.1f softplus %6.1f dsp %6.1f q_sp %6.1f | K=1024 M=135k plain %6.1f | M=114k K=256 plain %6.1f softplus %6.1f\n",
+                   prio, r[0], r[1], r[2], r[3], r[4], r[5], r[6]);
+        }
+        set_int(nu_lab_epi_prio, 0);
+    } else if (!strcmp(mode, "clock")) {
+        // matrix-pipe rate and shader clock of the two f32 MFMA shapes on random register operands, 1..3 waves per SIMD
+        float* src = dalloc(1 << 20, 99, 2.f);
+        for (int wps : {1, 2, 3}) {
+            for (int shape : {32, 16}) {
+                const int iters = 20000;
+                for (int rep = 0; rep < 2; ++rep) {
+                    hipEvent_t e0, e1;
+                    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+                    CK(hipEventRecord(e0, 0));
+                    if (shape == 32) hipLaunchKernelGGL(bare_mfma_kernel<32>, dim3(256 * wps), dim3(256), 0, 0, src, b256.C, iters);
+                    else hipLaunchKernelGGL(bare_mfma_kernel<16>, dim3(256 * wps), dim3(256), 0, 0, src, b256.C, iters);
+                    CK(hipEventRecord(e1, 0));
+                    CK(hipEventSynchronize(e1));
+                    float ms;
+                    CK(hipEventElapsedTime(&ms, e0, e1));
+                    unsigned long long h[4];
+                    CK(hipMemcpyFromSymbol(h, HIP_SYMBOL(lab_clk), sizeof(h)));
+                    // flops: 32x32x2: 4096 per MFMA, 8 per iteration... per wave: iters * (shape == 32 ? 16 * 4096 : 32 * 2048)
+                    const double fl = (double)iters * 65536.0 * 4 * 256 * wps;
+                    if (rep) printf("bare MFMA %s, %d wave(s)/SIMD: %6.1f TFLOP/s, shader clock %.0f MHz (block 0: %.2f ms)\n",
+                                    shape == 32 ? "32x32x2" : "16x16x4", wps, fl / ms / 1e9, (double)h[0] / (double)h[1] * 100.0, ms);
+                }
+            }
+        }
+        // the real kernel: clock held by block 0 over its whole life
+        for (int skip = 0; skip < 2; ++skip) {
+            set_int(nu_lab_skip_epi, skip);
+            for (int epi : {NU_EPI_PLAIN, NU_EPI_BIAS_SOFTPLUS}) {
+                const double ms = time_nt(b256, epi, 20);
+                unsigned long long h[2];
+                CK(hipMemcpyFromSymbol(h, HIP_SYMBOL(nu_dbg_clk), sizeof(h)));
+                printf("NT K=256 epi=%d skip_epi=%d: %6.1f TFLOP/s, shader clock %.0f MHz\n", epi, skip, tf(b256, ms), (double)h[0] / (double)h[1] * 100.0);
+            }
+        }
+    } else {
+        // traced launches: mean main-loop / epilogue duration per tile (tiles 1..5 of every workgroup), by grid size and epilogue
+        static unsigned long long tr[1024][NU_LAB_TILES][3];
+        for (int grid : {256, 512, 768}) {
+            for (int epi : {NU_EPI_PLAIN, NU_EPI_BIAS_SOFTPLUS, NU_EPI_MUL_DSP, NU_EPI_Q_SP}) {
+                nu_lab_grid = grid;
+                const double ms = time_nt(b256, epi, 3);
+                CK(hipMemcpyFromSymbol(tr, HIP_SYMBOL(nu_lab_trace), sizeof(tr)));
+                double main_us = 0, epi_us = 0, gap_us = 0;
+                int n = 0;
+                for (int w = 0; w < grid; ++w)
+                    for (int t = 1; t < NU_LAB_TILES; ++t) {
+                        main_us += (tr[w][t][1] - tr[w][t][0]) * 0.01;
+                        epi_us += (tr[w][t][2] - tr[w][t][1]) * 0.01;
+                        gap_us += (tr[w][t][0] - tr[w][t - 1][2]) * 0.01;
+                        ++n;
+                    }
+                printf("grid %3d epi %d: %6.1f TFLOP/s  per tile: main loop %6.2f us, epilogue %6.2f us, hand-over to next tile %5.2f us\n",
+                       grid, epi, tf(b256, ms), main_us / n, epi_us / n, gap_us / n);
+            }
+        }
+        nu_lab_grid = 0;
+    }
+    return 0;
+}
