@@ -47,9 +47,229 @@ __device__ unsigned long long nu_dbg_clk[2];
 __device__ unsigned long long nu_lab_trace[1024][NU_LAB_TILES][3];   // [wg][tile]{main-loop start, main-loop end, epilogue end} 100 MHz
 __device__ unsigned nu_lab_hwid[1024][2];
 __device__ int nu_lab_skip_epi;      // 1: store nothing in the epilogue (pure main loop + tile switch)
-__device__ int nu_lab_epi_prio;      // wave priority inside the epilogue (0..3)
 static int nu_lab_grid = 0;          // persistent grid size override (0: default)
+static int nu_lab_v1 = 0;            // 1: first-generation fp32 NT kernel
+__device__ int nu_lab_stamps;        // 1: wave 0 of block 0 stamps the stages of its third tile (perturbs that tile)
+__device__ long long nu_lab_stage[8][8];
+__device__ int nu_lab_small_a;       // 1: every tile reads A from an 8 MB window (memory-latency ablation, gen 2)
 #endif
+
+// ------------------------------------------------------------------------------------------------
+// Epilogue shared by the NT kernels: accumulators -> wave-private LDS scratch (32 rows at a time) -> row-contiguous float4
+// rows, fused bias / activation / derivative epilogues, ReLU sign-bit words.
+// ------------------------------------------------------------------------------------------------
+template <int EPI>
+struct NtEpiArgs {       // per launch (and group)
+    float* C; float* C2; const float* bias; const float* H; const float* D; const float* Cadd;
+    unsigned long long* mask;
+    int zero_to, act_cols;
+    bool vec_ok;
+    static constexpr bool kMaskW = (EPI == NU_EPI_BIAS_RELU);                                  // writes ReLU sign bits
+    static constexpr bool kMaskR = (EPI == NU_EPI_MUL_DRELU || EPI == NU_EPI_B_RELU);          // reads them instead of H
+    static constexpr bool kNeedH = (EPI == NU_EPI_MUL_DRELU || EPI == NU_EPI_MUL_DSP || EPI == NU_EPI_Q_SP ||
+                                    EPI == NU_EPI_B_SP || EPI == NU_EPI_B_RELU);
+    static constexpr bool kNeedD = (EPI == NU_EPI_Q_SP);
+    static constexpr bool kNeedAdd = (EPI == NU_EPI_B_SP || EPI == NU_EPI_B_RELU);
+    static constexpr bool kBias = (EPI <= NU_EPI_BIAS_SOFTPLUS);
+};
+
+template <int EPI>
+static __device__ inline NtEpiArgs<EPI> nt_epi_args(const NuGemmNT& g, int z) {
+    typedef NtEpiArgs<EPI> E;
+    E a;
+    a.C = g.C + (long long)z * g.sC;
+    a.C2 = g.C2 ? g.C2 + (long long)z * g.sC2 : nullptr;
+    a.bias = g.bias ? g.bias + (long long)z * g.sBias : nullptr;
+    a.H = g.H ? g.H + (long long)z * g.sH : nullptr;
+    a.D = g.D ? g.D + (long long)z * g.sD : nullptr;
+    a.Cadd = g.Cadd ? g.Cadd + (long long)z * g.sCadd : nullptr;
+    a.zero_to = g.zero_to > g.N ? g.zero_to : g.N;
+    a.act_cols = g.act_cols > 0 ? g.act_cols : 0x7fffffff;
+    a.mask = (E::kMaskW || E::kMaskR) ? g.mask : nullptr;
+    // 16-byte vector path needs every touched matrix 16-B aligned with ld % 4 == 0 (wave-uniform test)
+    bool v = (((uintptr_t)a.C & 15) == 0) && ((g.ldc & 3) == 0);
+    if (E::kNeedH) v = v && (((uintptr_t)a.H & 15) == 0) && ((g.ldh & 3) == 0);
+    if (E::kNeedD) v = v && (((uintptr_t)a.D & 15) == 0) && ((g.ldd & 3) == 0) && (((uintptr_t)a.C2 & 15) == 0) && ((g.ldc2 & 3) == 0);
+    if (E::kNeedAdd) v = v && (((uintptr_t)a.Cadd & 15) == 0) && ((g.ldadd & 3) == 0);
+    a.vec_ok = v;
+    return a;
+}
+
+// sign-bit words of the wave's 64 x 64 slab of tile (mt, nt) of group z (nullptr: no mask for this tile)
+template <int EPI>
+static __device__ inline unsigned long long* nt_mask_words(const NtEpiArgs<EPI>& ea, const NuGemmNT& g, int mt, int nt, int z, int ntn, int wid) {
+    const int ct = z * ntn + nt;
+    return (ea.mask && ct < g.mask_nct) ? ea.mask + ((((long long)mt * g.mask_nct + ct) * 4 + wid) * 64) : nullptr;
+}
+
+// NBH: row groups whose auxiliary loads are in flight together in the fast path (register budget of the caller)
+template <int EPI, int NBH>
+static __device__ __forceinline__ void nt_epilogue(const NuGemmNT& g, const NtEpiArgs<EPI>& ea, f32x16 (&acc)[2][2], float* scr,
+                                                   int m0, int n0, unsigned long long* mwave, unsigned mlo, unsigned mhi,
+                                                   int lane, int wid, bool lab_skip) {
+    typedef NtEpiArgs<EPI> E;
+    constexpr bool kMaskW = E::kMaskW, kMaskR = E::kMaskR, kNeedH = E::kNeedH, kNeedD = E::kNeedD, kNeedAdd = E::kNeedAdd, kBias = E::kBias;
+    float* const C = ea.C; float* const C2 = ea.C2;
+    const float* const bias = ea.bias; const float* const H = ea.H; const float* const D = ea.D; const float* const Cadd = ea.Cadd;
+    const int zero_to = ea.zero_to, act_cols = ea.act_cols;
+    const bool vec_ok = ea.vec_ok;
+    const int li = lane & 31, lh = lane >> 5;
+    const int wr = wid >> 1, wc = wid & 1;
+    unsigned wlo = 0, whi = 0;      // writer: lane l accumulates word l
+    // ---- epilogue: accumulators -> wave-private LDS scratch (32 rows at a time) -> row-contiguous float4 ----
+    const int colq = (lane & 15) * 4;
+    const int gcol = n0 + wc * 64 + colq;
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (kBias && bias) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bv[e] = (gcol + e < g.N) ? bias[gcol + e] : 0.f;
+    }
+    const bool full = vec_ok && (gcol + 3 < g.N) && (gcol + 3 < act_cols || gcol >= act_cols);
+    // the wave's whole 64 x 64 slab is interior and on one side of act_cols (wave-uniform): the fast path below
+    const int wcol0 = n0 + wc * 64, wrow0 = m0 + wr * 64;
+    const bool slab_full = vec_ok && (wrow0 + 64 <= g.M) && (wcol0 + 64 <= g.N) && (wcol0 + 64 <= act_cols || wcol0 >= act_cols);
+    const bool slab_plain = kNeedH && wcol0 >= act_cols;
+    // fast-path addressing: one wave-uniform base per matrix (SGPRs; the wave id is made provably uniform) + a 32-bit
+    // per-lane byte offset, so no 64-bit per-lane pointer lives in VGPRs
+    const int uwid = __builtin_amdgcn_readfirstlane(wid);
+    const long long urow0 = m0 + (uwid >> 1) * 64, ucol0 = n0 + (uwid & 1) * 64;
+    const unsigned lrow = lane >> 4;
+    char* const Cu = reinterpret_cast<char*>(C + urow0 * g.ldc + ucol0);
+    char* const C2u = kNeedD ? reinterpret_cast<char*>(C2 + urow0 * g.ldc2 + ucol0) : nullptr;
+    const char* const Hu = kNeedH ? reinterpret_cast<const char*>(H + urow0 * g.ldh + ucol0) : nullptr;
+    const char* const Du = kNeedD ? reinterpret_cast<const char*>(D + urow0 * g.ldd + ucol0) : nullptr;
+    const char* const Au = kNeedAdd ? reinterpret_cast<const char*>(Cadd + urow0 * g.ldadd + ucol0) : nullptr;
+    const unsigned oC = (lrow * (unsigned)g.ldc + (unsigned)colq) * 4u, oC2 = (lrow * (unsigned)g.ldc2 + (unsigned)colq) * 4u;
+    const unsigned oH = (lrow * (unsigned)g.ldh + (unsigned)colq) * 4u, oD = (lrow * (unsigned)g.ldd + (unsigned)colq) * 4u;
+    const unsigned oA = (lrow * (unsigned)g.ldadd + (unsigned)colq) * 4u;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                scr[((r & 3) + 8 * (r >> 2) + 4 * lh) * EPI_LDS + tn * 32 + li] = acc[tm][tn][r];
+        if (lab_skip) {
+            if (acc[tm][0][0] == 123.456f) C[0] = acc[tm][1][3];      // keeps the accumulators live
+        } else if (slab_full) {
+            // wave-uniform fast path (every interior tile): straight-line code, no per-lane guards; the auxiliary loads of
+            // four row groups are in flight together; the activation math is branch-free (nu_common.h)
+            constexpr int NB = kNeedH ? NBH : 4;         // row groups in flight
+#pragma unroll
+            for (int hb = 0; hb < 8 / NB; ++hb) {
+                f32x4 v4[NB], h4[NB], d4[NB], c4v[NB];
+#pragma unroll
+                for (int ii = 0; ii < NB; ++ii) {
+                    const int i = hb * NB + ii;
+                    const long long roff = (long long)(tm * 32 + i * 4);
+                    v4[ii] = *reinterpret_cast<const f32x4*>(&scr[(i * 4 + (lane >> 4)) * EPI_LDS + colq]);
+                    if (kNeedH && !slab_plain && !(kMaskR && mwave)) h4[ii] = *reinterpret_cast<const f32x4*>(Hu + roff * g.ldh * 4 + oH);
+                    if (kNeedD && !slab_plain) d4[ii] = *reinterpret_cast<const f32x4*>(Du + roff * g.ldd * 4 + oD);
+                    if (kNeedAdd && !slab_plain) c4v[ii] = *reinterpret_cast<const f32x4*>(Au + roff * g.ldadd * 4 + oA);
+                }
+#pragma unroll
+                for (int ii = 0; ii < NB; ++ii) {
+                    const int i = hb * NB + ii;
+                    const long long roff = (long long)(tm * 32 + i * 4);
+                    f32x4 o4, o24;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float h = 0.f, o2 = 0.f;
+                        if (kMaskR && mwave) {
+                            const int src = (tm * 8 + i) * 4 + e;           // wave-uniform
+                            const unsigned lo = __builtin_amdgcn_readlane(mlo, src), hi = __builtin_amdgcn_readlane(mhi, src);
+                            h = (((lane < 32 ? lo : hi) >> (lane & 31)) & 1u) ? 1.0f : 0.0f;
+                        } else if (kNeedH && !slab_plain) h = h4[ii][e];
+                        const float v = g.alpha * v4[ii][e];
+                        o4[e] = slab_plain ? v : nu_epi_apply<EPI>(v, bv[e], h, (kNeedD && !slab_plain) ? d4[ii][e] : 0.f,
+                                                                   (kNeedAdd && !slab_plain) ? c4v[ii][e] : 0.f, o2);
+                        o24[e] = o2;
+                    }
+                    *reinterpret_cast<f32x4*>(Cu + roff * g.ldc * 4 + oC) = o4;
+                    if (kNeedD) *reinterpret_cast<f32x4*>(C2u + roff * g.ldc2 * 4 + oC2) = o24;
+                    if (kMaskW && mwave) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const unsigned long long bits = __ballot(o4[e] > 0.f);
+                            const bool mine = lane == (tm * 8 + i) * 4 + e;
+                            wlo = mine ? (unsigned)bits : wlo;
+                            whi = mine ? (unsigned)(bits >> 32) : whi;
+                        }
+                    }
+                }
+            }
+        } else if (gcol < zero_to) {
+#pragma unroll 4
+            for (int i = 0; i < 8; ++i) {
+                const int rl = i * 4 + (lane >> 4);
+                const int row = m0 + wr * 64 + tm * 32 + rl;
+                const f32x4 v4 = *reinterpret_cast<const f32x4*>(&scr[rl * EPI_LDS + colq]);
+                bool pos[4] = {false, false, false, false};     // ReLU output > 0 (rows past M and non-vector lanes: false)
+                if (row < g.M) {
+                if (full) {
+                    f32x4 h4 = {0.f, 0.f, 0.f, 0.f}, d4 = h4, c4v = h4, o4, o24;
+                    const bool plain = gcol >= act_cols;
+                    if (kMaskR && mwave) {
+                        if (!plain) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const int src = (tm * 8 + i) * 4 + e;           // wave-uniform
+                                const unsigned lo = __builtin_amdgcn_readlane(mlo, src), hi = __builtin_amdgcn_readlane(mhi, src);
+                                h4[e] = (((lane < 32 ? lo : hi) >> (lane & 31)) & 1u) ? 1.0f : 0.0f;
+                            }
+                        }
+                    } else if (kNeedH && !plain) h4 = *reinterpret_cast<const f32x4*>(H + (long long)row * g.ldh + gcol);
+                    if (kNeedD && !plain) d4 = *reinterpret_cast<const f32x4*>(D + (long long)row * g.ldd + gcol);
+                    if (kNeedAdd && !plain) c4v = *reinterpret_cast<const f32x4*>(Cadd + (long long)row * g.ldadd + gcol);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float o2;
+                        const float v = g.alpha * v4[e];
+                        o4[e] = (kNeedH && plain) ? v : nu_epi_apply<EPI>(v, bv[e], h4[e], d4[e], c4v[e], o2);
+                        o24[e] = (kNeedH && plain) ? 0.f : o2;
+                    }
+                    *reinterpret_cast<f32x4*>(C + (long long)row * g.ldc + gcol) = o4;
+                    if (kNeedD) *reinterpret_cast<f32x4*>(C2 + (long long)row * g.ldc2 + gcol) = o24;
+                    if (kMaskW) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) pos[e] = o4[e] > 0.f;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int col = gcol + e;
+                        if (col >= zero_to) continue;
+                        float out = 0.f, out2 = 0.f;
+                        if (col < g.N) {
+                            const float v = g.alpha * v4[e];
+                            if (kNeedH && col >= act_cols) {
+                                out = v;
+                            } else {
+                                const float h = kNeedH ? H[(long long)row * g.ldh + col] : 0.f;
+                                const float d = kNeedD ? D[(long long)row * g.ldd + col] : 0.f;
+                                const float ca = kNeedAdd ? Cadd[(long long)row * g.ldadd + col] : 0.f;
+                                out = nu_epi_apply<EPI>(v, bv[e], h, d, ca, out2);
+                            }
+                        }
+                        C[(long long)row * g.ldc + col] = out;
+                        if (kNeedD) C2[(long long)row * g.ldc2 + col] = out2;
+                    }
+                }
+                }
+                if (kMaskW && mwave) {      // every lane of the slab is here (N % 64 == 0 for a writer): ballots are complete
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const unsigned long long bits = __ballot(pos[e]);
+                        const bool mine = lane == (tm * 8 + i) * 4 + e;
+                        wlo = mine ? (unsigned)bits : wlo;
+                        whi = mine ? (unsigned)(bits >> 32) : whi;
+                    }
+                }
+            }
+        }
+    }
+    if (kMaskW && mwave) mwave[lane] = ((unsigned long long)whi << 32) | wlo;
+}
 
 // One LDS buffer (36.9 KB per workgroup) -> 3 workgroups per CU.  The next k-chunk travels global -> registers
 // under the MFMAs; only the register -> LDS hand-over sits between two barriers, and the other resident workgroups
@@ -173,27 +393,8 @@ __global__ __launch_bounds__(256, PREC == 2 ? 2 : NT_WPC) void gemm_nt_kernel(Nu
     store_regs();
     __syncthreads();
 
-    float* __restrict__ C = g.C + (long long)z * g.sC;
-    float* __restrict__ C2 = g.C2 ? g.C2 + (long long)z * g.sC2 : nullptr;
-    const float* __restrict__ bias = g.bias ? g.bias + (long long)z * g.sBias : nullptr;
-    const float* __restrict__ H = g.H ? g.H + (long long)z * g.sH : nullptr;
-    const float* __restrict__ D = g.D ? g.D + (long long)z * g.sD : nullptr;
-    const float* __restrict__ Cadd = g.Cadd ? g.Cadd + (long long)z * g.sCadd : nullptr;
-    const int zero_to = g.zero_to > g.N ? g.zero_to : g.N;
-    const int act_cols = g.act_cols > 0 ? g.act_cols : 0x7fffffff;
-    constexpr bool kMaskW = (EPI == NU_EPI_BIAS_RELU);                                  // writes ReLU sign bits
-    constexpr bool kMaskR = (EPI == NU_EPI_MUL_DRELU || EPI == NU_EPI_B_RELU);          // reads them instead of H
-    unsigned long long* __restrict__ mask = (kMaskW || kMaskR) ? g.mask : nullptr;
-    constexpr bool kNeedH = (EPI == NU_EPI_MUL_DRELU || EPI == NU_EPI_MUL_DSP || EPI == NU_EPI_Q_SP ||
-                             EPI == NU_EPI_B_SP || EPI == NU_EPI_B_RELU);
-    constexpr bool kNeedD = (EPI == NU_EPI_Q_SP);
-    constexpr bool kNeedAdd = (EPI == NU_EPI_B_SP || EPI == NU_EPI_B_RELU);
-    constexpr bool kBias = (EPI <= NU_EPI_BIAS_SOFTPLUS);
-    // 16-byte vector path needs every touched matrix 16-B aligned with ld % 4 == 0 (wave-uniform test)
-    bool vec_ok = (((uintptr_t)C & 15) == 0) && ((g.ldc & 3) == 0);
-    if (kNeedH) vec_ok = vec_ok && (((uintptr_t)H & 15) == 0) && ((g.ldh & 3) == 0);
-    if (kNeedD) vec_ok = vec_ok && (((uintptr_t)D & 15) == 0) && ((g.ldd & 3) == 0) && (((uintptr_t)C2 & 15) == 0) && ((g.ldc2 & 3) == 0);
-    if (kNeedAdd) vec_ok = vec_ok && (((uintptr_t)Cadd & 15) == 0) && ((g.ldadd & 3) == 0);
+    const NtEpiArgs<EPI> ea = nt_epi_args<EPI>(g, z);
+    constexpr bool kMaskR = NtEpiArgs<EPI>::kMaskR;
 
     while (true) {
         int mtn = 0, ntnx = 0;
@@ -202,13 +403,10 @@ __global__ __launch_bounds__(256, PREC == 2 ? 2 : NT_WPC) void gemm_nt_kernel(Nu
         const int m0 = mt * TBM, n0 = nt * TBN;
         // ReLU sign bits of this wave's 64x64 slab: 64 ballot words [tm][i][e], one per lane.  The reader fetches its word
         // here, a whole main loop ahead of the epilogue (the point of the exercise: no load latency left in the epilogue)
-        const int ct = z * ntn + nt;
-        unsigned long long* mwave = (mask && ct < g.mask_nct)
-                                        ? mask + ((((long long)mt * g.mask_nct + ct) * 4 + wid) * 64) : nullptr;
+        unsigned long long* mwave = nt_mask_words<EPI>(ea, g, mt, nt, z, ntn, wid);
         unsigned long long mword = 0;
         if (kMaskR && mwave) mword = mwave[lane];
         const unsigned mlo = (unsigned)mword, mhi = (unsigned)(mword >> 32);
-        unsigned wlo = 0, whi = 0;      // writer: lane l accumulates word l
 
         f32x16 acc[2][2];
 #pragma unroll
@@ -293,168 +491,12 @@ __global__ __launch_bounds__(256, PREC == 2 ? 2 : NT_WPC) void gemm_nt_kernel(Nu
 #ifdef NU_LAB
         if (tid == 0 && blockIdx.x < 1024 && lab_tile < NU_LAB_TILES) nu_lab_trace[blockIdx.x][lab_tile][1] = wall_clock64();
         const bool lab_skip = nu_lab_skip_epi != 0;
-        if (nu_lab_epi_prio == 1) __builtin_amdgcn_s_setprio(1);
-        if (nu_lab_epi_prio == 2) __builtin_amdgcn_s_setprio(2);
-        if (nu_lab_epi_prio == 3) __builtin_amdgcn_s_setprio(3);
 #else
         constexpr bool lab_skip = false;
 #endif
-        // ---- epilogue: accumulators -> wave-private LDS scratch (32 rows at a time) -> row-contiguous float4 ----
-        float* scr = &smem[0][0] + wid * (32 * EPI_LDS);
-        const int colq = (lane & 15) * 4;
-        const int gcol = n0 + wc * 64 + colq;
-        float bv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (kBias && bias) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) bv[e] = (gcol + e < g.N) ? bias[gcol + e] : 0.f;
-        }
-        const bool full = vec_ok && (gcol + 3 < g.N) && (gcol + 3 < act_cols || gcol >= act_cols);
-        // the wave's whole 64 x 64 slab is interior and on one side of act_cols (wave-uniform): the fast path below
-        const int wcol0 = n0 + wc * 64, wrow0 = m0 + wr * 64;
-        const bool slab_full = vec_ok && (wrow0 + 64 <= g.M) && (wcol0 + 64 <= g.N) && (wcol0 + 64 <= act_cols || wcol0 >= act_cols);
-        const bool slab_plain = kNeedH && wcol0 >= act_cols;
-        // fast-path addressing: one wave-uniform base per matrix (SGPRs; the wave id is made provably uniform) + a 32-bit
-        // per-lane byte offset, so no 64-bit per-lane pointer lives in VGPRs
-        const int uwid = __builtin_amdgcn_readfirstlane(wid);
-        const long long urow0 = m0 + (uwid >> 1) * 64, ucol0 = n0 + (uwid & 1) * 64;
-        const unsigned lrow = lane >> 4;
-        char* const Cu = reinterpret_cast<char*>(C + urow0 * g.ldc + ucol0);
-        char* const C2u = kNeedD ? reinterpret_cast<char*>(C2 + urow0 * g.ldc2 + ucol0) : nullptr;
-        const char* const Hu = kNeedH ? reinterpret_cast<const char*>(H + urow0 * g.ldh + ucol0) : nullptr;
-        const char* const Du = kNeedD ? reinterpret_cast<const char*>(D + urow0 * g.ldd + ucol0) : nullptr;
-        const char* const Au = kNeedAdd ? reinterpret_cast<const char*>(Cadd + urow0 * g.ldadd + ucol0) : nullptr;
-        const unsigned oC = (lrow * (unsigned)g.ldc + (unsigned)colq) * 4u, oC2 = (lrow * (unsigned)g.ldc2 + (unsigned)colq) * 4u;
-        const unsigned oH = (lrow * (unsigned)g.ldh + (unsigned)colq) * 4u, oD = (lrow * (unsigned)g.ldd + (unsigned)colq) * 4u;
-        const unsigned oA = (lrow * (unsigned)g.ldadd + (unsigned)colq) * 4u;
-#pragma unroll
-        for (int tm = 0; tm < 2; ++tm) {
-#pragma unroll
-            for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    scr[((r & 3) + 8 * (r >> 2) + 4 * lh) * EPI_LDS + tn * 32 + li] = acc[tm][tn][r];
-            if (lab_skip) {
-                if (acc[tm][0][0] == 123.456f) C[0] = acc[tm][1][3];      // keeps the accumulators live
-            } else if (slab_full) {
-                // wave-uniform fast path (every interior tile): straight-line code, no per-lane guards; the auxiliary loads of
-                // four row groups are in flight together; the activation math is branch-free (nu_common.h)
-                constexpr int NB = kNeedH ? 2 : 4;           // row groups in flight (register budget: 168 VGPRs at 3 waves / SIMD)
-#pragma unroll
-                for (int hb = 0; hb < 8 / NB; ++hb) {
-                    f32x4 v4[NB], h4[NB], d4[NB], c4v[NB];
-#pragma unroll
-                    for (int ii = 0; ii < NB; ++ii) {
-                        const int i = hb * NB + ii;
-                        const long long roff = (long long)(tm * 32 + i * 4);
-                        v4[ii] = *reinterpret_cast<const f32x4*>(&scr[(i * 4 + (lane >> 4)) * EPI_LDS + colq]);
-                        if (kNeedH && !slab_plain && !(kMaskR && mwave)) h4[ii] = *reinterpret_cast<const f32x4*>(Hu + roff * g.ldh * 4 + oH);
-                        if (kNeedD && !slab_plain) d4[ii] = *reinterpret_cast<const f32x4*>(Du + roff * g.ldd * 4 + oD);
-                        if (kNeedAdd && !slab_plain) c4v[ii] = *reinterpret_cast<const f32x4*>(Au + roff * g.ldadd * 4 + oA);
-                    }
-#pragma unroll
-                    for (int ii = 0; ii < NB; ++ii) {
-                        const int i = hb * NB + ii;
-                        const long long roff = (long long)(tm * 32 + i * 4);
-                        f32x4 o4, o24;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            float h = 0.f, o2 = 0.f;
-                            if (kMaskR && mwave) {
-                                const int src = (tm * 8 + i) * 4 + e;           // wave-uniform
-                                const unsigned lo = __builtin_amdgcn_readlane(mlo, src), hi = __builtin_amdgcn_readlane(mhi, src);
-                                h = (((lane < 32 ? lo : hi) >> (lane & 31)) & 1u) ? 1.0f : 0.0f;
-                            } else if (kNeedH && !slab_plain) h = h4[ii][e];
-                            const float v = g.alpha * v4[ii][e];
-                            o4[e] = slab_plain ? v : nu_epi_apply<EPI>(v, bv[e], h, (kNeedD && !slab_plain) ? d4[ii][e] : 0.f,
-                                                                       (kNeedAdd && !slab_plain) ? c4v[ii][e] : 0.f, o2);
-                            o24[e] = o2;
-                        }
-                        *reinterpret_cast<f32x4*>(Cu + roff * g.ldc * 4 + oC) = o4;
-                        if (kNeedD) *reinterpret_cast<f32x4*>(C2u + roff * g.ldc2 * 4 + oC2) = o24;
-                        if (kMaskW && mwave) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const unsigned long long bits = __ballot(o4[e] > 0.f);
-                                const bool mine = lane == (tm * 8 + i) * 4 + e;
-                                wlo = mine ? (unsigned)bits : wlo;
-                                whi = mine ? (unsigned)(bits >> 32) : whi;
-                            }
-                        }
-                    }
-                }
-            } else if (gcol < zero_to) {
-#pragma unroll 4
-                for (int i = 0; i < 8; ++i) {
-                    const int rl = i * 4 + (lane >> 4);
-                    const int row = m0 + wr * 64 + tm * 32 + rl;
-                    const f32x4 v4 = *reinterpret_cast<const f32x4*>(&scr[rl * EPI_LDS + colq]);
-                    bool pos[4] = {false, false, false, false};     // ReLU output > 0 (rows past M and non-vector lanes: false)
-                    if (row < g.M) {
-                    if (full) {
-                        f32x4 h4 = {0.f, 0.f, 0.f, 0.f}, d4 = h4, c4v = h4, o4, o24;
-                        const bool plain = gcol >= act_cols;
-                        if (kMaskR && mwave) {
-                            if (!plain) {
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) {
-                                    const int src = (tm * 8 + i) * 4 + e;           // wave-uniform
-                                    const unsigned lo = __builtin_amdgcn_readlane(mlo, src), hi = __builtin_amdgcn_readlane(mhi, src);
-                                    h4[e] = (((lane < 32 ? lo : hi) >> (lane & 31)) & 1u) ? 1.0f : 0.0f;
-                                }
-                            }
-                        } else if (kNeedH && !plain) h4 = *reinterpret_cast<const f32x4*>(H + (long long)row * g.ldh + gcol);
-                        if (kNeedD && !plain) d4 = *reinterpret_cast<const f32x4*>(D + (long long)row * g.ldd + gcol);
-                        if (kNeedAdd && !plain) c4v = *reinterpret_cast<const f32x4*>(Cadd + (long long)row * g.ldadd + gcol);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            float o2;
-                            const float v = g.alpha * v4[e];
-                            o4[e] = (kNeedH && plain) ? v : nu_epi_apply<EPI>(v, bv[e], h4[e], d4[e], c4v[e], o2);
-                            o24[e] = (kNeedH && plain) ? 0.f : o2;
-                        }
-                        *reinterpret_cast<f32x4*>(C + (long long)row * g.ldc + gcol) = o4;
-                        if (kNeedD) *reinterpret_cast<f32x4*>(C2 + (long long)row * g.ldc2 + gcol) = o24;
-                        if (kMaskW) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) pos[e] = o4[e] > 0.f;
-                        }
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const int col = gcol + e;
-                            if (col >= zero_to) continue;
-                            float out = 0.f, out2 = 0.f;
-                            if (col < g.N) {
-                                const float v = g.alpha * v4[e];
-                                if (kNeedH && col >= act_cols) {
-                                    out = v;
-                                } else {
-                                    const float h = kNeedH ? H[(long long)row * g.ldh + col] : 0.f;
-                                    const float d = kNeedD ? D[(long long)row * g.ldd + col] : 0.f;
-                                    const float ca = kNeedAdd ? Cadd[(long long)row * g.ldadd + col] : 0.f;
-                                    out = nu_epi_apply<EPI>(v, bv[e], h, d, ca, out2);
-                                }
-                            }
-                            C[(long long)row * g.ldc + col] = out;
-                            if (kNeedD) C2[(long long)row * g.ldc2 + col] = out2;
-                        }
-                    }
-                    }
-                    if (kMaskW && mwave) {      // every lane of the slab is here (N % 64 == 0 for a writer): ballots are complete
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const unsigned long long bits = __ballot(pos[e]);
-                            const bool mine = lane == (tm * 8 + i) * 4 + e;
-                            wlo = mine ? (unsigned)bits : wlo;
-                            whi = mine ? (unsigned)(bits >> 32) : whi;
-                        }
-                    }
-                }
-            }
-        }
-        if (kMaskW && mwave) mwave[lane] = ((unsigned long long)whi << 32) | wlo;
+        // ---- epilogue ----
+        nt_epilogue<EPI, 2>(g, ea, acc, &smem[0][0] + wid * (32 * EPI_LDS), m0, n0, mwave, mlo, mhi, lane, wid, lab_skip);
 #ifdef NU_LAB
-        __builtin_amdgcn_s_setprio(0);
         if (tid == 0 && blockIdx.x < 1024 && lab_tile < NU_LAB_TILES) nu_lab_trace[blockIdx.x][lab_tile][2] = wall_clock64();
         ++lab_tile;
         if (!has_next && tid == 0 && blockIdx.x == 0) { nu_dbg_clk[0] = clock64() - lab_c0; nu_dbg_clk[1] = wall_clock64() - lab_w0; }
@@ -463,6 +505,237 @@ __global__ __launch_bounds__(256, PREC == 2 ? 2 : NT_WPC) void gemm_nt_kernel(Nu
         __syncthreads();   // every wave is done with the scratch
         store_regs();
         __syncthreads();
+        j = jn; mt = mtn; nt = ntnx;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// NT kernel, exact fp32 MFMA, second generation: the main loop is software-pipelined INSIDE each wave.
+//
+// What the phase stamps of scripts/gemm_lab.hip showed about the first-generation kernel above (K = 256, 128 x 128 tiles):
+// a workgroup alone on its CU spends 22 us in a main loop whose 512 MFMAs per wave take 13.9 us -- every k-chunk pays
+// fragment-read latency (the ds_reads of the next k-group issue right before the last MFMA of the current one), a vmcnt
+// wait + eight ds_write_b128 + lgkmcnt(0) between two barriers, and a second fragment-read latency after them; three
+// co-resident workgroups only hide part of that (82 % of the matrix pipe without any epilogue).  Here
+//   * LDS holds TWO stages (73.7 KB, two workgroups per CU, up to 256 VGPRs): the next chunk is written to the other stage
+//     in the MIDDLE of the current chunk's MFMAs, so a chunk has ONE barrier and no store sits between barriers;
+//   * fragments are double-buffered in registers: the reads of k-group kk+1 issue before the MFMAs of kk;
+//   * the barrier sits after the third k-group; the first fragments of the NEXT chunk are read right behind it, under the
+//     16 MFMAs of the fourth k-group -- the matrix pipe never waits for LDS at a chunk boundary;
+//   * global loads run two chunks ahead of the MFMAs (one chunk in registers, one in LDS), across tile boundaries.
+// __builtin_amdgcn_sched_barrier(0) pins the order of the stages; inside a stage the compiler schedules freely.
+// The epilogue (shared with the first generation) uses the stage that was just consumed as its scratch.
+// ------------------------------------------------------------------------------------------------
+#define NT2_STAGE (2 * TBM * NT_LDS)   // floats per stage: [A 128 x 36 | B 128 x 36]
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_nt2_kernel(NuGemmNT g) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * NT2_STAGE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = tid >> 6;
+    const int wr = wid >> 1, wc = wid & 1;
+    const int z = blockIdx.z;
+    const int ntn = (g.N + TBN - 1) / TBN;
+    const int mtiles = (g.M + TBM - 1) / TBM;
+    const int nslots = ((mtiles + 7) / 8) * 8 * ntn;       // slot order: see gemm_nt_kernel
+    const float* __restrict__ A = g.A + (long long)z * g.sA;
+    const float* __restrict__ B = g.B + (long long)z * g.sB;
+    const int c4 = tid & 7;
+    const int r0 = tid >> 3;
+    const int nk = g.K / TBK;
+    const int li = lane & 31, lh = lane >> 5;
+    const int a_off = (wr * 64 + li) * NT_LDS + 4 * lh;
+    const int b_off = TBM * NT_LDS + (wc * 64 + li) * NT_LDS + 4 * lh;
+    const int w_off = r0 * NT_LDS + 4 * c4;                 // this thread's slot of a staged operand row group
+
+    auto slot_tile = [&](int j, int& mt, int& nt) -> bool {
+        const int grp = j / (8 * ntn);
+        const int rem = j - grp * 8 * ntn;
+        nt = rem >> 3;
+        mt = grp * 8 + (rem & 7);
+        return mt < mtiles;
+    };
+    auto next_valid = [&](int j, int& mt, int& nt) -> int {
+        while (j < nslots && !slot_tile(j, mt, nt)) j += gridDim.x;
+        return j;
+    };
+
+    int mt = 0, nt = 0;
+    int j = next_valid(blockIdx.x, mt, nt);
+    if (j >= nslots) return;
+
+    // ---- loader: a cursor over the chunks of this workgroup's tiles, in order ----
+    int ld_j = j, ld_kt = 0;                                // next chunk to fetch
+    const float* ap[4];
+    const float* bp[4];
+    f32x4 ra4[4], rb4[4];
+    auto set_ptrs = [&](int mt_, int nt_) {
+#ifdef NU_LAB
+        if (nu_lab_small_a) mt_ &= 63;                      // ablation: A stays cache-resident (8 MB window)
+#endif
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int ra = mt_ * TBM + r0 + 32 * i;
+            ra = ra < g.M ? ra : g.M - 1;
+            ap[i] = A + (long long)ra * g.lda + 4 * c4;
+            bp[i] = B + (long long)(nt_ * TBN + r0 + 32 * i) * g.ldb + 4 * c4;
+        }
+    };
+    // The loader is split in three so that its pieces can sit BETWEEN MFMAs (an in-order wave issues nothing while it waits
+    // for the matrix pipe; a ds_write_b128 takes ~43 cycles to issue, a global_load_dwordx4 ~34, an MFMA occupies the pipe 64):
+    //   load_piece(i)   global -> registers, rows r0 + 32 i of A and B, chunk at the cursor (always a valid address: past the
+    //                   last chunk the cursor stays on the last tile and the data is never used)
+    //   advance()       moves the cursor to the next chunk (scalar bookkeeping; pointer set-up once per tile)
+    //   write_piece(st, i)   registers -> LDS stage st
+    int ld_koff = 0;
+    auto load_piece = [&](int i) {
+        ra4[i] = *reinterpret_cast<const f32x4*>(ap[i] + ld_koff);
+        rb4[i] = *reinterpret_cast<const f32x4*>(bp[i] + ld_koff);
+    };
+    auto advance = [&]() {
+        if (ld_j >= nslots) return;
+        if (++ld_kt == nk) {
+            ld_kt = 0;
+            int m2 = 0, n2 = 0;
+            ld_j = next_valid(ld_j + gridDim.x, m2, n2);
+            if (ld_j < nslots) set_ptrs(m2, n2);
+        }
+        if (ld_j < nslots) ld_koff = ld_kt * TBK;
+    };
+    auto write_piece = [&](int st, int i) {
+        float* s0 = &smem[st * NT2_STAGE];
+        *reinterpret_cast<f32x4*>(&s0[w_off + 32 * i * NT_LDS]) = ra4[i];
+        *reinterpret_cast<f32x4*>(&s0[TBM * NT_LDS + w_off + 32 * i * NT_LDS]) = rb4[i];
+    };
+    struct Frag { f32x4 a0, a1, b0, b1; };
+    auto read_frag = [&](Frag& f, int st, int kk) {
+        const float* s0 = &smem[st * NT2_STAGE];
+        f.a0 = *reinterpret_cast<const f32x4*>(&s0[a_off + kk * 8]);
+        f.a1 = *reinterpret_cast<const f32x4*>(&s0[a_off + 32 * NT_LDS + kk * 8]);
+        f.b0 = *reinterpret_cast<const f32x4*>(&s0[b_off + kk * 8]);
+        f.b1 = *reinterpret_cast<const f32x4*>(&s0[b_off + 32 * NT_LDS + kk * 8]);
+    };
+
+    const NtEpiArgs<EPI> ea = nt_epi_args<EPI>(g, z);
+    constexpr bool kMaskR = NtEpiArgs<EPI>::kMaskR;
+
+#ifdef NU_LAB
+    int lab_tile = 0;
+    const unsigned long long lab_c0 = clock64(), lab_w0 = wall_clock64();
+#endif
+    // ---- prologue: chunk 0 -> stage 0, chunk 1 -> registers, first fragments ----
+    set_ptrs(mt, nt);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) load_piece(i);
+    advance();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) write_piece(0, i);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) load_piece(i);
+    advance();
+    __syncthreads();
+    Frag F0, F1;
+    read_frag(F0, 0, 0);
+    int cur = 0;
+
+    while (true) {
+        const int m0 = mt * TBM, n0 = nt * TBN;
+        unsigned long long* mwave = nt_mask_words<EPI>(ea, g, mt, nt, z, ntn, wid);
+        unsigned long long mword = 0;
+        if (kMaskR && mwave) mword = mwave[lane];
+        const unsigned mlo = (unsigned)mword, mhi = (unsigned)(mword >> 32);
+
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.0f;
+#ifdef NU_LAB
+        if (tid == 0 && blockIdx.x < 1024 && lab_tile < NU_LAB_TILES) nu_lab_trace[blockIdx.x][lab_tile][0] = wall_clock64();
+#endif
+#define NT2_QUAD(F, e)                                                                                     \
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(F.a0[e], F.b0[e], acc[0][0], 0, 0, 0);                 \
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(F.a0[e], F.b1[e], acc[0][1], 0, 0, 0);                 \
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(F.a1[e], F.b0[e], acc[1][0], 0, 0, 0);                 \
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(F.a1[e], F.b1[e], acc[1][1], 0, 0, 0);                 \
+    __builtin_amdgcn_sched_barrier(0);
+#define NT2_PIN __builtin_amdgcn_sched_barrier(0);
+#ifdef NU_LAB
+#define NT2_STAMP(I) if (lab_stamp && kt < 8) { nu_lab_stage[kt][I] = clock64(); __builtin_amdgcn_sched_barrier(0); }
+        const bool lab_stamp = nu_lab_stamps != 0 && tid == 0 && blockIdx.x == 0 && lab_tile == 2;
+#else
+#define NT2_STAMP(I)
+#endif
+        // One chunk = 4 k-groups of 16 MFMAs (4 quads).  Everything else sits between quads, pinned by sched_barrier(0):
+        //   k-group 0: fragment reads of k-group 1
+        //   k-group 1: fragment reads of k-group 2; the NEXT chunk goes registers -> other LDS stage (8 ds_write_b128)
+        //   k-group 2: fragment reads of k-group 3; the chunk AFTER that goes global -> registers (8 global_load_dwordx4)
+        //   barrier (the other stage is complete, this one fully consumed); first fragments of the next chunk
+        //   k-group 3: under which those fragments land
+        for (int kt = 0; kt < nk; ++kt) {
+            NT2_STAMP(0)
+            NT2_QUAD(F0, 0) NT2_QUAD(F0, 1)
+            read_frag(F1, cur, 1); NT2_PIN
+            NT2_QUAD(F0, 2) NT2_QUAD(F0, 3)
+            NT2_STAMP(1)
+            NT2_QUAD(F1, 0)
+            write_piece(cur ^ 1, 0); NT2_PIN
+            NT2_QUAD(F1, 1)
+            read_frag(F0, cur, 2); NT2_PIN
+            write_piece(cur ^ 1, 1); NT2_PIN
+            NT2_QUAD(F1, 2)
+            write_piece(cur ^ 1, 2); NT2_PIN
+            NT2_QUAD(F1, 3)
+            write_piece(cur ^ 1, 3); NT2_PIN
+            NT2_STAMP(2)
+            NT2_QUAD(F0, 0)
+            load_piece(0); NT2_PIN
+            NT2_QUAD(F0, 1)
+            read_frag(F1, cur, 3); NT2_PIN
+            load_piece(1); NT2_PIN
+            NT2_QUAD(F0, 2)
+            load_piece(2); NT2_PIN
+            NT2_QUAD(F0, 3)
+            load_piece(3); NT2_PIN
+            NT2_STAMP(4)
+            advance();
+            __syncthreads();        // the other stage is complete; every wave holds its last fragments of this one
+            NT2_STAMP(5)
+            read_frag(F0, cur ^ 1, 0);      // (after the very last chunk: stale bytes, never used)
+            NT2_PIN
+            NT2_QUAD(F1, 0) NT2_QUAD(F1, 1) NT2_QUAD(F1, 2) NT2_QUAD(F1, 3)
+            NT2_STAMP(6)
+            cur ^= 1;
+        }
+#undef NT2_QUAD
+#undef NT2_PIN
+#undef NT2_STAMP
+#undef NT2_GROUP
+#undef NT2_MFMA8
+#ifdef NU_LAB
+        if (tid == 0 && blockIdx.x < 1024 && lab_tile < NU_LAB_TILES) nu_lab_trace[blockIdx.x][lab_tile][1] = wall_clock64();
+        const bool lab_skip = nu_lab_skip_epi != 0;
+#else
+        constexpr bool lab_skip = false;
+#endif
+        // ---- epilogue: the stage consumed last (cur ^ 1 after the flip) is free until the next chunk's hand-over ----
+        nt_epilogue<EPI, 4>(g, ea, acc, &smem[(cur ^ 1) * NT2_STAGE] + wid * (32 * EPI_LDS), m0, n0, mwave, mlo, mhi, lane, wid, lab_skip);
+#ifdef NU_LAB
+        if (tid == 0 && blockIdx.x < 1024 && lab_tile < NU_LAB_TILES) nu_lab_trace[blockIdx.x][lab_tile][2] = wall_clock64();
+        ++lab_tile;
+#endif
+        int mtn = 0, ntnx = 0;
+        const int jn = next_valid(j + gridDim.x, mtn, ntnx);
+        if (jn >= nslots) {
+#ifdef NU_LAB
+            if (tid == 0 && blockIdx.x == 0) { nu_dbg_clk[0] = clock64() - lab_c0; nu_dbg_clk[1] = wall_clock64() - lab_w0; }
+#endif
+            break;
+        }
+        __syncthreads();            // every wave is done with the scratch before the next hand-over writes that stage
         j = jn; mt = mtn; nt = ntnx;
     }
 }
@@ -493,6 +766,31 @@ int nu_gemm_nt_launch(const NuGemmNT& g, hipStream_t stream) {
     long long per = nu_rup(nu_cdiv(grid_target, groups), 8);
     if (per > nslots) per = nslots;
     dim3 grid((unsigned)per, 1, groups), block(256);
+    static const bool v1_env = getenv("NU_NT_V1") && atoi(getenv("NU_NT_V1")) != 0;   // development switch: first-generation fp32 kernel
+    bool v1 = v1_env;
+#ifdef NU_LAB
+    v1 = nu_lab_v1 != 0;
+#endif
+    if (g.bf16 == 0 && !v1) {
+        long long per2 = nu_rup(nu_cdiv(grid_env ? grid_env : 512, groups), 8);       // two workgroups per CU
+        if (per2 > nslots) per2 = nslots;
+        dim3 grid2((unsigned)per2, 1, groups);
+        switch (g.epi) {
+#define NU_CASE2(E) case E: hipLaunchKernelGGL((gemm_nt2_kernel<E>), grid2, block, 0, stream, g); break;
+            NU_CASE2(NU_EPI_BIAS_NONE)
+            NU_CASE2(NU_EPI_BIAS_RELU)
+            NU_CASE2(NU_EPI_BIAS_SOFTPLUS)
+            NU_CASE2(NU_EPI_MUL_DRELU)
+            NU_CASE2(NU_EPI_MUL_DSP)
+            NU_CASE2(NU_EPI_Q_SP)
+            NU_CASE2(NU_EPI_B_SP)
+            NU_CASE2(NU_EPI_PLAIN)
+            NU_CASE2(NU_EPI_B_RELU)
+#undef NU_CASE2
+            default: return NU_ERR_ARG;
+        }
+        return nu_launch_status();
+    }
     switch (g.epi) {
 #define NU_CASE(E) case E: if (g.bf16 == 2) hipLaunchKernelGGL((gemm_nt_kernel<E, 2>), grid, block, 0, stream, g); \
                            else if (g.bf16 == 1) hipLaunchKernelGGL((gemm_nt_kernel<E, 1>), grid, block, 0, stream, g); \

@@ -91,42 +91,63 @@ int main(int argc, char** argv) {
     Bufs b1024 = b256;
     b1024.M = M / 4; b1024.K = 1024; b1024.B = dalloc(256 * 1024, 8, 0.06f);
     CK(hipDeviceSynchronize());
-    set_int(nu_lab_epi_prio, 0);
     set_int(nu_lab_skip_epi, 0);
     auto tf = [](const Bufs& b, double ms) { return 2.0 * b.M * b.N * b.K / ms / 1e9; };
     if (!strcmp(mode, "sweep")) {
         // warm the clocks
         for (int i = 0; i < 3; ++i) time_nt(b256, NU_EPI_PLAIN, 10);
-        for (int grid : {256, 512, 768}) {
-            nu_lab_grid = grid;
-            const double ms = time_nt(b256, NU_EPI_BIAS_SOFTPLUS, 20), ms2 = time_nt(b256, NU_EPI_PLAIN, 20), ms3 = time_nt(b1024, NU_EPI_PLAIN, 20);
-            printf("grid %4d : K=256 softplus %6.1f  K=256 plain %6.1f  K=1024 plain %6.1f TFLOP/s\n", grid, tf(b256, ms), tf(b256, ms2), tf(b1024, ms3));
-        }
-        nu_lab_grid = 0;
-        for (int skip = 0; skip < 2; ++skip) {
-            set_int(nu_lab_skip_epi, skip);
-            for (int epi : {NU_EPI_PLAIN, NU_EPI_BIAS_RELU, NU_EPI_BIAS_SOFTPLUS, NU_EPI_MUL_DSP, NU_EPI_Q_SP}) {
-                const double ms = time_nt(b256, epi, 20);
-                printf("K=256  epi=%d skip_epi=%d : %7.1f us  %6.1f TFLOP/s\n", epi, skip, ms * 1e3, tf(b256, ms));
-            }
-            const double ms = time_nt(b1024, NU_EPI_PLAIN, 20);
-            printf("K=1024 epi=7 skip_epi=%d : %7.1f us  %6.1f TFLOP/s\n", skip, ms * 1e3, tf(b1024, ms));
-        }
-        set_int(nu_lab_skip_epi, 0);
         Bufs bin = b256;
-        bin.M = 114048;                       // the step's inner-point count: 891 row tiles, 2.3 tiles per workgroup
+        bin.M = 114048;                       // the step's inner-point count: 891 row tiles
+        Bufs b64 = b256;
+        b64.K = 64;                           // input layers (A is read with lda = 64 from the same buffer)
         for (int pass = 0; pass < 2; ++pass)
-        for (int prio = 0; prio < 4; ++prio) {
-            set_int(nu_lab_epi_prio, prio);
-            double r[8];
-            int i = 0;
-            for (int epi : {NU_EPI_PLAIN, NU_EPI_BIAS_SOFTPLUS, NU_EPI_MUL_DSP, NU_EPI_Q_SP}) r[i++] = tf(b256, time_nt(b256, epi, 20));
-            r[i++] = tf(b1024, time_nt(b1024, NU_EPI_PLAIN, 20));
-            for (int epi : {NU_EPI_PLAIN, NU_EPI_BIAS_SOFTPLUS}) r[i++] = tf(bin, time_nt(bin, epi, 40));
-            printf("epilogue prio %d : M=540k K=256 plain %6.1f softplus %6.1f dsp %6.1f q_sp %6.1f | K=1024 M=135k plain %6.1f | M=114k K=256 plain %6.1f softplus %6.1f\n",
-                   prio, r[0], r[1], r[2], r[3], r[4], r[5], r[6]);
+        for (int v1 = 1; v1 >= 0; --v1) {
+            nu_lab_v1 = v1;
+            for (int grid : {0, 256}) {
+                nu_lab_grid = grid;
+                for (int skip = 0; skip < 2; ++skip) {
+                    set_int(nu_lab_skip_epi, skip);
+                    double r[10];
+                    int i = 0;
+                    for (int epi : {NU_EPI_PLAIN, NU_EPI_BIAS_RELU, NU_EPI_BIAS_SOFTPLUS, NU_EPI_MUL_DSP, NU_EPI_Q_SP}) r[i++] = tf(b256, time_nt(b256, epi, 20));
+                    r[i++] = tf(b1024, time_nt(b1024, NU_EPI_PLAIN, 20));
+                    for (int epi : {NU_EPI_BIAS_RELU, NU_EPI_BIAS_SOFTPLUS}) r[i++] = tf(bin, time_nt(bin, epi, 40));
+                    r[i++] = tf(b64, time_nt(b64, NU_EPI_BIAS_SOFTPLUS, 40));
+                    printf("gen %d grid %3d skip_epi %d : M=540k K=256 plain %6.1f relu %6.1f softplus %6.1f dsp %6.1f q_sp %6.1f | K=1024 %6.1f | M=114k relu %6.1f softplus %6.1f | K=64 softplus %6.1f\n",
+                           v1 ? 1 : 2, grid, skip, r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], r[8]);
+                }
+            }
         }
-        set_int(nu_lab_epi_prio, 0);
+        nu_lab_grid = 0; nu_lab_v1 = 0;
+        set_int(nu_lab_skip_epi, 0);
+    } else if (!strcmp(mode, "mem")) {
+        // is the lone workgroup's main loop waiting for memory?  A from an 8 MB window vs streamed from HBM
+        for (int small = 0; small < 2; ++small) {
+            set_int(nu_lab_small_a, small);
+            for (int grid : {256, 512}) {
+                nu_lab_grid = grid;
+                for (int skip = 1; skip >= 0; --skip) {
+                    set_int(nu_lab_skip_epi, skip);
+                    printf("gen 2 small_A %d grid %3d skip_epi %d : K=256 plain %6.1f relu %6.1f | K=1024 plain %6.1f TFLOP/s\n", small, grid, skip,
+                           tf(b256, time_nt(b256, NU_EPI_PLAIN, 20)), tf(b256, time_nt(b256, NU_EPI_BIAS_RELU, 20)), tf(b1024, time_nt(b1024, NU_EPI_PLAIN, 20)));
+                }
+            }
+        }
+        set_int(nu_lab_small_a, 0); set_int(nu_lab_skip_epi, 0); nu_lab_grid = 0;
+    } else if (!strcmp(mode, "stages")) {
+        // shader cycles one wave spends in each stage of a chunk (third tile of block 0), lone workgroup and two per CU
+        set_int(nu_lab_stamps, 1);
+        for (int grid : {256, 512}) {
+            nu_lab_grid = grid;
+            time_nt(b256, NU_EPI_BIAS_RELU, 2);
+            long long st[8][8];
+            CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(nu_lab_stage), sizeof(st)));
+            printf("grid %d: cycles per stage [k-group 0 | k-group 1 + LDS hand-over | k-group 2 + fetch | advance + barrier | k-group 3] (a k-group = 16 MFMAs = 1024 matrix cycles)\n", grid);
+            for (int kt = 0; kt < 8; ++kt)
+                printf("  chunk %d: %5lld %5lld %5lld %5lld %5lld   total %5lld\n", kt, st[kt][1] - st[kt][0], st[kt][2] - st[kt][1], st[kt][4] - st[kt][2],
+                       st[kt][5] - st[kt][4], st[kt][6] - st[kt][5], st[kt][6] - st[kt][0]);
+        }
+        set_int(nu_lab_stamps, 0); nu_lab_grid = 0;
     } else if (!strcmp(mode, "clock")) {
         // matrix-pipe rate and shader clock of the two f32 MFMA shapes on random register operands, 1..3 waves per SIMD
         float* src = dalloc(1 << 20, 99, 2.f);
@@ -152,20 +173,26 @@ int main(int argc, char** argv) {
                 }
             }
         }
-        // the real kernel: clock held by block 0 over its whole life
+        // the real kernels: clock held by block 0 over its whole life
+        for (int v1 = 1; v1 >= 0; --v1)
+        for (int grid : {256, 0})
         for (int skip = 0; skip < 2; ++skip) {
             set_int(nu_lab_skip_epi, skip);
+            nu_lab_v1 = v1; nu_lab_grid = grid;
             for (int epi : {NU_EPI_PLAIN, NU_EPI_BIAS_SOFTPLUS}) {
-                const double ms = time_nt(b256, epi, 20);
+                const double ms = time_nt(b256, epi, 30);
                 unsigned long long h[2];
                 CK(hipMemcpyFromSymbol(h, HIP_SYMBOL(nu_dbg_clk), sizeof(h)));
-                printf("NT K=256 epi=%d skip_epi=%d: %6.1f TFLOP/s, shader clock %.0f MHz\n", epi, skip, tf(b256, ms), (double)h[0] / (double)h[1] * 100.0);
+                const double mhz = (double)h[0] / (double)h[1] * 100.0;
+                printf("NT gen %d grid %3d K=256 epi=%d skip_epi=%d: %6.1f TFLOP/s, shader clock %.0f MHz -> %.1f %% of the matrix pipe at that clock\n", v1 ? 1 : 2, grid, epi, skip,
+                       tf(b256, ms), mhz, 100.0 * tf(b256, ms) / (157.3 * mhz / 2400.0));
             }
         }
+        nu_lab_v1 = 0; nu_lab_grid = 0; set_int(nu_lab_skip_epi, 0);
     } else {
         // traced launches: mean main-loop / epilogue duration per tile (tiles 1..5 of every workgroup), by grid size and epilogue
         static unsigned long long tr[1024][NU_LAB_TILES][3];
-        for (int grid : {256, 512, 768}) {
+        for (int grid : {256, 512}) {
             for (int epi : {NU_EPI_PLAIN, NU_EPI_BIAS_SOFTPLUS, NU_EPI_MUL_DSP, NU_EPI_Q_SP}) {
                 nu_lab_grid = grid;
                 const double ms = time_nt(b256, epi, 3);
