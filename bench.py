@@ -368,7 +368,7 @@ def main():
                 res["roofline"] = {"bound": "mfma", "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                    "frac": tf / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
                                    "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/r01/traffic_pmc.json)",
-                                   "kernel": "gemm_nt_kernel<*> (fp32 v_mfma_f32_32x32x2_f32)", **common}
+                                   "kernel": "gemm_nt2_kernel<*> (fp32 v_mfma_f32_32x32x2_f32, software-pipelined, 2 LDS stages)", **common}
         if world == 1 and not args.no_cpu_baseline and not args.real_capture and args.mlp_dtype == 'fp32':
             res["cpu_baseline"] = cpu_baseline(pool, args.start_step)
         print(json.dumps(res), flush=True)

@@ -101,8 +101,8 @@ int main(int argc, char** argv) {
         Bufs b64 = b256;
         b64.K = 64;                           // input layers (A is read with lda = 64 from the same buffer)
         for (int pass = 0; pass < 2; ++pass)
-        for (int v1 = 1; v1 >= 0; --v1) {
-            nu_lab_v1 = v1;
+        for (int gen = 1; gen <= 2; ++gen) {
+            nu_lab_v1 = gen == 1;
             for (int grid : {0, 256}) {
                 nu_lab_grid = grid;
                 for (int skip = 0; skip < 2; ++skip) {
@@ -114,7 +114,7 @@ int main(int argc, char** argv) {
                     for (int epi : {NU_EPI_BIAS_RELU, NU_EPI_BIAS_SOFTPLUS}) r[i++] = tf(bin, time_nt(bin, epi, 40));
                     r[i++] = tf(b64, time_nt(b64, NU_EPI_BIAS_SOFTPLUS, 40));
                     printf("gen %d grid %3d skip_epi %d : M=540k K=256 plain %6.1f relu %6.1f softplus %6.1f dsp %6.1f q_sp %6.1f | K=1024 %6.1f | M=114k relu %6.1f softplus %6.1f | K=64 softplus %6.1f\n",
-                           v1 ? 1 : 2, grid, skip, r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], r[8]);
+                           gen, grid, skip, r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], r[8]);
                 }
             }
         }

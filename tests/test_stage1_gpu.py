@@ -267,22 +267,50 @@ def test_standard_renderer_sphere_direction_vs_reference_golden(gpu):
     d = torch.nn.functional.normalize(torch.from_numpy(g['rays_d']).to(gpu), dim=-1)
     near, far = net.near_far_from_sphere(o, d)
     np.testing.assert_allclose(near.cpu().numpy(), g['near'], rtol=1e-5, atol=1e-6)
+    names = ['nerf_render', 'eikonal', 'std', 'init_sdf_reg', 'occ', 'outer_reg', 'normal_ori']
+    rgbs = torch.from_numpy(g['rgbs']).to(gpu)
+    # (1) render_core on the REFERENCE's z_vals: the sampler's last-bit sensitivity is out of the picture -> tight tolerances
+    out = net.render_core(o, d, torch.from_numpy(g['z_vals']).to(gpu), None, cos_anneal_ratio=net.get_anneal_val(step), step=step,
+                          is_train=True, is_nerf=False)
+    out['loss_rgb'] = net.compute_rgb_loss(out['ray_rgb'], rgbs)
+    total, log = total_loss(out, [name2loss[n](cfg) for n in names], step)
+    total.backward()
+    for k in ('ray_rgb', 'acc', 'color_bkgr', 'color_spec', 'loss_normal'):
+        np.testing.assert_allclose(out[k].detach().cpu().numpy(), g['out_' + k], rtol=1e-4, atol=2e-6, err_msg=k)
+    for k in g:
+        if k.startswith('term_') and k != 'term_loss_occ':      # the occlusion target runs a second inverse-CDF sampler
+            np.testing.assert_allclose(float(torch.mean(log[k[5:]]).detach()), float(g[k]), rtol=1e-4, atol=1e-7, err_msg=k)
+    np.testing.assert_allclose(float(log['loss_occ'].detach()), float(g['term_loss_occ']), rtol=2e-3)
+    np.testing.assert_allclose(float(total.detach()), float(g['total_loss']), rtol=2e-5)
+    named = dict(net.named_parameters())
+    bad = []
+    for n, ref_norm in zip([str(s) for s in g['grad_names']], g['grad_norms']):
+        assert named[n].grad is not None, n
+        err = abs(float(named[n].grad.double().norm()) - ref_norm) / (ref_norm + 1e-12)
+        # outer_light's first layers see the 72 + 72 IDE columns; the degree-8 / 16 terms make their weight gradients
+        # ill-conditioned in fp32: the CPU oracle itself sits 5e-3 (element-wise) from the reference on outer_light.0.weight_v,
+        # with the same worst columns (11, 19, 21-23: the l = 16 terms)
+        if err > (2e-3 if ('inner_weight' in n or 'outer_light' in n) else 3e-4):
+            bad.append((round(err, 6), n))
+    for k in g:
+        if k.startswith('grad__'):
+            err = rel_err(named[k[6:]].grad.cpu(), g[k])
+            if err > (3e-2 if 'outer_light.0' in k else 1.5e-3):     # measured 1.6e-2 / 7e-4 (oracle: 5e-3 / 5e-4)
+                bad.append((round(err, 6), k))
+    assert not bad, sorted(bad, reverse=True)[:10]
+    # (2) the whole entry point with the build's own sampler: z differs from the reference's in a few per cent of the samples
+    # (tests/test_stage1_gpu.py::test_sampler_matches_oracle), per-ray outputs do not care, element-wise gradients a little
+    net.zero_grad()
     out = net.render(o, d, near, far, None, -1, net.get_anneal_val(step), is_train=True, step=step, is_nerf=False,
                      rand=(torch.from_numpy(g['u1']).to(gpu), torch.from_numpy(g['u2']).to(gpu)))
-    out['loss_rgb'] = net.compute_rgb_loss(out['ray_rgb'], torch.from_numpy(g['rgbs']).to(gpu))
-    names = ['nerf_render', 'eikonal', 'std', 'init_sdf_reg', 'occ', 'outer_reg', 'normal_ori']
+    out['loss_rgb'] = net.compute_rgb_loss(out['ray_rgb'], rgbs)
     total, log = total_loss(out, [name2loss[n](cfg) for n in names], step)
     total.backward()
     for k in ('ray_rgb', 'acc', 'color_bkgr', 'color_spec', 'loss_normal'):
         np.testing.assert_allclose(out[k].detach().cpu().numpy(), g['out_' + k], rtol=2e-4, atol=3e-5, err_msg=k)
-    for k in g:
-        if k.startswith('term_'):
-            np.testing.assert_allclose(float(torch.mean(log[k[5:]]).detach()), float(g[k]), rtol=5e-4, atol=1e-7, err_msg=k)
     np.testing.assert_allclose(float(total.detach()), float(g['total_loss']), rtol=2e-5)
-    named = dict(net.named_parameters())
     for n, ref_norm in zip([str(s) for s in g['grad_names']], g['grad_norms']):
-        assert named[n].grad is not None, n
         assert abs(float(named[n].grad.double().norm()) - ref_norm) <= 3e-3 * ref_norm + 1e-9, (n, float(named[n].grad.norm()), ref_norm)
     for k in g:
         if k.startswith('grad__'):
-            assert rel_err(named[k[6:]].grad.cpu(), g[k]) < 1.5e-2, k   # element-wise: sensitive to the shifted samples
+            assert rel_err(named[k[6:]].grad.cpu(), g[k]) < 3e-2, k   # element-wise: sensitive to the shifted samples
