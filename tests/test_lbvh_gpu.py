@@ -1,5 +1,7 @@
 """GPU parity of the HIP LBVH (build + closest-hit traversal) against the brute-force oracle: hit flags and face
 indices BIT-EXACT (integer outputs), hit distance identical float32 bits."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -91,3 +93,35 @@ def test_scene_dintersect_matches_analytic_sphere(gpu):
     cosang = (inter['n'] * torch.nn.functional.normalize(p, dim=1)).sum(1)
     assert float(cosang.min()) > 0.999
     assert float(inter['t'].min()) > 0 and bool(((inter['u'] >= -1e-5) & (inter['v'] >= -1e-5) & (inter['u'] + inter['v'] <= 1 + 1e-5)).all())
+
+
+def test_mask_renderer_matches_brute_force_and_the_analytic_silhouette(gpu, tmp_path):
+    """N4: utils/render_mask_synthetic.py:64-75 on the LBVH.  Every pixel's hit flag equals the exhaustive tracer's; the
+    silhouette of an icosphere seen from distance 4 is the disc of angular radius asin(r / 4) (up to the facets)."""
+    from nu_nerf_amd.mask_render import render_masks, write_masks, pixel_directions
+    from nu_nerf_amd.lbvh import LBVH, icosphere
+    from nu_nerf_amd.synthetic import make_cameras
+    v, f = icosphere(3, 0.5)
+    V, Fc = torch.from_numpy(v).to(gpu), torch.from_numpy(f).to(gpu)
+    poses = torch.from_numpy(make_cameras(3, radius=4.0, seed=5)).to(gpu)
+    h = w = 96
+    focal = 0.5 * w / np.tan(0.5 * 0.6911)
+    K = torch.tensor([[focal, 0, w / 2], [0, focal, h / 2], [0, 0, 1]], dtype=torch.float32)
+    bvh = LBVH(V, Fc)
+    masks = render_masks(V, Fc, K, poses, h, w, bvh=bvh)
+    assert masks.shape == (3, h, w) and masks.dtype == torch.uint8 and set(np.unique(masks.cpu().numpy())) <= {0, 255}
+    dirs = pixel_directions(K, h, w, gpu)
+    for n in range(3):
+        rd = dirs @ poses[n, :3, :3].T
+        ray = torch.cat([poses[n, :3, 3].expand_as(rd), rd], 1)
+        hit_b, _ = bvh.intersect_brute(ray)
+        assert torch.equal(masks[n].reshape(-1) > 0, hit_b > 0)                          # bit-exact vs the O(N F) sweep
+        # analytic disc: the camera looks at the origin, so the pixel's angle from the optical axis decides
+        cosang = (torch.nn.functional.normalize(rd, dim=-1) @ (-torch.nn.functional.normalize(poses[n, :3, 3], dim=0)))
+        ang = torch.acos(cosang.clamp(-1, 1))
+        lim = np.arcsin(0.5 / 4.0)
+        inside, outside = ang < lim * 0.97, ang > lim * 1.01                              # facets sit slightly inside the sphere
+        m = masks[n].reshape(-1) > 0
+        assert bool(m[inside].all()) and not bool(m[outside].any()) and 0.01 < float(m.float().mean()) < 0.2
+    paths = write_masks(masks, str(tmp_path), ['r_0.png', 'r_1.png', 'r_2.png'])
+    assert all(os.path.getsize(p) > 0 for p in paths)

@@ -179,8 +179,10 @@ def test_fused_adam_resumes_state_with_differing_step_counts(gpu):
 
 
 def test_train_steps_across_freeze_inv_s_step(gpu):
-    """Steps 14999 / 15000 / 15001 with freeze_inv_s_step = 15000: the variance parameter has no gradient, then joins
-    the optimizer with its own step count.  FusedAdam and torch.optim.Adam on two replicas of the HIP renderer agree."""
+    """Steps 14999 / 15000 / 15001 with freeze_inv_s_step = 15000: the variance parameter has no gradient, then joins the
+    optimizer with its own step count.  The HIP renderer is trained with FusedAdam; a shadow copy of its parameters is fed
+    the SAME gradients and stepped by torch.optim.Adam -- the two parameter sets must stay together (same inputs to both
+    optimizers, so no chaotic amplification through the renderer)."""
     from nu_nerf_amd.renderer import NeROShapeRenderer
     from nu_nerf_amd.params import init_stage1_params
     from nu_nerf_amd.synthetic import make_rays, make_jitter
@@ -188,30 +190,28 @@ def test_train_steps_across_freeze_inv_s_step(gpu):
     from nu_nerf_amd.train_glue import FusedAdam
     cfg = {'name': 't', 'network': 'shape', 'database_name': 'synthetic/64', 'is_nerf': True, 'apply_occ_loss': True,
            'occ_loss_step': 15000, 'freeze_inv_s_step': 15000, 'n_samples': 16, 'n_importance': 16, 'n_bg_samples': 8}
-    nets, opts = [], []
-    for kind in (FusedAdam, torch.optim.Adam):
-        net = NeROShapeRenderer(cfg, training=False)
-        net.load_param_dict(init_stage1_params(6033))
-        nets.append(net.to(gpu))
-        opts.append(kind(nets[-1].parameters(), lr=1e-3))
+    net = NeROShapeRenderer(cfg, training=False)
+    net.load_param_dict(init_stage1_params(6033))
+    net = net.to(gpu)
+    opt = FusedAdam(net.parameters(), lr=1e-3)
+    shadow = [torch.nn.Parameter(p.detach().clone()) for p in net.parameters()]
+    sopt = torch.optim.Adam(shadow, lr=1e-3)
     losses = [name2loss[n](cfg) for n in SPHEREPOT_LOSSES]
+    var = net.deviation_network.variance
     var_hist = []
     for it, step in enumerate((14999, 15000, 15001)):
         rays = make_rays(48, seed=90 + it)
         u1, u2 = make_jitter(48, 8, seed=95 + it)
         batch = {k: torch.from_numpy(rays[k]).to(gpu) for k in ('rays_o', 'rays_d', 'rgbs')}
-        rand = (torch.from_numpy(u1).to(gpu), torch.from_numpy(u2).to(gpu))
-        for net, opt in zip(nets, opts):
-            opt.zero_grad(set_to_none=True)
-            total, _ = total_loss(net.train_step_rays(batch, step, rand=rand), losses, step)
-            total.backward()
-            opt.step()
-        var_hist.append((float(nets[0].deviation_network.variance), nets[0].deviation_network.variance.grad is not None))
-    assert var_hist[0] == (pytest.approx(0.3), False) and var_hist[1][1] and var_hist[1][0] != pytest.approx(0.3, abs=1e-7)
-    assert int(opts[0].state[nets[0].deviation_network.variance]['step']) == 2
-    assert int(opts[0].state[nets[0].sdf_network.lin0.bias]['step']) == 3
-    torch.testing.assert_close(nets[0].deviation_network.variance, nets[1].deviation_network.variance, rtol=1e-6, atol=1e-7)
-    for (n, a), (_, b) in zip(nets[0].named_parameters(), nets[1].named_parameters()):
-        # after the first update the replicas differ by an ulp, and elements whose gradient is a near-total cancellation turn
-        # that into a different m / sqrt(v): a few elements move by ~1 % of one Adam step (lr 1e-3) -- atol 1e-4 = 10 % of it (measured: single elements at 3e-5 .. 7e-5)
-        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-4, msg=lambda m: f"{n}: {m}")
+        opt.zero_grad(set_to_none=True)
+        total, _ = total_loss(net.train_step_rays(batch, step, rand=(torch.from_numpy(u1).to(gpu), torch.from_numpy(u2).to(gpu))), losses, step)
+        total.backward()
+        for p, q in zip(net.parameters(), shadow):
+            q.grad = None if p.grad is None else p.grad.detach().clone()
+        opt.step()
+        sopt.step()
+        var_hist.append((float(var), var.grad is not None))
+    assert var_hist[0] == (pytest.approx(0.3), False) and var_hist[1][1] and abs(var_hist[1][0] - 0.3) > 5e-4   # ~ one lr step
+    assert int(opt.state[var]['step']) == 2 and int(opt.state[net.sdf_network.lin0.bias]['step']) == 3
+    for (n, p), q in zip(net.named_parameters(), shadow):
+        torch.testing.assert_close(p, q, rtol=2e-6, atol=2e-7, msg=lambda m: f"{n}: {m}")
