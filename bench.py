@@ -190,6 +190,7 @@ def main():
     ap.add_argument('--real-capture', action='store_true',
                     help='real-capture code path (is_nerf False, sphere_direction True): BASELINE config 4 with --rays 8192 --mlp-dtype bf16')
     ap.add_argument('--no-kernel-timing', action='store_true')
+    ap.add_argument('--unfused-loss', action='store_true', help='assemble the loss with the eager torch registry (development A/B)')
     ap.add_argument('--time-every', type=int, default=0,
                     help='bracket the GEMM launches with HIP events on every Nth step of the timed region; 0 (default): on ONE '
                          'step in the middle of it (the ~330 event pairs cost that step 2-4 ms)')
@@ -223,7 +224,7 @@ def main():
     from nu_nerf_amd.renderer import NeROShapeRenderer
     from nu_nerf_amd.params import init_stage1_params
     from nu_nerf_amd.synthetic import make_rays, make_object_rays
-    from nu_nerf_amd.loss import name2loss, SPHEREPOT_LOSSES, total_loss
+    from nu_nerf_amd.loss import name2loss, SPHEREPOT_LOSSES, total_loss, fused_stage1_loss
     from nu_nerf_amd.parallel import GradAllReducer
     from nu_nerf_amd.train_glue import FusedAdam
 
@@ -258,10 +259,13 @@ def main():
         for g in opt.param_groups:
             g['lr'] = lr
         opt.zero_grad(set_to_none=True)
-        out = net.train_step_rays(batch_for(it), step)
-        if reducer is not None:     # eikonal mean over the union of all ranks' inner points (exact data parallelism)
-            out['gradient_error'] = out['gradient_error'] * reducer.point_weight(eng.last_ctx['P_in_dev'], dev)
-        total, _ = total_loss(out, losses, step)
+        if reducer is None and not args.unfused_loss:
+            total, _, _ = fused_stage1_loss(net, batch_for(it), step, losses)        # loss assembly on the HIP loss kernels
+        else:
+            out = net.train_step_rays(batch_for(it), step)
+            if reducer is not None:     # eikonal mean over the union of all ranks' inner points (exact data parallelism)
+                out['gradient_error'] = out['gradient_error'] * reducer.point_weight(eng.last_ctx['P_in_dev'], dev)
+            total, _ = total_loss(out, losses, step)
         total.backward()
         if reducer is not None:
             reducer.all_reduce()

@@ -254,6 +254,27 @@ int nu_brute_trace(const float* V, const int* F, int n_faces, const float* rays,
                    float* hit, int* idx, float* t_out, hipStream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * Fused loss assembly: from the renderer's per-ray outputs to the scalar the trainer back-propagates, for
+ * the loss set of the shipped stage-1 configs -- white background + clamp (renderer_zerothick.py:783-787), charbonier RGB
+ * loss (:501-513), colour_spec activation (:780-781), NeRFRenderLoss / EikonalLoss / OuterRegLoss / NormalOrientationLoss
+ * (network/loss.py:26-48, :194-213) and the trainer's sum of means (train/trainer_zero.py:153-161).
+ *   rgb, rgb_bg, spec_raw, gt [R,3]; acc, nrm_sum (optional) [R]; gerr [P] (P = 0: no inner point); cand (optional) u8[R]:
+ *   rays that take part in the outer regulariser.  Weights of inactive terms are passed as 0.
+ *   terms[6] = {loss_rgb, loss_eikonal, loss_outer_reg, loss_normal, their sum, candidate count}; per-ray outputs
+ *   ray_rgb / color_spec [R,3], loss_rgb [R].  nu_loss_bwd reads the upstream gradient from device memory.
+ * --------------------------------------------------------------------------------------------------------- */
+long long nu_loss_workspace_bytes(int R, int P);
+int nu_loss_fwd(const float* rgb, const float* acc, const float* rgb_bg, const float* spec_raw, const float* gerr,
+                const float* nrm_sum, const float* gt, const unsigned char* cand, int R, int P, int white_bg, float exp_max,
+                float w_eik, float w_reg, float w_nrm, float* ray_rgb, float* color_spec, float* loss_rgb, float* terms,
+                void* workspace, long long workspace_bytes, hipStream_t stream);
+int nu_loss_bwd(const float* rgb, const float* acc, const float* rgb_bg, const float* spec_raw, const float* gt,
+                const unsigned char* cand, const float* ray_rgb, const float* color_spec, const float* loss_rgb,
+                const float* terms, const float* upstream, int R, int P, int white_bg, float exp_max, float w_eik, float w_reg,
+                float w_nrm, float* d_rgb, float* d_acc, float* d_rgb_bg, float* d_spec_raw, float* d_gerr, float* d_nrm,
+                hipStream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
  * Trainer glue: torch.optim.Adam's update (train/trainer_zero.py:74-85, lr from
  * train/lr_common_manager.py:22-46) over many parameter tensors in one launch per NU_ADAM_MAX tensors.
  * p, g, m (exp_avg), v (exp_avg_sq): contiguous fp32 of n elements; step >= 1 is the count AFTER this update.

@@ -156,3 +156,108 @@ def total_loss(outputs, losses, step):
         if k.startswith('loss'):
             total = total + torch.mean(v)
     return total, log
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Fused loss assembly on the HIP loss kernels (csrc/loss.hip)
+# ------------------------------------------------------------------------------------------------------------------
+class _FusedLossFn(torch.autograd.Function):
+    """rgb, acc, rgb_bg, spec_raw, gerr, nrm_sum -> (sum of the fused loss terms, terms[6], ray_rgb, colour_spec, loss_rgb[R]).
+    Two launches forward, one backward; the upstream gradient never visits the host."""
+
+    @staticmethod
+    def forward(ctx, rgb, acc, rgb_bg, spec_raw, gerr, nrm_sum, gt, cand, white_bg, exp_max, w_eik, w_reg, w_nrm):
+        import ctypes
+        from . import _lib as L
+        lib = L.load()
+        lib.nu_loss_workspace_bytes.restype = ctypes.c_longlong
+        L.require_cuda(rgb, acc, rgb_bg, spec_raw, gt)
+        dev = rgb.device
+        R, P = rgb.shape[0], gerr.shape[0]
+        ts = [t.detach().contiguous() if t is not None else None for t in (rgb, acc, rgb_bg, spec_raw, gerr, nrm_sum, gt)]
+        rgb_, acc_, bg_, spec_, gerr_, nrm_, gt_ = ts
+        cand_ = None if cand is None else cand.to(torch.uint8).contiguous()
+        nb = lib.nu_loss_workspace_bytes(R, P)
+        ws = torch.empty((nb + 3) // 4, device=dev)
+        ray_rgb, color_spec, loss_rgb, terms = (torch.empty(R, 3, device=dev), torch.empty(R, 3, device=dev),
+                                                torch.empty(R, device=dev), torch.empty(6, device=dev))
+        L.check(lib.nu_loss_fwd(L.ptr(rgb_), L.ptr(acc_), L.ptr(bg_), L.ptr(spec_), L.ptr(gerr_ if P else None), L.ptr(nrm_), L.ptr(gt_),
+                                L.ptr(cand_), R, P, int(white_bg), ctypes.c_float(exp_max), ctypes.c_float(w_eik), ctypes.c_float(w_reg),
+                                ctypes.c_float(w_nrm), L.ptr(ray_rgb), L.ptr(color_spec), L.ptr(loss_rgb), L.ptr(terms), L.ptr(ws),
+                                ctypes.c_longlong(nb), L.stream()), "nu_loss_fwd")
+        ctx.save_for_backward(rgb_, acc_, bg_, spec_, gt_, ray_rgb, color_spec, loss_rgb, terms)
+        ctx.cand, ctx.nrm = cand_, nrm_ is not None
+        ctx.k = (R, P, int(white_bg), float(exp_max), float(w_eik), float(w_reg), float(w_nrm))
+        ctx.mark_non_differentiable(terms, ray_rgb, color_spec, loss_rgb)
+        return terms[4].clone(), terms, ray_rgb, color_spec, loss_rgb
+
+    @staticmethod
+    def backward(ctx, d_total, *_):
+        import ctypes
+        from . import _lib as L
+        lib = L.load()
+        rgb_, acc_, bg_, spec_, gt_, ray_rgb, color_spec, loss_rgb, terms = ctx.saved_tensors
+        R, P, white_bg, exp_max, w_eik, w_reg, w_nrm = ctx.k
+        dev = rgb_.device
+        up = d_total.detach().reshape(1).to(torch.float32).contiguous()
+        d_rgb, d_acc, d_bg, d_spec = (torch.empty(R, 3, device=dev), torch.empty(R, device=dev), torch.empty(R, 3, device=dev),
+                                      torch.empty(R, 3, device=dev))
+        d_gerr = torch.empty(P, device=dev)
+        d_nrm = torch.empty(R, device=dev) if ctx.nrm else None
+        L.check(lib.nu_loss_bwd(L.ptr(rgb_), L.ptr(acc_), L.ptr(bg_), L.ptr(spec_), L.ptr(gt_), L.ptr(ctx.cand), L.ptr(ray_rgb),
+                                L.ptr(color_spec), L.ptr(loss_rgb), L.ptr(terms), L.ptr(up), R, P, white_bg, ctypes.c_float(exp_max),
+                                ctypes.c_float(w_eik), ctypes.c_float(w_reg), ctypes.c_float(w_nrm), L.ptr(d_rgb), L.ptr(d_acc),
+                                L.ptr(d_bg), L.ptr(d_spec), L.ptr(d_gerr if P else None), L.ptr(d_nrm), L.stream()), "nu_loss_bwd")
+        return d_rgb, d_acc, d_bg, d_spec, d_gerr, d_nrm, None, None, None, None, None, None, None
+
+
+_FUSED_TYPES = None
+
+
+def fused_stage1_loss(renderer, batch, step, losses, rand=None):
+    """One training forward + the trainer's total (train/trainer_zero.py:153-161) with the loss assembly on the HIP loss
+    kernels: NeRFRenderLoss (charbonier), EikonalLoss, OuterRegLoss and NormalOrientationLoss are fused; StdRecorder, OccLoss,
+    InitSDFRegLoss and MaskLoss entries keep their (O(1)-sized) torch form and are added on.  Returns (total, log, outputs)
+    with the same log keys and values as `total_loss` gives on the unfused outputs."""
+    if renderer.cfg['rgb_loss'] != 'charbonier' or not any(isinstance(ls, NeRFRenderLoss) for ls in losses):
+        out = renderer.train_step_rays(batch, step, rand=rand)
+        total, log = total_loss(out, losses, step)
+        return total, log, out
+    out = renderer.train_step_rays(batch, step, rand=rand, fused=True)
+    raw = out.pop('_raw')
+    w_eik = w_reg = w_nrm = 0.0
+    rest = []
+    for ls in losses:
+        if isinstance(ls, EikonalLoss):
+            w_eik = float(ls.get_eikonal_weight(step))
+        elif isinstance(ls, OuterRegLoss):
+            w_reg = float(ls.cfg['outer_reg_loss_weight']) if step >= 15000 else 0.0
+        elif isinstance(ls, NormalOrientationLoss):
+            w_nrm = 1.0 if 'loss_normal' in out else 0.0
+        elif isinstance(ls, NeRFRenderLoss):
+            pass
+        else:
+            rest.append(ls)
+    gerr = raw['gerr']
+    nrm = raw['nrm_sum'] if w_nrm else None
+    total, terms, ray_rgb, color_spec, loss_rgb = _FusedLossFn.apply(
+        raw['rgb'], raw['acc'], raw['rgb_bg'], raw['spec_raw'], gerr, nrm, batch['rgbs'], raw['cand'], raw['is_nerf'], raw['exp_max'],
+        w_eik, w_reg, w_nrm)
+    cand = raw['cand']
+    out['ray_rgb'] = ray_rgb
+    out['color_spec'] = color_spec if cand is None else color_spec[cand]
+    out['color_bkgr'] = raw['rgb_bg'] if cand is None else raw['rgb_bg'][cand]
+    out['loss_rgb'] = loss_rgb
+    log = {'loss_rgb': loss_rgb}
+    log['loss_eikonal'] = terms[1].reshape(1)
+    if w_reg:
+        log['loss_outer_reg'] = terms[2]
+    if w_nrm:
+        log['loss_normal'] = terms[3].reshape(1)
+    for ls in rest:                      # std (log only), occ, init_sdf_reg, mask: already reduced or O(points in the shell)
+        extra = ls(out, {}, step)
+        for k, v in extra.items():
+            if k.startswith('loss'):
+                total = total + torch.mean(v)
+        log.update(extra)
+    return total, log, out

@@ -343,7 +343,7 @@ class NeROShapeRenderer(nn.Module):
                               far.reshape(-1).contiguous(), perturb, u1, u2)
 
     def render(self, rays_o, rays_d, near, far, human_poses=None, perturb_overwrite=-1, cos_anneal_ratio=0.0,
-               is_train=True, step=None, is_nerf=False, rand=None):
+               is_train=True, step=None, is_nerf=False, rand=None, fused=False):
         """Same contract as the reference `render` (renderer_zerothick.py:614-634).  `rand` optionally injects the
         sampler's two uniform draws, and as an optional third element the permutation of the occlusion-loss subsample
         (renderer_zerothick.py:710) -- parity tests."""
@@ -356,10 +356,10 @@ class NeROShapeRenderer(nn.Module):
             z_vals = self.sample_ray(rays_o, rays_d, near, far, perturb, rand)
         return self.render_core(rays_o, rays_d, z_vals, human_poses, cos_anneal_ratio=cos_anneal_ratio, step=step,
                                 is_train=is_train, is_nerf=is_nerf, _packed=True,
-                                occ_perm=rand[2] if rand is not None and len(rand) > 2 else None)
+                                occ_perm=rand[2] if rand is not None and len(rand) > 2 else None, fused=fused)
 
     def render_core(self, rays_o, rays_d, z_vals, human_poses=None, cos_anneal_ratio=0.0, step=None, is_train=True,
-                    is_nerf=False, _packed=False, occ_perm=None):
+                    is_nerf=False, _packed=False, occ_perm=None, fused=False):
         eng = self.engine()
         if not _packed:
             eng.pack()
@@ -368,16 +368,23 @@ class NeROShapeRenderer(nn.Module):
         spec_pts, cand = self._spec_query_points(rays_o, rays_d, z_vals)
         rgb, acc, rgb_bg, gerr, spec_raw, occ_raw, sdf_in, nrm_sum = _RenderCoreFn.apply(
             eng, rays_o, rays_d, z_vals, float(cos_anneal_ratio), not frozen, self._grad_names, spec_pts, *self._grad_params)
-        color = rgb + (1. - acc[..., None]) if is_nerf else rgb
         exp_max = eng.exp_max
-        color_spec = linear_to_srgb(torch.exp(torch.clamp(spec_raw, max=exp_max)))
-        outputs = {
-            'ray_rgb': torch.clamp(color, min=0.0, max=1.0),
-            'gradient_error': gerr if gerr.numel() else torch.zeros(1, device=rgb.device),
-            'acc': acc,
-            'color_bkgr': rgb_bg if cand is None else rgb_bg[cand],
-            'color_spec': color_spec if cand is None else color_spec[cand],
-        }
+        if fused and is_train:
+            # loss.fused_stage1_loss finishes the step in the HIP loss kernels: white background, clamp, colour_spec activation
+            # and every per-ray loss integrand are formed there, not in eager torch ops
+            outputs = {'gradient_error': gerr if gerr.numel() else torch.zeros(1, device=rgb.device), 'acc': acc,
+                       '_raw': dict(rgb=rgb, acc=acc, rgb_bg=rgb_bg, spec_raw=spec_raw, gerr=gerr, nrm_sum=nrm_sum, cand=cand,
+                                    is_nerf=bool(is_nerf), exp_max=float(exp_max))}
+        else:
+            color = rgb + (1. - acc[..., None]) if is_nerf else rgb
+            color_spec = linear_to_srgb(torch.exp(torch.clamp(spec_raw, max=exp_max)))
+            outputs = {
+                'ray_rgb': torch.clamp(color, min=0.0, max=1.0),
+                'gradient_error': gerr if gerr.numel() else torch.zeros(1, device=rgb.device),
+                'acc': acc,
+                'color_bkgr': rgb_bg if cand is None else rgb_bg[cand],
+                'color_spec': color_spec if cand is None else color_spec[cand],
+            }
         self._extra_outputs(outputs, nrm_sum)
         var = self.deviation_network.variance
         inv_s = torch.exp(var * 10.0).clip(1e-6, 1e6)
@@ -503,14 +510,16 @@ class NeROShapeRenderer(nn.Module):
             self._shuffle_train_batch()
         return self.train_step_rays(batch, step)
 
-    def train_step_rays(self, batch, step, rand=None):
-        """One training forward on an explicit ray batch {'rays_o','rays_d','rgbs'} (renderer_zerothick.py:447-466)."""
+    def train_step_rays(self, batch, step, rand=None, fused=False):
+        """One training forward on an explicit ray batch {'rays_o','rays_d','rgbs'} (renderer_zerothick.py:447-466).
+        fused=True leaves the colour finishing and the RGB loss to loss.fused_stage1_loss (HIP loss kernels)."""
         rays_o, rays_d, near, far, poses = self._process_nerf_ray_batch(batch)
         if not self.is_nerf:    # real captures: near / far bracket the unit sphere (renderer_zerothick.py:320-327, :357)
             near, far = self.near_far_from_sphere(rays_o, rays_d)
         outputs = self.render(rays_o, rays_d, near, far, poses, -1, self.get_anneal_val(step), is_train=True, step=step,
-                              is_nerf=self.is_nerf, rand=rand)
-        outputs['loss_rgb'] = self.compute_rgb_loss(outputs['ray_rgb'], batch['rgbs'])
+                              is_nerf=self.is_nerf, rand=rand, fused=fused)
+        if not fused:
+            outputs['loss_rgb'] = self.compute_rgb_loss(outputs['ray_rgb'], batch['rgbs'])
         return outputs
 
 

@@ -60,7 +60,7 @@ class NeROShapeRenderer(_ZeroThickRenderer):
         near, far = self.near_far_from_sphere(rays_o, rays_d)
         return rays_o, rays_d, near, far, self.get_human_coordinate_poses(poses)[idxs]
 
-    def train_step_rays(self, batch, step, rand=None, poses=None):
+    def train_step_rays(self, batch, step, rand=None, poses=None, fused=False):
         if 'dirs' in batch:
             rays_o, rays_d, near, far, hp = self._process_ray_batch(batch, poses)
         else:
@@ -68,8 +68,9 @@ class NeROShapeRenderer(_ZeroThickRenderer):
             if not self.is_nerf:    # explicit rays of a real capture: bracket the unit sphere like the base class does
                 near, far = self.near_far_from_sphere(rays_o, rays_d)
         outputs = self.render(rays_o, rays_d, near, far, hp, -1, self.get_anneal_val(step), is_train=True, step=step,
-                              is_nerf=self.is_nerf, rand=rand)
-        outputs['loss_rgb'] = self.compute_rgb_loss(outputs['ray_rgb'], batch['rgbs'])
+                              is_nerf=self.is_nerf, rand=rand, fused=fused)
+        if not fused:
+            outputs['loss_rgb'] = self.compute_rgb_loss(outputs['ray_rgb'], batch['rgbs'])
         if self.is_nerf and 'masks' in batch:
             outputs['loss_mask'] = F.l1_loss(batch['masks'], outputs['acc'], reduction='mean')
         return outputs

@@ -141,6 +141,13 @@ def train_step(network, optimizer, lr_manager, losses, step, batch=None, reducer
     store (forward({'step': step})); otherwise an explicit {'rays_o','rays_d','rgbs'} batch."""
     lr = lr_manager(optimizer, step)
     optimizer.zero_grad(set_to_none=True)
+    if batch is not None and reducer is None and hasattr(network, 'engine') and type(network).__name__ == 'NeROShapeRenderer':
+        # explicit stage-1 ray batch: loss assembly on the HIP loss kernels (loss.fused_stage1_loss), same total and log
+        from .loss import fused_stage1_loss
+        total, log_info, _ = fused_stage1_loss(network, batch, step, losses)
+        total.backward()
+        optimizer.step()
+        return total.detach(), log_info, lr
     outputs = network({'step': step}) if batch is None else network.train_step_rays(batch, step)
     if reducer is not None and reducer.world > 1:
         # per-point means (eikonal) become this rank's share of the mean over the union of all ranks' inner points, so the

@@ -185,3 +185,49 @@ def test_full_size_backward_sub_batch_property_and_oracle_spot_check(gpu):
             ('sdf_network.lin2.weight_v', 'outer_nerf.pts_linears.6.weight', 'color_network.refrac_light.2.weight_v')}
     print("oracle spot-check (24 rays of the 4096-ray batch), element-wise rel err:", errs)
     assert max(errs.values()) < 1e-3, errs          # 24 rays: few terms per sum, so fp32 ordering noise averages less (measured 4.4e-4)
+
+
+@pytest.mark.parametrize("std", [False, True])
+def test_fused_loss_kernels_equal_the_loss_registry(gpu, std):
+    """N1: loss.fused_stage1_loss (csrc/loss.hip) against the eager registry path (network/loss.py semantics) on the same
+    forward: total, every log term, per-ray outputs and every parameter gradient."""
+    from nu_nerf_amd.loss import name2loss, SPHEREPOT_LOSSES, total_loss, fused_stage1_loss
+    if std:
+        from helpers import STD_CFG   # noqa: F401
+        from nu_nerf_amd.renderer_std import NeROShapeRenderer as R
+        from nu_nerf_amd.params import init_stage1_params, randomize_for_parity
+        g = golden("train_std_step20000_r40.npz")
+        cfg = {'is_nerf': False, 'n_samples': 64, 'n_importance': 32, 'n_bg_samples': 16, 'freeze_inv_s_step': 15000,
+               'apply_occ_loss': True, 'occ_loss_step': 15000, 'eikonal_weight': 0.05, 'outer_reg_loss_weight': 0.1,
+               'shader_config': {'sphere_direction': True, 'human_light': False, 'refrac_freq': 3}}
+        names = ['nerf_render', 'eikonal', 'std', 'init_sdf_reg', 'occ', 'outer_reg', 'normal_ori']
+        def build():
+            n = R(cfg, training=False)
+            n.load_param_dict(randomize_for_parity(init_stage1_params(6033, sphere_direction=True, refrac_freq=3), seed=1))
+            return n.to(gpu)
+    else:
+        g = golden("train_step20000_r48.npz")
+        cfg, names = CFG, SPHEREPOT_LOSSES
+        def build():
+            return make_net(gpu)
+    step = int(g['step'])
+    batch = {k: torch.from_numpy(g[k]).to(gpu) for k in ('rays_o', 'rays_d', 'rgbs')}
+    rand = (torch.from_numpy(g['u1']).to(gpu), torch.from_numpy(g['u2']).to(gpu))
+    losses = [name2loss[n](cfg) for n in names]
+    a, b = build(), build()
+    out_a = a.train_step_rays(batch, step, rand=rand)
+    total_a, log_a = total_loss(out_a, losses, step)
+    total_a.backward()
+    total_b, log_b, out_b = fused_stage1_loss(b, batch, step, losses, rand=rand)
+    total_b.backward()
+    np.testing.assert_allclose(float(total_b.detach()), float(total_a.detach()), rtol=2e-6)
+    assert set(k for k in log_a if k.startswith('loss')) == set(k for k in log_b if k.startswith('loss'))
+    for k in log_a:
+        if k.startswith('loss'):
+            np.testing.assert_allclose(float(torch.mean(log_b[k]).detach()), float(torch.mean(log_a[k]).detach()), rtol=3e-6, atol=1e-9, err_msg=k)
+    for k in ('ray_rgb', 'color_spec', 'color_bkgr', 'loss_rgb'):
+        torch.testing.assert_close(out_b[k].detach(), out_a[k].detach(), rtol=2e-6, atol=2e-7)
+    for (n, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
+        assert (p.grad is None) == (q.grad is None), n
+        if p.grad is not None:
+            assert rel_err(q.grad, p.grad) < 1e-5, (n, rel_err(q.grad, p.grad))
