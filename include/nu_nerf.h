@@ -254,6 +254,93 @@ int nu_brute_trace(const float* V, const int* F, int n_faces, const float* rays,
                    float* hit, int* idx, float* t_out, hipStream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * Network-level entry points: one call sequences every kernel launch of a network pass from C++.
+ *   nu_sdf_mlp_{fwd,normal,bwd}      SDFNetwork.forward / .gradient and their (double) backward   field.py:133-170
+ *   nu_nerfpp_mlp_{fwd,bwd}          NeRFNetwork.forward / backward                               field.py:265-289
+ *   nu_shading_stack_{fwd,bwd}       AppShadingNetwork.forward / backward                         field.py:684-777, :636-682
+ * Buffers are the caller's (device pointers, layouts in DESIGN.md "Data layout in HBM"); NuLin holds one packed layer as
+ * nu_pack_layers leaves it.  Split reductions (weight gradients, skinny heads, column sums) go to the arena of NuOpCtx and
+ * are finished by nu_ctx_flush (or implicitly when the arena / descriptor list is full).  Bias gradients are written at
+ * NuOpCtx.flat + NuLin.db_off (the flat gradient buffer nu_unpack_grads reads).
+ * --------------------------------------------------------------------------------------------------------- */
+typedef struct NuLin {
+    const float* Wp; const float* WpT; float* dWp; const float* bias;
+    long long db_off;
+    int N, K, Kp, ldT, ldd, pad_;
+} NuLin;
+
+typedef struct NuOpCtx {
+    int prec, pad_;                       /* NuGemmNT.bf16 of every GEMM */
+    float* flat;                          /* flat gradient buffer of the current backward */
+    float* arena; long long arena_floats; long long arena_off;
+    NuReduceDesc* descs; int ndesc, cap;  /* HOST array of deferred reductions */
+} NuOpCtx;
+int nu_op_ctx_size(void);
+int nu_ctx_flush(NuOpCtx* ctx, hipStream_t stream);
+
+typedef struct NuSdfNet { NuLin lin[9]; } NuSdfNet;
+typedef struct NuSdfBufs {
+    int P, pad_;
+    float *E, *U4, *YX, *sdf;             /* E [P,64]; U4 [P,256]; YX [P,288] (want_feat) or sdf [P] */
+    float* H[9];                          /* H[1..8] [P,256] post-softplus, H[4] == U4 (inference: two ping-pong buffers) */
+    float* D[8]; float* G0; float* n;     /* reverse sweep: delta_l [P,256], G0 [P,64], n [P,3] */
+    float* Q[9]; float* C[8];             /* second-order: Q[0] [P,64], Q[1..8] [P,256] (Q[4] doubles as the skip slot), C_l [P,256] */
+    float* Aux[8];                        /* abar_l [P,256] of a first-order-only backward */
+    float* dE0;                           /* [P,64] (input gradient) */
+} NuSdfBufs;
+int nu_sdf_net_size(void);
+int nu_sdf_bufs_size(void);
+int nu_sdf_mlp_fwd(NuOpCtx* ctx, const NuSdfNet* net, const float* X, int x_ld, NuSdfBufs* bufs, int want_feat, hipStream_t stream);
+int nu_sdf_mlp_normal(NuOpCtx* ctx, const NuSdfNet* net, NuSdfBufs* bufs, hipStream_t stream);
+int nu_sdf_mlp_bwd(NuOpCtx* ctx, const NuSdfNet* net, NuSdfBufs* bufs, const float* dYX, const float* nbar, float* dx,
+                   hipStream_t stream);
+
+typedef struct NuNerfNet { NuLin pts[8]; NuLin feat, alpha, view, rgb; } NuNerfNet;
+typedef struct NuNerfBufs {
+    int P, pad_;
+    float* H[9];                          /* H[0] = E4 [P,96]; H[i] = input of layer i ([P,256]; H[5] = U5 [P,352]); H[8] last hidden */
+    unsigned long long* mask[9];          /* ReLU sign bits of H[1..8] */
+    float *V, *HV, *sig, *rgb;            /* V [P,288] = feature | view embedding; HV [P,128]; raw heads sig [P], rgb [P,4] */
+    float *dHV, *dF, *dH8a;               /* backward: [P,128], [P,256|288], [P,256] */
+    float* dA[9];                         /* dA[i] = d pre-activation of layer i-1's output, i = 1..8 ([P,256]; dA[5] [P,352] with dx) */
+    float *dE4, *dx, *ddir;               /* input gradients (stage 2): [P,96], [P,3], [P,3]; dx == NULL: parameters only */
+} NuNerfBufs;
+int nu_nerf_net_size(void);
+int nu_nerf_bufs_size(void);
+int nu_nerfpp_mlp_fwd(NuOpCtx* ctx, const NuNerfNet* net, const float* pt, int pt_ld, NuNerfBufs* bufs, hipStream_t stream);
+int nu_nerfpp_mlp_bwd(NuOpCtx* ctx, const NuNerfNet* net, const float* pt, int pt_ld, NuNerfBufs* bufs, const float* dsig,
+                      const float* drgb, hipStream_t stream);
+
+typedef struct NuShadeNet {
+    const float *WpM0, *WpTM0, *bM0; float* dWpM0;                  /* materials layer 0, 4 predictors side by side (N = 1024) */
+    const float* WpM[3]; const float* WpTM[3]; const float* bM[3]; float* dWpM[3];      /* [1], [2]: grouped x4 */
+    long long dbM_off[3];
+    const float *Ws6, *b6; float* dWs6; long long db6_off;          /* block-diagonal 6-wide head */
+    NuLin outer_light[4], inner_light[4], inner_weight[4], refrac_light[4];
+    const float* lut;
+    float exp_max; int sphere, ld_ol, refrac_dim, ld_rl, pad_;
+} NuShadeNet;
+typedef struct NuShadeBufs {
+    int P, R;                             /* inner points; per-ray mirror queries riding along the outer_light batch */
+    const float *extra_dirs, *extra_pts;
+    float* M[3]; unsigned long long* maskM[3]; float* Mraw;         /* materials hidden [P,1024] x3, raw heads [P,8] */
+    float *OLin, *ILin, *IWin, *RLin, *SD;                          /* predictor inputs, shading directions [P,8] */
+    float* OLh[3]; float* ILh[3]; float* IWh[3]; float* RLh[3];     /* hidden activations [rows,256] */
+    unsigned long long* maskOL[3]; unsigned long long* maskIL[3]; unsigned long long* maskIW[3]; unsigned long long* maskRL[3];
+    float *OLo, *ILo, *IWo, *RLo, *aux;                             /* raw heads, aux [P,4] */
+    float *dMraw, *dOLo, *dILo, *dIWo, *dRLo, *dNoV;                /* backward of the combine */
+    float* dH3[4]; float* tmpOL[2]; float* tmpIL[2]; float* tmpIW[2]; float* tmpRL[2];
+    float *dOLin, *dILin, *dn; float* dM[3]; float* dYX;
+} NuShadeBufs;
+int nu_shade_net_size(void);
+int nu_shade_bufs_size(void);
+int nu_shading_stack_fwd(NuOpCtx* ctx, const NuShadeNet* net, NuShadeBufs* bufs, const float* YX, const float* E, const float* nrm,
+                         const float* pt, const int* idx, float* color_rm, hipStream_t stream);
+/* stage 0: combine backward only (fills dMraw, dOLo, dILo, dIWo, dRLo, dNoV); stage 1: everything after it */
+int nu_shading_stack_bwd(NuOpCtx* ctx, const NuShadeNet* net, NuShadeBufs* bufs, const float* YX, const float* nrm, const float* pt,
+                         const int* idx, const float* dcolor_rm, int stage, hipStream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
  * Fused loss assembly: from the renderer's per-ray outputs to the scalar the trainer back-propagates, for
  * the loss set of the shipped stage-1 configs -- white background + clamp (renderer_zerothick.py:783-787), charbonier RGB
  * loss (:501-513), colour_spec activation (:780-781), NeRFRenderLoss / EikonalLoss / OuterRegLoss / NormalOrientationLoss

@@ -1,0 +1,393 @@
+// mlp_ops.hip -- network-level C entry points: nu_sdf_mlp_{fwd,normal,bwd}, nu_nerfpp_mlp_{fwd,bwd},
+// nu_shading_stack_{fwd,bwd}.  Each SEQUENCES the library's kernels for one network pass from C++ -- the launches a host
+// binding would otherwise issue one by one (about 500 per training step) -- over caller-provided buffers: the structs of
+// include/nu_nerf.h carry the packed layer tables (NuLin) and the activation / gradient buffers (device pointers borrowed
+// from the caller, layouts as in DESIGN.md "Data layout").  Nothing is allocated here; split reductions go to the
+// caller's arena through NuOpCtx and are finished by nu_ctx_flush.
+//
+// Reference code replaced (paths relative to /root/reference):
+//   SDFNetwork.forward / .gradient and their (double) backward     network/field.py:133-170
+//   NeRFNetwork.forward and backward                               network/field.py:265-289
+//   AppShadingNetwork.forward and backward                         network/field.py:684-777, :636-682, :371-408
+#include "gemm.h"
+
+#define CHK(x) do { const int rc_ = (x); if (rc_ != NU_OK) return rc_; } while (0)
+
+extern "C" int nu_skinny_fwd(const float*, int, int, int, const float*, int, const float*, int, float*, int, hipStream_t);
+extern "C" long long nu_skinny_bwd_workspace_bytes(int, int);
+extern "C" int nu_skinny_bwd_enqueue(const float*, int, const float*, int, int, int, const float*, int, int, float*, int, int, int,
+                                     float*, int, float*, void*, long long, NuReduceDesc*, int*, int, hipStream_t);
+extern "C" long long nu_colsum_workspace_bytes(int);
+extern "C" int nu_colsum_enqueue(const float*, int, int, int, float*, int, void*, long long, NuReduceDesc*, int*, int, hipStream_t);
+extern "C" int nu_rowscale_dsp(const float*, int, int, int, const float*, float*, int, hipStream_t);
+extern "C" long long nu_wgrad_workspace_bytes(int, int, int, int);
+extern "C" int nu_wgrad_enqueue(const NuGemmTN*, float*, int, long long, float*, long long, void*, long long, NuReduceDesc*, int*, int,
+                                hipStream_t);
+
+static inline int rup_i(int a, int b) { return (a + b - 1) / b * b; }
+
+// ---------------------------------------------------------------------------------------------------------
+// context: arithmetic mode + the deferred-reduction arena
+// ---------------------------------------------------------------------------------------------------------
+extern "C" int nu_op_ctx_size(void) { return (int)sizeof(NuOpCtx); }
+
+extern "C" int nu_ctx_flush(NuOpCtx* c, hipStream_t stream) {
+    if (c->ndesc > 0) {
+        CHK(nu_slab_reduce_batched(c->descs, c->ndesc, stream));
+        c->ndesc = 0;
+    }
+    c->arena_off = 0;
+    return NU_OK;
+}
+
+// `nbytes` of slab space that stays untouched until the next flush (stream order makes reuse after a flush safe)
+static int ctx_take(NuOpCtx* c, long long nbytes, int ndesc_needed, hipStream_t stream, float** out, long long* out_bytes) {
+    const long long n = (nbytes + 255) / 256 * 64;          // floats, 256-byte granules
+    if (n > c->arena_floats) return NU_ERR_WORKSPACE;
+    if (c->arena_off + n > c->arena_floats || c->ndesc + ndesc_needed > c->cap) CHK(nu_ctx_flush(c, stream));
+    *out = c->arena + c->arena_off;
+    *out_bytes = n * 4;
+    c->arena_off += n;
+    return NU_OK;
+}
+
+struct NtArgs {
+    const float* A; int lda; const float* B; int ldb; int M, N, K; float* C; int ldc; int epi;
+    float* C2 = nullptr; int ldc2 = 0; const float* bias = nullptr; const float* H = nullptr; int ldh = 0; const float* D = nullptr;
+    int ldd = 0; const float* Cadd = nullptr; int ldadd = 0; int zero_to = 0; int act_cols = 0; int groups = 1;
+    long long sA = 0, sB = 0, sC = 0, sBias = 0, sH = 0; unsigned long long* mask = nullptr; int mask_nct = 0;
+};
+static int nt(const NuOpCtx* c, const NtArgs& a, hipStream_t stream) {
+    if (a.M <= 0) return NU_OK;
+    NuGemmNT g = {};
+    g.A = a.A; g.lda = a.lda; g.B = a.B; g.ldb = a.ldb; g.M = a.M; g.N = a.N; g.K = a.K; g.C = a.C; g.ldc = a.ldc; g.C2 = a.C2;
+    g.ldc2 = a.ldc2; g.bias = a.bias; g.H = a.H; g.ldh = a.ldh; g.D = a.D; g.ldd = a.ldd; g.Cadd = a.Cadd; g.ldadd = a.ldadd;
+    g.zero_to = a.zero_to; g.act_cols = a.act_cols; g.alpha = 1.0f; g.groups = a.groups; g.sA = a.sA; g.sB = a.sB; g.sC = a.sC;
+    g.sBias = a.sBias; g.sH = a.sH; g.epi = a.epi; g.bf16 = c->prec; g.mask = a.mask; g.mask_nct = a.mask ? a.mask_nct : 0;
+    return nu_gemm_nt_launch(g, stream);
+}
+
+// dW[N1, N2] = A0^T B0 (+ A1^T B1), db = column sums of A0; the split follows the host layer's rule (512 workgroups)
+static int wgrad(NuOpCtx* c, const float* A0, int lda0, const float* B0, int ldb0, int P, int N1, int N2, float* dW, int ldw, float* db,
+                 hipStream_t stream, const float* A1 = nullptr, int lda1 = 0, const float* B1 = nullptr, int ldb1 = 0, int groups = 1,
+                 long long sA0 = 0, long long sB0 = 0, long long sW = 0, long long sDb = 0) {
+    if (P <= 0) return NU_OK;
+    const int tiles = ((N1 + 127) / 128) * ((N2 + 127) / 128) * groups;
+    int S = 512 / tiles;
+    if (S < 1) S = 1;
+    if (S > (P + 255) / 256) S = (P + 255) / 256;
+    if (S < 1) S = 1;
+    float* ws;
+    long long nb;
+    CHK(ctx_take(c, nu_wgrad_workspace_bytes(N1, N2, S, groups), 2 * groups, stream, &ws, &nb));
+    NuGemmTN g = {};
+    g.A0 = A0; g.lda0 = lda0; g.B0 = B0; g.ldb0 = ldb0; g.A1 = A1; g.lda1 = lda1; g.B1 = B1; g.ldb1 = ldb1; g.P = P; g.N1 = N1;
+    g.N2 = N2; g.S = S; g.groups = groups; g.sA0 = sA0; g.sB0 = sB0; g.bf16 = c->prec;
+    return nu_wgrad_enqueue(&g, dW, ldw, sW, db, sDb, ws, nb, c->descs, &c->ndesc, c->cap, stream);
+}
+
+static int skinny_bwd(NuOpCtx* c, const float* dy, int ldy, const float* H, int ldh, int P, int K, const float* Ws, int ldw, int NO,
+                      float* dH, int lddh, int relu_mask, float* dWs, int lddw, float* db, hipStream_t stream) {
+    if (P <= 0) return NU_OK;
+    float* ws;
+    long long nb;
+    CHK(ctx_take(c, nu_skinny_bwd_workspace_bytes(K, NO), 2, stream, &ws, &nb));
+    return nu_skinny_bwd_enqueue(dy, ldy, H, ldh, P, K, Ws, ldw, NO, dH, lddh, relu_mask, 0, dWs, lddw, db, ws, nb, c->descs, &c->ndesc,
+                                 c->cap, stream);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// SDF network (field.py:133-170): dims 39 -> 256 x3 -> 217 (+39 skip) -> 256 x4 -> 257, Softplus(beta = 100)
+// ---------------------------------------------------------------------------------------------------------
+extern "C" int nu_sdf_net_size(void) { return (int)sizeof(NuSdfNet); }
+extern "C" int nu_sdf_bufs_size(void) { return (int)sizeof(NuSdfBufs); }
+
+extern "C" int nu_sdf_mlp_fwd(NuOpCtx* c, const NuSdfNet* net, const float* X, int x_ld, NuSdfBufs* a, int want_feat,
+                              hipStream_t stream) {
+    const int P = a->P;
+    if (P <= 0) return NU_OK;
+    CHK(nu_sdf_embed(X, x_ld, P, a->E, a->U4, want_feat ? a->YX : nullptr, stream));
+    const float* src = a->E;
+    int lds = 64, K = 64;
+    for (int l = 0; l < 8; ++l) {
+        const NuLin& L = net->lin[l];
+        NtArgs g = {src, lds, L.Wp, L.Kp, P, L.N, K, a->H[l + 1], 256, NU_EPI_BIAS_SOFTPLUS};
+        g.bias = L.bias; g.zero_to = L.N;
+        CHK(nt(c, g, stream));
+        src = a->H[l + 1]; lds = 256; K = 256;
+    }
+    const NuLin& L8 = net->lin[8];
+    if (want_feat) {     // row 0 = sdf (skinny), rows 1..256 = feature
+        CHK(nu_skinny_fwd(a->H[8], 256, P, 256, L8.Wp, 256, L8.bias, 1, a->YX, 288, stream));
+        NtArgs g = {a->H[8], 256, L8.Wp + 256, 256, P, 256, 256, a->YX + 1, 288, NU_EPI_BIAS_NONE};
+        g.bias = L8.bias + 1;
+        CHK(nt(c, g, stream));
+    } else {
+        CHK(nu_skinny_fwd(a->H[8], 256, P, 256, L8.Wp, 256, L8.bias, 1, a->sdf, 1, stream));
+    }
+    return NU_OK;
+}
+
+// reverse sweep: n = d sdf / d x, keeping delta_l for the second-order backward
+extern "C" int nu_sdf_mlp_normal(NuOpCtx* c, const NuSdfNet* net, NuSdfBufs* a, hipStream_t stream) {
+    const int P = a->P;
+    if (P <= 0) return NU_OK;
+    const NuLin* ls = net->lin;
+    CHK(nu_rowscale_dsp(a->H[8], 256, P, 256, ls[8].Wp, a->D[7], 256, stream));
+    for (int l = 7; l > 0; --l) {
+        const int Kred = rup_i(ls[l].N, 32);
+        NtArgs g = {a->D[l], 256, ls[l].WpT, ls[l].ldT, P, l == 4 ? 256 : ls[l - 1].N, Kred, a->D[l - 1], 256, NU_EPI_MUL_DSP};
+        g.H = a->H[l]; g.ldh = 256;
+        if (l == 4) g.act_cols = 217;      // columns 217..255 are the skip gradient w.r.t. the embedding: written plain
+        else g.zero_to = 256;
+        CHK(nt(c, g, stream));
+    }
+    NtArgs g0 = {a->D[0], 256, ls[0].WpT, ls[0].ldT, P, 39, 256, a->G0, 64, NU_EPI_PLAIN};
+    g0.zero_to = 64;
+    CHK(nt(c, g0, stream));
+    return nu_embed_jt(a->E, a->G0, 64, a->D[3] + 217, 256, P, a->n, stream);
+}
+
+// backward of (y, n) w.r.t. the parameters (and x when dx != NULL) given dYX [P,288] and nbar [P,3] (NULL: first order)
+extern "C" int nu_sdf_mlp_bwd(NuOpCtx* c, const NuSdfNet* net, NuSdfBufs* a, const float* dYX, const float* nbar, float* dx,
+                              hipStream_t stream) {
+    const int P = a->P;
+    if (P <= 0) return NU_OK;
+    const NuLin* ls = net->lin;
+    const bool second = nbar != nullptr;
+    if (second) {
+        CHK(nu_embed_j(a->E, nbar, P, a->Q[0], a->Q[4], stream));
+        const float* src = a->Q[0];
+        int lds = 64, K = 64;
+        for (int l = 0; l < 8; ++l) {
+            NtArgs g = {src, lds, ls[l].Wp, ls[l].Kp, P, ls[l].N, K, a->Q[l + 1], 256, NU_EPI_Q_SP};
+            g.C2 = a->C[l]; g.ldc2 = 256; g.H = a->H[l + 1]; g.ldh = 256; g.D = a->D[l]; g.ldd = 256; g.zero_to = l == 3 ? ls[l].N : 256;
+            CHK(nt(c, g, stream));
+            src = a->Q[l + 1]; lds = 256; K = 256;
+        }
+    }
+    // B sweep: abar_l (written over C_l when second order)
+    float* A[8];
+    for (int l = 7; l >= 0; --l) {
+        const float* srcA; int lda, K; const float* WT; int ldT;
+        if (l == 7) { srcA = dYX; lda = 288; K = 288; WT = ls[8].WpT; ldT = ls[8].ldT; }
+        else { srcA = A[l + 1]; lda = 256; K = rup_i(ls[l + 1].N, 32); WT = ls[l + 1].WpT; ldT = ls[l + 1].ldT; }
+        A[l] = second ? a->C[l] : a->Aux[l];
+        NtArgs g = {srcA, lda, WT, ldT, P, ls[l].N, K, A[l], 256, second ? NU_EPI_B_SP : NU_EPI_MUL_DSP};
+        g.H = a->H[l + 1]; g.ldh = 256; g.Cadd = second ? a->C[l] : nullptr; g.ldadd = 256;
+        if (l == 3 && dx != nullptr) { g.N = 256; g.act_cols = 217; }     // keep the plain skip columns 217..255
+        else g.zero_to = 256;
+        CHK(nt(c, g, stream));
+    }
+    for (int l = 0; l < 8; ++l) {
+        const float* u = l == 0 ? a->E : a->H[l];
+        const int ldu = l == 0 ? 64 : 256;
+        if (second) CHK(wgrad(c, A[l], 256, u, ldu, P, ls[l].N, ls[l].Kp, ls[l].dWp, ls[l].ldd, c->flat + ls[l].db_off, stream, a->D[l], 256, a->Q[l],
+                              l == 0 ? 64 : 256));
+        else CHK(wgrad(c, A[l], 256, u, ldu, P, ls[l].N, ls[l].Kp, ls[l].dWp, ls[l].ldd, c->flat + ls[l].db_off, stream));
+    }
+    CHK(wgrad(c, dYX, 288, a->H[8], 256, P, 257, 256, ls[8].dWp, 256, c->flat + ls[8].db_off, stream));
+    if (second) {          // d W8[sdf row] += sum_p q_8
+        float* ws; long long nb;
+        CHK(ctx_take(c, nu_colsum_workspace_bytes(256), 1, stream, &ws, &nb));
+        CHK(nu_colsum_enqueue(a->Q[8], 256, P, 256, ls[8].dWp, 1, ws, nb, c->descs, &c->ndesc, c->cap, stream));
+    }
+    if (dx != nullptr) {
+        NtArgs g = {A[0], 256, ls[0].WpT, ls[0].ldT, P, 39, 256, a->dE0, 64, NU_EPI_PLAIN};
+        g.zero_to = 64;
+        CHK(nt(c, g, stream));
+        CHK(nu_embed_jt2(a->E, a->dE0, 64, A[3] + 217, 256, second ? a->G0 : nullptr, 64, second ? a->D[3] + 217 : nullptr, 256,
+                         second ? nbar : nullptr, P, dx, 0, stream));
+    }
+    return NU_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// make_predictor stacks (field.py:371-408): 3 hidden ReLU layers + a 1..3-wide head
+// ---------------------------------------------------------------------------------------------------------
+static int relu_stack_fwd(NuOpCtx* c, const NuLin* ls, const float* X, int ldx, int rows, float* const* Hs, unsigned long long* const* masks,
+                          int nct, hipStream_t stream) {
+    const float* src = X;
+    int lds = ldx;
+    for (int j = 0; j < 3; ++j) {
+        NtArgs g = {src, lds, ls[j].Wp, ls[j].Kp, rows, 256, ls[j].Kp, Hs[j], 256, NU_EPI_BIAS_RELU};
+        g.bias = ls[j].bias; g.mask = masks[j]; g.mask_nct = nct;
+        CHK(nt(c, g, stream));
+        src = Hs[j]; lds = 256;
+    }
+    return NU_OK;
+}
+// dH3: gradient w.r.t. the pre-activation of layer 2; tmp[2]: [rows,256] scratch; dX (optional): input gradient
+static int relu_stack_bwd(NuOpCtx* c, const NuLin* ls, const float* X, int ldx, int rows, float* const* Hs,
+                          unsigned long long* const* masks, int nct, const float* dH3, float* const* tmp, float* dX, int lddx, int dx_cols,
+                          hipStream_t stream) {
+    const float* dA = dH3;
+    for (int j = 2; j >= 0; --j) {
+        const float* u = j == 0 ? X : Hs[j - 1];
+        const int ldu = j == 0 ? ldx : 256;
+        CHK(wgrad(c, dA, 256, u, ldu, rows, 256, ls[j].Kp, ls[j].dWp, ls[j].ldd, c->flat + ls[j].db_off, stream));
+        if (j > 0) {
+            NtArgs g = {dA, 256, ls[j].WpT, ls[j].ldT, rows, 256, 256, tmp[j - 1], 256, NU_EPI_MUL_DRELU};
+            g.H = Hs[j - 1]; g.ldh = 256; g.mask = masks[j - 1]; g.mask_nct = nct;
+            CHK(nt(c, g, stream));
+            dA = tmp[j - 1];
+        } else if (dX != nullptr) {
+            NtArgs g = {dA, 256, ls[j].WpT, ls[j].ldT, rows, dx_cols, 256, dX, lddx, NU_EPI_PLAIN};
+            CHK(nt(c, g, stream));
+        }
+    }
+    return NU_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// NeRF++ (field.py:265-289): 8 x 256 ReLU with the 84-d embedding re-concatenated before layer 5, alpha / feature heads,
+// one 283 -> 128 view layer, rgb head
+// ---------------------------------------------------------------------------------------------------------
+extern "C" int nu_nerf_net_size(void) { return (int)sizeof(NuNerfNet); }
+extern "C" int nu_nerf_bufs_size(void) { return (int)sizeof(NuNerfBufs); }
+
+extern "C" int nu_nerfpp_mlp_fwd(NuOpCtx* c, const NuNerfNet* net, const float* pt, int pt_ld, NuNerfBufs* b, hipStream_t stream) {
+    const int P = b->P;
+    if (P <= 0) return NU_OK;
+    CHK(nu_nerf_embed(pt, pt_ld, P, b->H[0], b->H[5], b->V, stream));
+    const float* src = b->H[0];
+    int lds = 96;
+    for (int i = 0; i < 8; ++i) {
+        const NuLin& L = net->pts[i];
+        const int ldc = i == 4 ? 352 : 256;
+        NtArgs g = {src, lds, L.Wp, L.Kp, P, 256, L.Kp, b->H[i + 1], ldc, NU_EPI_BIAS_RELU};
+        g.bias = L.bias; g.mask = b->mask[i + 1]; g.mask_nct = 2;
+        CHK(nt(c, g, stream));
+        src = b->H[i + 1]; lds = ldc;
+    }
+    CHK(nu_skinny_fwd(b->H[8], 256, P, 256, net->alpha.Wp, 256, net->alpha.bias, 1, b->sig, 1, stream));
+    NtArgs gf = {b->H[8], 256, net->feat.Wp, 256, P, 256, 256, b->V, 288, NU_EPI_BIAS_NONE};
+    gf.bias = net->feat.bias;
+    CHK(nt(c, gf, stream));
+    NtArgs gv = {b->V, 288, net->view.Wp, 288, P, 128, 288, b->HV, 128, NU_EPI_BIAS_RELU};
+    gv.bias = net->view.bias;
+    CHK(nt(c, gv, stream));
+    return nu_skinny_fwd(b->HV, 128, P, 128, net->rgb.Wp, 128, net->rgb.bias, 3, b->rgb, 4, stream);
+}
+
+// raw head cotangents dsig [P], drgb [P,4] -> parameter gradients (and dx, ddir when b->dx != NULL)
+extern "C" int nu_nerfpp_mlp_bwd(NuOpCtx* c, const NuNerfNet* net, const float* pt, int pt_ld, NuNerfBufs* b, const float* dsig,
+                                 const float* drgb, hipStream_t stream) {
+    const int P = b->P;
+    if (P <= 0) return NU_OK;
+    const bool want_in = b->dx != nullptr;
+    const int ldf = want_in ? 288 : 256;
+    CHK(skinny_bwd(c, drgb, 4, b->HV, 128, P, 128, net->rgb.Wp, 128, 3, b->dHV, 128, 1, net->rgb.dWp, 128, c->flat + net->rgb.db_off, stream));
+    CHK(wgrad(c, b->dHV, 128, b->V, 288, P, 128, 288, net->view.dWp, 288, c->flat + net->view.db_off, stream));
+    NtArgs gF = {b->dHV, 128, net->view.WpT, net->view.ldT, P, ldf, 128, b->dF, ldf, NU_EPI_PLAIN};
+    CHK(nt(c, gF, stream));
+    CHK(wgrad(c, b->dF, ldf, b->H[8], 256, P, 256, 256, net->feat.dWp, 256, c->flat + net->feat.db_off, stream));
+    CHK(skinny_bwd(c, dsig, 1, b->H[8], 256, P, 256, net->alpha.Wp, 256, 1, b->dH8a, 256, 1, net->alpha.dWp, 256, c->flat + net->alpha.db_off, stream));
+    NtArgs g8 = {b->dF, ldf, net->feat.WpT, net->feat.ldT, P, 256, 256, b->dA[8], 256, NU_EPI_B_RELU};
+    g8.H = b->H[8]; g8.ldh = 256; g8.Cadd = b->dH8a; g8.ldadd = 256; g8.mask = b->mask[8]; g8.mask_nct = 2;
+    CHK(nt(c, g8, stream));
+    const float* dA = b->dA[8];
+    int lda = 256;
+    const float* dskip = nullptr;
+    for (int i = 7; i >= 0; --i) {
+        const NuLin& L = net->pts[i];
+        const int ldu = i == 0 ? 96 : (i == 5 ? 352 : 256);
+        CHK(wgrad(c, dA, lda, b->H[i], ldu, P, 256, L.Kp, L.dWp, L.ldd, c->flat + L.db_off, stream));
+        if (i > 0) {
+            if (i == 5 && want_in) {       // columns 256..339 of the layer-5 input: the re-concatenated embedding, plain gradient
+                NtArgs g = {dA, lda, L.WpT, L.ldT, P, 340, 256, b->dA[i], 352, NU_EPI_MUL_DRELU};
+                g.H = b->H[i]; g.ldh = ldu; g.act_cols = 256; g.zero_to = 352; g.mask = b->mask[i]; g.mask_nct = 2;
+                CHK(nt(c, g, stream));
+                dskip = b->dA[i];
+                dA = b->dA[i]; lda = 352;
+            } else {
+                NtArgs g = {dA, lda, L.WpT, L.ldT, P, 256, 256, b->dA[i], 256, NU_EPI_MUL_DRELU};
+                g.H = b->H[i]; g.ldh = ldu; g.mask = b->mask[i]; g.mask_nct = 2;
+                CHK(nt(c, g, stream));
+                dA = b->dA[i]; lda = 256;
+            }
+        } else if (want_in) {
+            NtArgs g = {dA, lda, L.WpT, L.ldT, P, 84, 256, b->dE4, 96, NU_EPI_PLAIN};
+            g.zero_to = 96;
+            CHK(nt(c, g, stream));
+            CHK(nu_nerf_embed_bwd(pt, pt_ld, b->H[0], b->V, b->dE4, 96, dskip + 256, 352, b->dF + 256, ldf, P, b->dx, b->ddir, stream));
+        }
+    }
+    return NU_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Shading stack (field.py:684-777): 4 material predictors (batched), the encodings, 4 light predictors, BRDF combine
+// ---------------------------------------------------------------------------------------------------------
+extern "C" int nu_shade_net_size(void) { return (int)sizeof(NuShadeNet); }
+extern "C" int nu_shade_bufs_size(void) { return (int)sizeof(NuShadeBufs); }
+
+extern "C" int nu_shading_stack_fwd(NuOpCtx* c, const NuShadeNet* net, NuShadeBufs* s, const float* YX, const float* E, const float* nrm,
+                                    const float* pt, const int* idx, float* color_rm, hipStream_t stream) {
+    const int P = s->P, R = s->R;
+    if (P <= 0) return NU_OK;
+    const int rows_ol = 3 * P + R;
+    // materials: layer 0 batched (N = 1024), layers 1-2 grouped x4, block-diagonal 6-wide head
+    NtArgs m0 = {YX, 288, net->WpM0, 288, P, 1024, 288, s->M[0], 1024, NU_EPI_BIAS_RELU};
+    m0.bias = net->bM0; m0.mask = s->maskM[0]; m0.mask_nct = 8;
+    CHK(nt(c, m0, stream));
+    for (int j = 1; j <= 2; ++j) {
+        NtArgs g = {s->M[j - 1], 1024, net->WpM[j], 256, P, 256, 256, s->M[j], 1024, NU_EPI_BIAS_RELU};
+        g.bias = net->bM[j]; g.groups = 4; g.sA = 256; g.sB = 65536; g.sC = 256; g.sBias = 256; g.mask = s->maskM[j]; g.mask_nct = 8;
+        CHK(nt(c, g, stream));
+    }
+    CHK(nu_skinny_fwd(s->M[2], 1024, P, 1024, net->Ws6, 1024, net->b6, 6, s->Mraw, 8, stream));
+    CHK(nu_shade_encode_fwd(nrm, pt, 8, E, s->Mraw, 8, P, net->sphere, net->ld_ol, net->refrac_dim, net->ld_rl, s->OLin, s->ILin, s->IWin,
+                            s->RLin, s->SD, stream));
+    if (R > 0) CHK(nu_spec_encode(s->extra_dirs, s->extra_pts, R, s->extra_pts ? net->sphere : 0, s->OLin + (long long)3 * P * net->ld_ol,
+                                  net->ld_ol, stream));
+    CHK(relu_stack_fwd(c, net->outer_light, s->OLin, net->ld_ol, rows_ol, s->OLh, s->maskOL, 2, stream));
+    CHK(relu_stack_fwd(c, net->inner_light, s->ILin, 128, 2 * P, s->ILh, s->maskIL, 2, stream));
+    CHK(relu_stack_fwd(c, net->inner_weight, s->IWin, 96, P, s->IWh, s->maskIW, 2, stream));
+    CHK(relu_stack_fwd(c, net->refrac_light, s->RLin, net->ld_rl, P, s->RLh, s->maskRL, 2, stream));
+    CHK(nu_skinny_fwd(s->OLh[2], 256, rows_ol, 256, net->outer_light[3].Wp, 256, net->outer_light[3].bias, 3, s->OLo, 4, stream));
+    CHK(nu_skinny_fwd(s->ILh[2], 256, 2 * P, 256, net->inner_light[3].Wp, 256, net->inner_light[3].bias, 3, s->ILo, 4, stream));
+    CHK(nu_skinny_fwd(s->IWh[2], 256, P, 256, net->inner_weight[3].Wp, 256, net->inner_weight[3].bias, 1, s->IWo, 1, stream));
+    CHK(nu_skinny_fwd(s->RLh[2], 256, P, 256, net->refrac_light[3].Wp, 256, net->refrac_light[3].bias, 3, s->RLo, 4, stream));
+    return nu_shade_combine_fwd(s->Mraw, 8, s->OLo, s->ILo, s->IWo, s->RLo, s->SD, net->lut, idx, P, net->exp_max, color_rm, s->aux, stream);
+}
+
+// dcolor_rm -> parameter gradients, dYX [P,288] (feature / x columns) and dn [P,3].  The caller has already put the cotangents
+// of the R per-ray mirror queries into dOLo[3P..] and added any direct cotangent of the occlusion head to dIWo AFTER
+// nu_shade_combine_bwd -- so this entry takes `stage`: 0 = combine backward only, 1 = everything after it.
+extern "C" int nu_shading_stack_bwd(NuOpCtx* c, const NuShadeNet* net, NuShadeBufs* s, const float* YX, const float* nrm, const float* pt,
+                                    const int* idx, const float* dcolor_rm, int stage, hipStream_t stream) {
+    const int P = s->P, R = s->R;
+    if (P <= 0) return NU_OK;
+    const int rows_ol = 3 * P + R;
+    if (stage == 0)
+        return nu_shade_combine_bwd(s->Mraw, 8, s->OLo, s->ILo, s->IWo, s->RLo, s->SD, net->lut, idx, P, net->exp_max, dcolor_rm, s->dMraw,
+                                    s->dOLo, s->dILo, s->dIWo, s->dRLo, s->dNoV, stream);
+    struct Pred { const NuLin* ls; float* const* Hs; unsigned long long* const* masks; const float* dy; int ldy, rows, no; const float* X;
+                  int ldx; float* dX; int lddx, dxc; float* dH3; float* const* tmp; };
+    const Pred preds[4] = {
+        {net->outer_light, s->OLh, s->maskOL, s->dOLo, 4, rows_ol, 3, s->OLin, net->ld_ol, s->dOLin, net->ld_ol, net->ld_ol, s->dH3[0], s->tmpOL},
+        {net->inner_light, s->ILh, s->maskIL, s->dILo, 4, 2 * P, 3, s->ILin, 128, s->dILin, 128, 128, s->dH3[1], s->tmpIL},
+        {net->inner_weight, s->IWh, s->maskIW, s->dIWo, 1, P, 1, s->IWin, 96, nullptr, 0, 0, s->dH3[2], s->tmpIW},
+        {net->refrac_light, s->RLh, s->maskRL, s->dRLo, 4, P, 3, s->RLin, net->ld_rl, nullptr, 0, 0, s->dH3[3], s->tmpRL}};
+    for (const Pred& p : preds) {
+        const NuLin& head = p.ls[3];
+        CHK(skinny_bwd(c, p.dy, p.ldy, p.Hs[2], 256, p.rows, 256, head.Wp, 256, p.no, p.dH3, 256, 1, head.dWp, head.ldd, c->flat + head.db_off, stream));
+        CHK(relu_stack_bwd(c, p.ls, p.X, p.ldx, p.rows, p.Hs, p.masks, 2, p.dH3, p.tmp, p.dX, p.lddx, p.dxc, stream));
+    }
+    CHK(nu_shade_encode_bwd(nrm, pt, 8, s->SD, s->dOLin, net->ld_ol, net->sphere, s->dILin, s->dNoV, P, s->dn, s->dMraw, 8, stream));
+    // materials backward
+    CHK(skinny_bwd(c, s->dMraw, 8, s->M[2], 1024, P, 1024, net->Ws6, 1024, 6, s->dM[2], 1024, 1, net->dWs6, 1024, c->flat + net->db6_off, stream));
+    const float* dA = s->dM[2];
+    for (int j = 2; j >= 1; --j) {
+        CHK(wgrad(c, dA, 1024, s->M[j - 1], 1024, P, 256, 256, net->dWpM[j], 256, c->flat + net->dbM_off[j], stream, nullptr, 0, nullptr, 0, 4, 256, 256,
+                  65536, 256));
+        NtArgs g = {dA, 1024, net->WpTM[j], 256, P, 256, 256, s->dM[j - 1], 1024, NU_EPI_MUL_DRELU};
+        g.H = s->M[j - 1]; g.ldh = 1024; g.groups = 4; g.sA = 256; g.sB = 65536; g.sC = 256; g.sH = 256; g.mask = s->maskM[j - 1]; g.mask_nct = 8;
+        CHK(nt(c, g, stream));
+        dA = s->dM[j - 1];
+    }
+    CHK(wgrad(c, dA, 1024, YX, 288, P, 1024, 288, net->dWpM0, 288, c->flat + net->dbM_off[0], stream));
+    NtArgs gy = {dA, 1024, net->WpTM0, 1024, P, 288, 1024, s->dYX, 288, NU_EPI_PLAIN};
+    return nt(c, gy, stream);
+}

@@ -61,6 +61,54 @@ class PackDesc(ctypes.Structure):
                 ("Kp", c_int), ("ldT", c_int), ("ldd", c_int), ("row_begin", c_int), ("col_off", c_int)]
 
 
+class Lin(ctypes.Structure):
+    """Mirror of NuLin (include/nu_nerf.h): one packed layer."""
+    _fields_ = [("Wp", c_p), ("WpT", c_p), ("dWp", c_p), ("bias", c_p), ("db_off", c_ll), ("N", c_int), ("K", c_int), ("Kp", c_int),
+                ("ldT", c_int), ("ldd", c_int), ("pad_", c_int)]
+
+
+class OpCtx(ctypes.Structure):
+    """Mirror of NuOpCtx: arithmetic mode, flat gradient buffer, deferred-reduction arena (shared by the Python-sequenced path)."""
+    _fields_ = [("prec", c_int), ("pad_", c_int), ("flat", c_p), ("arena", c_p), ("arena_floats", c_ll), ("arena_off", c_ll),
+                ("descs", c_p), ("ndesc", c_int), ("cap", c_int)]
+
+
+class SdfNet(ctypes.Structure):
+    _fields_ = [("lin", Lin * 9)]
+
+
+class SdfBufs(ctypes.Structure):
+    _fields_ = [("P", c_int), ("pad_", c_int), ("E", c_p), ("U4", c_p), ("YX", c_p), ("sdf", c_p), ("H", c_p * 9), ("D", c_p * 8),
+                ("G0", c_p), ("n", c_p), ("Q", c_p * 9), ("C", c_p * 8), ("Aux", c_p * 8), ("dE0", c_p)]
+
+
+class NerfNet(ctypes.Structure):
+    _fields_ = [("pts", Lin * 8), ("feat", Lin), ("alpha", Lin), ("view", Lin), ("rgb", Lin)]
+
+
+class NerfBufs(ctypes.Structure):
+    _fields_ = [("P", c_int), ("pad_", c_int), ("H", c_p * 9), ("mask", c_p * 9), ("V", c_p), ("HV", c_p), ("sig", c_p), ("rgb", c_p),
+                ("dHV", c_p), ("dF", c_p), ("dH8a", c_p), ("dA", c_p * 9), ("dE4", c_p), ("dx", c_p), ("ddir", c_p)]
+
+
+class ShadeNet(ctypes.Structure):
+    _fields_ = [("WpM0", c_p), ("WpTM0", c_p), ("bM0", c_p), ("dWpM0", c_p), ("WpM", c_p * 3), ("WpTM", c_p * 3), ("bM", c_p * 3),
+                ("dWpM", c_p * 3), ("dbM_off", c_ll * 3), ("Ws6", c_p), ("b6", c_p), ("dWs6", c_p), ("db6_off", c_ll),
+                ("outer_light", Lin * 4), ("inner_light", Lin * 4), ("inner_weight", Lin * 4), ("refrac_light", Lin * 4),
+                ("lut", c_p), ("exp_max", c_f), ("sphere", c_int), ("ld_ol", c_int), ("refrac_dim", c_int), ("ld_rl", c_int), ("pad_", c_int)]
+
+
+class ShadeBufs(ctypes.Structure):
+    _fields_ = [("P", c_int), ("R", c_int), ("extra_dirs", c_p), ("extra_pts", c_p), ("M", c_p * 3), ("maskM", c_p * 3), ("Mraw", c_p),
+                ("OLin", c_p), ("ILin", c_p), ("IWin", c_p), ("RLin", c_p), ("SD", c_p),
+                ("OLh", c_p * 3), ("ILh", c_p * 3), ("IWh", c_p * 3), ("RLh", c_p * 3),
+                ("maskOL", c_p * 3), ("maskIL", c_p * 3), ("maskIW", c_p * 3), ("maskRL", c_p * 3),
+                ("OLo", c_p), ("ILo", c_p), ("IWo", c_p), ("RLo", c_p), ("aux", c_p),
+                ("dMraw", c_p), ("dOLo", c_p), ("dILo", c_p), ("dIWo", c_p), ("dRLo", c_p), ("dNoV", c_p),
+                ("dH3", c_p * 4), ("tmpOL", c_p * 2), ("tmpIL", c_p * 2), ("tmpIW", c_p * 2), ("tmpRL", c_p * 2),
+                ("dOLin", c_p), ("dILin", c_p), ("dn", c_p), ("dM", c_p * 3), ("dYX", c_p)]
+
+
 def rup(a, b):
     return (a + b - 1) // b * b
 
@@ -118,9 +166,17 @@ class Stage1Engine:
         # until flush_reductions() sums them all in a few batched launches (before unpack_grads reads the results)
         self._rd_cap = 1024
         self._rd = (ReduceDesc * self._rd_cap)()
-        self._nrd = c_int(0)
         self._arena = None
-        self._arena_off = 0
+        # one context for both sequencing paths (network-level C entries and the launch-by-launch Python path below): the
+        # descriptor count and the arena offset live in the struct
+        self._ctx = OpCtx(prec=self.bf16, flat=0, arena=0, arena_floats=0, arena_off=0,
+                          descs=ctypes.cast(self._rd, c_p).value, ndesc=0, cap=self._rd_cap)
+        self._ndesc_p = ctypes.cast(ctypes.addressof(self._ctx) + OpCtx.ndesc.offset, ctypes.POINTER(c_int))
+        for fn, st in (("nu_op_ctx_size", OpCtx), ("nu_sdf_net_size", SdfNet), ("nu_sdf_bufs_size", SdfBufs), ("nu_nerf_net_size", NerfNet),
+                       ("nu_nerf_bufs_size", NerfBufs), ("nu_shade_net_size", ShadeNet), ("nu_shade_bufs_size", ShadeBufs)):
+            assert getattr(lib, fn)() == ctypes.sizeof(st), f"{st.__name__} ABI mismatch"
+        # NU_PY_SEQ=1: sequence every launch from Python (the path bench.py's per-launch event timing uses)
+        self.py_seq = os.environ.get('NU_PY_SEQ', '0') != '0'
         self._ws = None
         self._ptr_sig = None
         self._ktime = None
@@ -189,20 +245,22 @@ class Stage1Engine:
     def _arena_take(self, nbytes):
         """Device address of `nbytes` of slab space that stays untouched until the next flush_reductions()."""
         n = (int(nbytes) + 255) // 256 * 64          # floats, 256-byte granules
-        if self._arena is None or self._arena_off + n > self._arena.numel():
+        if self._arena is None or self._ctx.arena_off + n > self._arena.numel():
             self.flush_reductions()                   # stream order: later producers may then reuse the space
             if self._arena is None or n > self._arena.numel():
-                self._arena = None
-                self._arena = torch.empty(max(n, 1 << 29), dtype=torch.float32, device=self.dev)   # >= 2 GiB: one step's slabs
-        off = self._arena_off
-        self._arena_off += n
+                self._ensure_arena(n)
+        off = self._ctx.arena_off
+        self._ctx.arena_off += n
         return self._arena.data_ptr() + 4 * off, n * 4
 
+    def _ensure_arena(self, n=0):
+        if self._arena is None or n > self._arena.numel():
+            self._arena = None
+            self._arena = torch.empty(max(n, 1 << 29), dtype=torch.float32, device=self.dev)   # >= 2 GiB: one step's slabs
+            self._ctx.arena, self._ctx.arena_floats = self._arena.data_ptr(), self._arena.numel()
+
     def flush_reductions(self):
-        if self._nrd.value:
-            L.check(self.lib.nu_slab_reduce_batched(self._rd, self._nrd.value, self.stream()), "nu_slab_reduce_batched")
-            self._nrd.value = 0
-        self._arena_off = 0
+        L.check(self.lib.nu_ctx_flush(ctypes.byref(self._ctx), self.stream()), "nu_ctx_flush")
 
     # ------------------------------------------------------------------ layer tables
     def _build_layers(self):
@@ -366,6 +424,43 @@ class Stage1Engine:
         host = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
         self._desc_dev = host.to(self.dev)
         self._ptr_sig = self._signature()
+        self._build_net_structs()
+
+    @staticmethod
+    def _lin(lay):
+        return Lin(addr(*lay.Wp), addr(*lay.WpT) if lay.WpT is not None else 0, addr(*lay.dWp), addr(lay.b), lay.db_off, lay.N, lay.K,
+                   lay.Kp, lay.ldT, lay.ldd, 0)
+
+    def _build_net_structs(self):
+        """Packed-layer tables of the network-level C entries (include/nu_nerf.h: NuSdfNet, NuNerfNet, NuShadeNet)."""
+        self._sdf_net = SdfNet()
+        for l in range(9):
+            self._sdf_net.lin[l] = self._lin(self.sdf[l])
+        self._nerf_net = NerfNet()
+        for i in range(8):
+            self._nerf_net.pts[i] = self._lin(self.nerf[i])
+        self._nerf_net.feat, self._nerf_net.alpha = self._lin(self.nerf_feat), self._lin(self.nerf_alpha)
+        self._nerf_net.view, self._nerf_net.rgb = self._lin(self.nerf_view), self._lin(self.nerf_rgb)
+        n = ShadeNet()
+        db0, db12, db6 = self.mat_db
+        n.WpM0, n.WpTM0, n.bM0, n.dWpM0 = addr(self.WpM0), addr(self.WpTM0), addr(self.bM0), addr(self.dWpM0)
+        for j in (1, 2):
+            n.WpM[j], n.WpTM[j], n.bM[j], n.dWpM[j] = addr(self.WpM[j]), addr(self.WpTM[j]), addr(self.bM[j]), addr(self.dWpM[j])
+            n.dbM_off[j] = db12[j]
+        n.dbM_off[0] = db0
+        n.Ws6, n.b6, n.dWs6, n.db6_off = addr(self.Ws6), addr(self.b6), addr(self.dWs6), db6
+        for name in ('outer_light', 'inner_light', 'inner_weight', 'refrac_light'):
+            arr = getattr(n, name)
+            for j, lay in enumerate(getattr(self, name)):
+                arr[j] = self._lin(lay)
+        n.lut, n.exp_max, n.sphere = addr(self.lut), self.exp_max, 1 if self.sphere_direction else 0
+        n.ld_ol, n.refrac_dim, n.ld_rl = self.ld_ol, self.refrac_dim, self.ld_rl
+        self._shade_net = n
+
+    def _use_c(self):
+        """Network-level C entries unless launch-by-launch sequencing is asked for (NU_PY_SEQ=1, or bench.py's per-launch
+        event timing, which brackets individual GEMM launches)."""
+        return not self.py_seq and not (self._ktime is not None and self.ktime_on)
 
     def pack(self):
         """Fold weight-norm, pad/permute and transpose every layer's weight: one launch."""
@@ -447,31 +542,31 @@ class Stage1Engine:
     def _wgrad(self, A0, lda0, B0, ldb0, P, N1, N2, dW, ldw, db, A1, lda1, B1, ldb1, groups, sA0, sB0, sA1, sB1, sW, sDb):
         tiles = ((N1 + 127) // 128) * ((N2 + 127) // 128) * groups
         S = max(1, min((P + 255) // 256, max(1, 512 // tiles)))   # 2 workgroups per CU; fewer, larger slabs
-        if self._nrd.value + 2 * groups > self._rd_cap:
+        if self._ctx.ndesc + 2 * groups > self._rd_cap:
             self.flush_reductions()
         ws, nb = self._arena_take(self.lib.nu_wgrad_workspace_bytes(N1, N2, S, groups))
         g = GemmTN(A0, lda0, B0, ldb0, A1, lda1, B1, ldb1, P, N1, N2, 0, 0, S, groups, sA0, sB0, sA1, sB1, 0, 0, self.bf16, 0)
         L.check(self.lib.nu_wgrad_enqueue(ctypes.byref(g), c_p(dW), ldw, c_ll(sW), c_p(db), c_ll(sDb), c_p(ws), c_ll(nb),
-                                          self._rd, ctypes.byref(self._nrd), self._rd_cap, self.stream()), "nu_wgrad_enqueue")
+                                          self._rd, self._ndesc_p, self._rd_cap, self.stream()), "nu_wgrad_enqueue")
 
     def skinny_fwd(self, H, ldh, P, K, Ws, ldw, b, NO, out, ldo):
         L.check(self.lib.nu_skinny_fwd(c_p(H), ldh, P, K, c_p(Ws), ldw, c_p(b), NO, c_p(out), ldo, self.stream()),
                 "nu_skinny_fwd")
 
     def skinny_bwd(self, dy, ldy, H, ldh, P, K, Ws, ldw, NO, dH, lddh, relu_mask, accumulate, dWs, lddw, db):
-        if self._nrd.value + 2 > self._rd_cap:
+        if self._ctx.ndesc + 2 > self._rd_cap:
             self.flush_reductions()
         ws, nb = self._arena_take(self.lib.nu_skinny_bwd_workspace_bytes(K, NO))
         L.check(self.lib.nu_skinny_bwd_enqueue(c_p(dy), ldy, c_p(H), ldh, P, K, c_p(Ws), ldw, NO, c_p(dH), lddh, relu_mask,
                                                accumulate, c_p(dWs), lddw, c_p(db), c_p(ws), c_ll(nb), self._rd,
-                                               ctypes.byref(self._nrd), self._rd_cap, self.stream()), "nu_skinny_bwd_enqueue")
+                                               self._ndesc_p, self._rd_cap, self.stream()), "nu_skinny_bwd_enqueue")
 
     def colsum(self, A, lda, P, ncols, out, accumulate):
-        if self._nrd.value + 1 > self._rd_cap:
+        if self._ctx.ndesc + 1 > self._rd_cap:
             self.flush_reductions()
         ws, nb = self._arena_take(self.lib.nu_colsum_workspace_bytes(ncols))
         L.check(self.lib.nu_colsum_enqueue(c_p(A), lda, P, ncols, c_p(out), accumulate, c_p(ws), c_ll(nb), self._rd,
-                                           ctypes.byref(self._nrd), self._rd_cap, self.stream()), "nu_colsum_enqueue")
+                                           self._ndesc_p, self._rd_cap, self.stream()), "nu_colsum_enqueue")
 
     # ------------------------------------------------------------------ SDF network
     def sdf_forward(self, X, x_ld, P, *, keep=True, want_feat=True):
@@ -484,8 +579,6 @@ class Stage1Engine:
         a['E'] = e(P, 64)
         a['U4'] = e(P, 256)
         a['YX'] = e(P, 288) if want_feat else None
-        L.check(lib.nu_sdf_embed(c_p(X), x_ld, P, c_p(addr(a['E'])), c_p(addr(a['U4'])),
-                                 c_p(addr(a['YX'])), S), "nu_sdf_embed")
         ls = self.sdf
         if keep:
             H = [None] + [e(P, 256) for _ in range(3)] + [a['U4']] + [e(P, 256) for _ in range(4)]
@@ -493,6 +586,18 @@ class Stage1Engine:
             t0, t1 = e(P, 256), e(P, 256)
             H = [None, t0, t1, t0, a['U4'], t0, t1, t0, t1]
         a['H'] = H
+        if self._use_c():          # one C call sequences the embedding, the eight hidden GEMMs and the output layer
+            cb = SdfBufs(P=P, E=addr(a['E']), U4=addr(a['U4']), YX=addr(a['YX']))
+            for l in range(1, 9):
+                cb.H[l] = addr(H[l])
+            a['sdf'] = None if want_feat else e(P)
+            cb.sdf = addr(a['sdf'])
+            a['cb'] = cb
+            L.check(lib.nu_sdf_mlp_fwd(ctypes.byref(self._ctx), ctypes.byref(self._sdf_net), c_p(X), x_ld, ctypes.byref(cb),
+                                       1 if want_feat else 0, S), "nu_sdf_mlp_fwd")
+            return a
+        L.check(lib.nu_sdf_embed(c_p(X), x_ld, P, c_p(addr(a['E'])), c_p(addr(a['U4'])),
+                                 c_p(addr(a['YX'])), S), "nu_sdf_embed")
         src, lds, K = a['E'], 64, 64
         for l in range(8):
             N = ls[l].N
@@ -516,6 +621,14 @@ class Stage1Engine:
         e = self.empty
         D = [e(P, 256) for _ in range(8)]
         a['D'] = D
+        if self._use_c():
+            cb = self._sdf_cb(a)
+            a['G0'], a['n'] = e(P, 64), e(P, 3)
+            for l in range(8):
+                cb.D[l] = addr(D[l])
+            cb.G0, cb.n = addr(a['G0']), addr(a['n'])
+            L.check(lib.nu_sdf_mlp_normal(ctypes.byref(self._ctx), ctypes.byref(self._sdf_net), ctypes.byref(cb), S), "nu_sdf_mlp_normal")
+            return a['n']
         L.check(lib.nu_rowscale_dsp(c_p(addr(H[8])), 256, P, 256, c_p(addr(*ls[8].Wp)), c_p(addr(D[7])), 256, S),
                 "nu_rowscale_dsp")
         for l in range(7, 0, -1):
@@ -544,6 +657,33 @@ class Stage1Engine:
         lib, S, P, ls, H, E = self.lib, self.stream(), a['P'], self.sdf, a['H'], a['E']
         e = self.empty
         second = nbar is not None
+        if self._use_c():
+            cb = self._sdf_cb(a)
+            keep = []
+            if second:
+                for l in range(8):
+                    t = e(P, 256)
+                    keep.append(t)
+                    cb.C[l] = addr(t)
+                for l in range(9):
+                    t = e(P, 64 if l == 0 else 256)
+                    keep.append(t)
+                    cb.Q[l] = addr(t)
+            else:
+                for l in range(8):
+                    t = e(P, 256)
+                    keep.append(t)
+                    cb.Aux[l] = addr(t)
+            if dx is not None:
+                t = e(P, 64)
+                keep.append(t)
+                cb.dE0 = addr(t)
+            self._ensure_arena()
+            self._ctx.flat = addr(flat)
+            L.check(lib.nu_sdf_mlp_bwd(ctypes.byref(self._ctx), ctypes.byref(self._sdf_net), ctypes.byref(cb), c_p(addr(dYX)),
+                                       c_p(addr(nbar)), c_p(addr(dx)), S), "nu_sdf_mlp_bwd")
+            a['_bwd_keep'] = keep          # buffers stay referenced until the caller drops the activation dict
+            return
         Cb = [None] * 8
         Q = [None] * 9
         if second:
@@ -597,6 +737,20 @@ class Stage1Engine:
                                      c_p(addr(a['G0']) if second else 0), 64, c_p(addr(a['D'][3], 217) if second else 0), 256,
                                      c_p(addr(nbar) if second else 0), P, c_p(addr(dx)), 0, S), "nu_embed_jt2")
 
+    def _sdf_cb(self, a):
+        """The C buffer table of an activation dict (built on demand for dicts made by the Python-sequenced forward)."""
+        cb = a.get('cb')
+        if cb is None:
+            cb = SdfBufs(P=a['P'], E=addr(a['E']), U4=addr(a['U4']), YX=addr(a['YX']), sdf=addr(a.get('sdf')))
+            for l in range(1, 9):
+                cb.H[l] = addr(a['H'][l])
+            a['cb'] = cb
+        if 'D' in a:
+            for l in range(8):
+                cb.D[l] = addr(a['D'][l])
+            cb.G0, cb.n = addr(a.get('G0')), addr(a.get('n'))
+        return cb
+
     # ------------------------------------------------------------------ generic ReLU stacks
     def relu_stack_fwd(self, layers, X, ldx, rows):
         """3 hidden ReLU layers (make_predictor, field.py:371-408); returns hidden activations [H1,H2,H3]."""
@@ -635,6 +789,8 @@ class Stage1Engine:
         e = self.empty
         s = {'P': P}
         YX = a['YX']
+        if self._use_c():
+            return self._c_shading_forward(a, pt, idx, P, color_rm, extra_dirs, extra_pts)
         # materials: layer 0 batched (N=1024), layers 1-2 grouped x4, block-diagonal 6-wide head
         M1, M2, M3 = e(P, 1024), e(P, 1024), e(P, 1024)
         self.nt(addr(YX), 288, addr(self.WpM0), 288, P, 1024, 288, addr(M1), 1024, EPI_BIAS_RELU, bias=addr(self.bM0),
@@ -676,11 +832,77 @@ class Stage1Engine:
                 "nu_shade_combine_fwd")
         return s
 
+    def _c_shading_forward(self, a, pt, idx, P, color_rm, extra_dirs, extra_pts):
+        """shading_forward through nu_shading_stack_fwd: this method only allocates the buffers and fills the pointer table."""
+        lib, S, e = self.lib, self.stream(), self.empty
+        R = 0 if extra_dirs is None else extra_dirs.shape[0]
+        rows_ol = 3 * P + R
+        ld_ol, ld_rl = self.ld_ol, self.ld_rl
+        s = {'P': P, 'R': R, 'rows_ol': rows_ol}
+        cb = ShadeBufs(P=P, R=R, extra_dirs=addr(extra_dirs), extra_pts=addr(extra_pts))
+        M = [e(P, 1024) for _ in range(3)]
+        for j in range(3):
+            cb.M[j], cb.maskM[j] = addr(M[j]), addr(self.relu_mask(M[j], P, 1024))
+        s.update(M1=M[0], M2=M[1], M3=M[2], Mraw=e(P, 8), OLin=e(rows_ol, ld_ol), ILin=e(2 * P, 128), IWin=e(P, 96), RLin=e(P, ld_rl),
+                 SD=e(P, 8), OLo=e(rows_ol, 4), ILo=e(2 * P, 4), IWo=e(P), RLo=e(P, 4), aux=e(P, 4))
+        for k in ('Mraw', 'OLin', 'ILin', 'IWin', 'RLin', 'SD', 'OLo', 'ILo', 'IWo', 'RLo', 'aux'):
+            setattr(cb, k, addr(s[k]))
+        for key, rows, arr, marr in (('OLh', rows_ol, cb.OLh, cb.maskOL), ('ILh', 2 * P, cb.ILh, cb.maskIL),
+                                     ('IWh', P, cb.IWh, cb.maskIW), ('RLh', P, cb.RLh, cb.maskRL)):
+            Hs = [e(rows, 256) for _ in range(3)]
+            for j in range(3):
+                arr[j], marr[j] = addr(Hs[j]), addr(self.relu_mask(Hs[j], rows, 256))
+            s[key] = Hs
+        s['cb'] = cb
+        L.check(lib.nu_shading_stack_fwd(ctypes.byref(self._ctx), ctypes.byref(self._shade_net), ctypes.byref(cb), c_p(addr(a['YX'])),
+                                         c_p(addr(a['E'])), c_p(addr(a['n'])), c_p(addr(pt)), c_p(addr(idx)), c_p(addr(color_rm)), S),
+                "nu_shading_stack_fwd")
+        return s
+
+    def _c_shading_backward(self, a, s, pt, idx, dcolor_rm, flat, d_spec_raw, d_occ_raw):
+        lib, S, e, P = self.lib, self.stream(), self.empty, s['P']
+        rows_ol, R = s['rows_ol'], s['R']
+        cb = s['cb']
+        dMraw, dOLo, dILo, dIWo, dRLo, dNoV = e(P, 8), e(rows_ol, 4), e(2 * P, 4), e(P), e(P, 4), e(P)
+        cb.dMraw, cb.dOLo, cb.dILo, cb.dIWo, cb.dRLo, cb.dNoV = (addr(t) for t in (dMraw, dOLo, dILo, dIWo, dRLo, dNoV))
+        args = (ctypes.byref(self._ctx), ctypes.byref(self._shade_net), ctypes.byref(cb), c_p(addr(a['YX'])), c_p(addr(a['n'])),
+                c_p(addr(pt)), c_p(addr(idx)), c_p(addr(dcolor_rm)))
+        L.check(lib.nu_shading_stack_bwd(*args, 0, S), "nu_shading_stack_bwd(0)")
+        if R:
+            if d_spec_raw is not None:
+                dOLo[3 * P:, :3] = d_spec_raw
+                dOLo[3 * P:, 3] = 0
+            else:
+                dOLo[3 * P:].zero_()
+        if d_occ_raw is not None:
+            dIWo += d_occ_raw
+        keep = []
+        for i, rows in enumerate((rows_ol, 2 * P, P, P)):
+            t = e(rows, 256)
+            keep.append(t)
+            cb.dH3[i] = addr(t)
+        for arr, rows in ((cb.tmpOL, rows_ol), (cb.tmpIL, 2 * P), (cb.tmpIW, P), (cb.tmpRL, P)):
+            for j in range(2):
+                t = e(rows, 256)
+                keep.append(t)
+                arr[j] = addr(t)
+        dOLin, dILin, dn, dYX = e(rows_ol, self.ld_ol), e(2 * P, 128), e(P, 3), e(P, 288)
+        dM = [e(P, 1024) for _ in range(3)]
+        cb.dOLin, cb.dILin, cb.dn, cb.dYX = addr(dOLin), addr(dILin), addr(dn), addr(dYX)
+        for j in range(3):
+            cb.dM[j] = addr(dM[j])
+        self._ensure_arena()
+        self._ctx.flat = addr(flat)
+        L.check(lib.nu_shading_stack_bwd(*args, 1, S), "nu_shading_stack_bwd(1)")
+        return dYX, dn
+
     def shading_backward(self, a, s, pt, idx, dcolor_rm, flat, d_spec_raw=None, d_occ_raw=None):
         """Returns (dYX [P,288] with feature/x columns filled, dn_shade [P,3])."""
         lib, S, P = self.lib, self.stream(), s['P']
         e = self.empty
         rows_ol, R = s['rows_ol'], s['R']
+        if self._use_c() and 'cb' in s:
+            return self._c_shading_backward(a, s, pt, idx, dcolor_rm, flat, d_spec_raw, d_occ_raw)
         dMraw, dOLo, dILo, dIWo, dRLo, dNoV = e(P, 8), e(rows_ol, 4), e(2 * P, 4), e(P), e(P, 4), e(P)
         L.check(lib.nu_shade_combine_bwd(c_p(addr(s['Mraw'])), 8, c_p(addr(s['OLo'])), c_p(addr(s['ILo'])),
                                          c_p(addr(s['IWo'])), c_p(addr(s['RLo'])), c_p(addr(s['SD'])),
@@ -738,6 +960,22 @@ class Stage1Engine:
         e = self.empty
         b = {'P': P}
         E4, U5, V = e(P, 96), e(P, 352), e(P, 288)
+        if self._use_c():
+            H = [E4] + [U5 if i == 4 else e(P, 256) for i in range(8)]
+            cb = NerfBufs(P=P)
+            for i in range(9):
+                cb.H[i] = addr(H[i])
+                if i > 0:
+                    cb.mask[i] = addr(self.relu_mask(H[i], P, 256))
+            HV, sig, rgb = e(P, 128), e(P), e(P, 4)
+            cb.V, cb.HV, cb.sig, cb.rgb = addr(V), addr(HV), addr(sig), addr(rgb)
+            L.check(lib.nu_nerfpp_mlp_fwd(ctypes.byref(self._ctx), ctypes.byref(self._nerf_net), c_p(addr(pt)), pt.shape[1],
+                                          ctypes.byref(cb), S), "nu_nerfpp_mlp_fwd")
+            if alpha_rm is not None:
+                L.check(lib.nu_nerf_act_fwd(c_p(addr(sig)), 1, c_p(addr(rgb)), 4, c_p(addr(pt)), c_p(addr(idx)), P,
+                                            c_p(addr(alpha_rm)), c_p(addr(color_rm)), S), "nu_nerf_act_fwd")
+            b.update(H=H, V=V, HV=HV, sig=sig, rgb=rgb, cb=cb)
+            return b
         L.check(lib.nu_nerf_embed(c_p(addr(pt)), pt.shape[1], P, c_p(addr(E4)), c_p(addr(U5)), c_p(addr(V)), S), "nu_nerf_embed")
         H = [E4]
         src, lds = E4, 96
@@ -777,6 +1015,32 @@ class Stage1Engine:
             L.check(lib.nu_nerf_act_bwd(c_p(addr(b['sig'])), 1, c_p(addr(b['rgb'])), 4, c_p(addr(pt)), c_p(addr(idx)), P,
                                         c_p(addr(dalpha_rm)), c_p(addr(dcolor_rm)), c_p(addr(dsig)), 1, c_p(addr(drgb)), 4, S),
                     "nu_nerf_act_bwd")
+        if self._use_c():
+            cb = b.get('cb')
+            if cb is None:                 # forward was sequenced from Python
+                cb = NerfBufs(P=P, V=addr(b['V']), HV=addr(b['HV']), sig=addr(b['sig']), rgb=addr(b['rgb']))
+                for i in range(9):
+                    cb.H[i] = addr(H[i])
+                    if i > 0:
+                        cb.mask[i] = addr(getattr(H[i], '_nu_mask', None))
+            ldf = 288 if want_in else 256
+            keep = [e(P, 128), e(P, ldf), e(P, 256)]
+            cb.dHV, cb.dF, cb.dH8a = (addr(t) for t in keep)
+            for i in range(1, 9):
+                t = e(P, 352 if (i == 5 and want_in) else 256)
+                keep.append(t)
+                cb.dA[i] = addr(t)
+            if want_in:
+                t = e(P, 96)
+                keep.append(t)
+                cb.dE4, cb.dx, cb.ddir = addr(t), addr(dx), addr(ddir)
+            else:
+                cb.dE4 = cb.dx = cb.ddir = 0
+            self._ensure_arena()
+            self._ctx.flat = addr(flat)
+            L.check(lib.nu_nerfpp_mlp_bwd(ctypes.byref(self._ctx), ctypes.byref(self._nerf_net), c_p(addr(pt)), pt.shape[1],
+                                          ctypes.byref(cb), c_p(addr(dsig)), c_p(addr(drgb)), S), "nu_nerfpp_mlp_bwd")
+            return
         # rgb head -> view layer
         dHV = e(P, 128)
         self.skinny_bwd(addr(drgb), 4, addr(b['HV']), 128, P, 128, addr(*self.nerf_rgb.Wp), 128, 3, addr(dHV), 128, 1, 0,

@@ -28,7 +28,11 @@ def test_header_declares_the_expected_surface():
                  "nu_neus_alpha_fwd", "nu_neus_alpha_bwd", "nu_upsample", "nu_merge_sorted", "nu_shade_combine_fwd",
                  "nu_shade_combine_bwd", "nu_ide", "nu_partition_count", "nu_partition_write"):
         assert must in names
-    assert len(names) >= 35
+    # network-level entries of SURVEY 8(b) and the fused loss (N1)
+    for must in ("nu_sdf_mlp_fwd", "nu_sdf_mlp_normal", "nu_sdf_mlp_bwd", "nu_nerfpp_mlp_fwd", "nu_nerfpp_mlp_bwd", "nu_shading_stack_fwd",
+                 "nu_shading_stack_bwd", "nu_ctx_flush", "nu_loss_fwd", "nu_loss_bwd", "nu_lbvh_build", "nu_lbvh_trace"):
+        assert must in names
+    assert len(names) >= 50
 
 
 def test_library_exports_every_declared_symbol(lib):
@@ -42,6 +46,10 @@ def test_struct_layouts_match_python_mirrors(lib):
     # natural-alignment sizes of the C structs in include/nu_nerf.h
     assert ctypes.sizeof(GemmNT) == 232 and ctypes.sizeof(GemmTN) == 152
     assert lib.nu_gemm_nt_size() == 232 and lib.nu_gemm_tn_size() == 152 and lib.nu_reduce_desc_size() == 64
+    from nu_nerf_amd.engine import OpCtx, SdfNet, SdfBufs, NerfNet, NerfBufs, ShadeNet, ShadeBufs
+    for fn, st in (("nu_op_ctx_size", OpCtx), ("nu_sdf_net_size", SdfNet), ("nu_sdf_bufs_size", SdfBufs), ("nu_nerf_net_size", NerfNet),
+                   ("nu_nerf_bufs_size", NerfBufs), ("nu_shade_net_size", ShadeNet), ("nu_shade_bufs_size", ShadeBufs)):
+        assert getattr(lib, fn)() == ctypes.sizeof(st), fn
 
 
 def test_workspace_queries_are_pure_host_functions(lib):

@@ -231,3 +231,25 @@ def test_fused_loss_kernels_equal_the_loss_registry(gpu, std):
         assert (p.grad is None) == (q.grad is None), n
         if p.grad is not None:
             assert rel_err(q.grad, p.grad) < 1e-5, (n, rel_err(q.grad, p.grad))
+
+
+def test_network_level_c_entries_equal_launch_by_launch_sequencing(gpu):
+    """nu_sdf_mlp_*, nu_nerfpp_mlp_*, nu_shading_stack_* sequence the same kernels in the same order as the
+    launch-by-launch Python path (engine.py_seq): outputs and every gradient are bit-identical."""
+    from nu_nerf_amd.loss import name2loss, SPHEREPOT_LOSSES, total_loss
+    g = golden("train_step20000_r48.npz")
+    step = int(g['step'])
+    batch = {k: torch.from_numpy(g[k]).to(gpu) for k in ('rays_o', 'rays_d', 'rgbs')}
+    rand = (torch.from_numpy(g['u1']).to(gpu), torch.from_numpy(g['u2']).to(gpu))
+    res = []
+    for py_seq in (False, True):
+        net = make_net(gpu)
+        net.engine().py_seq = py_seq
+        out = net.train_step_rays(batch, step, rand=rand)
+        total, _ = total_loss(out, [name2loss[n](CFG) for n in SPHEREPOT_LOSSES], step)
+        total.backward()
+        res.append((out['ray_rgb'].detach().clone(), float(total.detach()), {n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None}))
+    assert torch.equal(res[0][0], res[1][0]) and res[0][1] == res[1][1]
+    assert set(res[0][2]) == set(res[1][2])
+    for n in res[0][2]:
+        assert torch.equal(res[0][2][n], res[1][2][n]), n
