@@ -12,6 +12,7 @@
 // ray/triangle test below is written with explicit single-rounding fp32 operations in a fixed order, ties in t go
 // to the lowest face id, and boxes are padded so that traversal never culls a triangle the test would accept.
 #include "nu_common.h"
+#include <stdlib.h>
 
 // Bit-exact parity with the oracle needs one rounding per operation.  HIP's __fmul_rn/__fadd_rn are header-defined
 // plain operators that still carry the 'contract' flag, so the arithmetic is written with ordinary operators and FMA
@@ -216,6 +217,32 @@ __global__ void lbvh_refit_kernel(int n, char* buf, NuBvhLayout L) {
     }
 }
 
+// Every (j, k) step of the sorting network whose partner distance j fits inside one NU_SORT_TILE-key tile is executed from
+// LDS: one launch covers k = 2 .. NU_SORT_TILE completely, and for each larger k the tail j = NU_SORT_TILE/2 .. 1.  Same
+// comparators as lbvh_bitonic_kernel in the same order, hence the same permutation; 10 launches instead of 120 at 32768 keys.
+#define NU_SORT_TILE 4096
+__global__ __launch_bounds__(256) void lbvh_bitonic_local_kernel(unsigned long long* keys, int npad, int k_first, int k_last) {
+    __shared__ unsigned long long sk[NU_SORT_TILE];
+    const int base = blockIdx.x * NU_SORT_TILE;
+    const int tile = npad < NU_SORT_TILE ? npad : NU_SORT_TILE;
+    for (int t = threadIdx.x; t < tile; t += 256) sk[t] = keys[base + t];
+    __syncthreads();
+    for (int k = k_first; k <= k_last; k <<= 1) {
+        for (int j = (k >> 1) < (tile >> 1) ? (k >> 1) : (tile >> 1); j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < tile; t += 256) {
+                const int l = t ^ j;
+                if (l > t) {
+                    const unsigned long long a = sk[t], b = sk[l];
+                    const bool up = ((base + t) & k) == 0;
+                    if ((a > b) == up) { sk[t] = b; sk[l] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int t = threadIdx.x; t < tile; t += 256) keys[base + t] = sk[t];
+}
+
 extern "C" int nu_lbvh_build(const float* V, int n_verts, const int* F, int n_faces, void* bvh, long long bvh_bytes,
                              hipStream_t stream) {
     if (n_faces <= 0 || n_verts <= 0) return NU_ERR_ARG;
@@ -230,9 +257,16 @@ extern "C" int nu_lbvh_build(const float* V, int n_verts, const int* F, int n_fa
     hipLaunchKernelGGL(lbvh_bounds_kernel, dim3(nu_cdiv(n_faces, T)), dim3(T), 0, stream, V, F, n_faces, buf, L);
     hipLaunchKernelGGL(lbvh_morton_kernel, dim3(nu_cdiv(npad, T)), dim3(T), 0, stream, V, F, n_faces, npad, buf, L);
     unsigned long long* keys = (unsigned long long*)(buf + L.keys);
-    for (int k = 2; k <= npad; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1)
-            hipLaunchKernelGGL(lbvh_bitonic_kernel, dim3(nu_cdiv(npad, T)), dim3(T), 0, stream, keys, npad, j, k);
+    {
+        const int tile = npad < NU_SORT_TILE ? npad : NU_SORT_TILE;
+        const int nblk = npad / tile;
+        hipLaunchKernelGGL(lbvh_bitonic_local_kernel, dim3(nblk), dim3(256), 0, stream, keys, npad, 2, tile);
+        for (int k = tile << 1; k <= npad; k <<= 1) {
+            for (int j = k >> 1; j >= tile; j >>= 1)
+                hipLaunchKernelGGL(lbvh_bitonic_kernel, dim3(nu_cdiv(npad, T)), dim3(T), 0, stream, keys, npad, j, k);
+            hipLaunchKernelGGL(lbvh_bitonic_local_kernel, dim3(nblk), dim3(256), 0, stream, keys, npad, k, k);
+        }
+    }
     hipLaunchKernelGGL(lbvh_gather_kernel, dim3(nu_cdiv(n_faces, T)), dim3(T), 0, stream, V, F, n_faces, buf, L);
     if (n_faces > 1) {
         hipLaunchKernelGGL(lbvh_hierarchy_kernel, dim3(nu_cdiv(n_faces - 1, T)), dim3(T), 0, stream, n_faces, buf, L);
@@ -283,13 +317,20 @@ static __device__ inline bool nu_ray_box(const float* o, const float* invd, cons
     return t0 <= t1 * 1.0000005f;
 }
 
+// STACK entries per lane live in LDS, wavefront-interleaved ([entry][lane]: a push or pop of all 64 lanes is one conflict-free
+// row).  The first pass runs with a SHORT stack (16 entries = 4 KB per wave, so LDS no longer pins the kernel at 8 waves per
+// CU: measured 1.22 -> 1.85 G rays/s on 20480 faces, 0.61 -> 1.33 on 327680; 8 / 12 / 24 / 32 entries are slower); a lane whose traversal would need more marks its ray (hit = -1) and the second pass re-traces exactly those rays with
+// the full 64-entry stack (a Morton tree over 30-bit codes + index tie-break is at most 62 deep).  RETRACE: only marked rays.
+template <int STACK, bool RETRACE>
 __global__ __launch_bounds__(256) void lbvh_trace_kernel(const char* __restrict__ buf, NuBvhLayout L, const float* __restrict__ rays,
                                                          int N, float tmin, float tmax, float* __restrict__ hit,
                                                          int* __restrict__ idx, float* __restrict__ tout) {
-    __shared__ int stack[4][NU_STACK][64];
+    __shared__ int stack[4][STACK][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= N) return;
+    if (RETRACE && hit[r] >= 0.0f) return;
+    bool overflow = false;
     const NuBvhHeader* h = (const NuBvhHeader*)(buf + L.header);
     const NuBvhNode* nodes = (const NuBvhNode*)(buf + L.nodes);
     const float* tris = (const float*)(buf + L.tris);
@@ -328,7 +369,8 @@ __global__ __launch_bounds__(256) void lbvh_trace_kernel(const char* __restrict_
             if (il && ir) {
                 const bool left_first = tl <= tr;
                 next = left_first ? nd.left : nd.right;
-                if (sp < NU_STACK) stack[w][sp++][lane] = left_first ? nd.right : nd.left;
+                if (sp < STACK) stack[w][sp++][lane] = left_first ? nd.right : nd.left;
+                else overflow = true;
             } else if (il) {
                 next = nd.left;
             } else if (ir) {
@@ -341,6 +383,7 @@ __global__ __launch_bounds__(256) void lbvh_trace_kernel(const char* __restrict_
             node = next;
         }
     }
+    if (overflow && STACK < NU_STACK) { hit[r] = -1.0f; return; }      // incomplete: the second pass re-traces this ray
     hit[r] = found ? 1.0f : 0.0f;
     idx[r] = best_id;
     if (tout) tout[r] = found ? best_t : 0.0f;
@@ -350,8 +393,20 @@ extern "C" int nu_lbvh_trace(const void* bvh, int n_faces, const float* rays, in
                              int* idx, float* t_out, hipStream_t stream) {
     if (N <= 0) return NU_OK;
     const NuBvhLayout L = nu_bvh_layout(n_faces);
-    hipLaunchKernelGGL(lbvh_trace_kernel, dim3(nu_cdiv(N, 256)), dim3(256), 0, stream, (const char*)bvh, L, rays, N, tmin, tmax,
-                       hit, idx, t_out);
+    static const int full_only = getenv("NU_LBVH_FULL_STACK") ? atoi(getenv("NU_LBVH_FULL_STACK")) : 0;   // development A/B
+    if (full_only) {
+        hipLaunchKernelGGL((lbvh_trace_kernel<NU_STACK, false>), dim3(nu_cdiv(N, 256)), dim3(256), 0, stream, (const char*)bvh, L, rays, N,
+                           tmin, tmax, hit, idx, t_out);
+        return nu_launch_status();
+    }
+    static const int short_env = getenv("NU_LBVH_SHORT") ? atoi(getenv("NU_LBVH_SHORT")) : 16;   // development sweep: 16 measured best
+#define NU_TRACE1(S) hipLaunchKernelGGL((lbvh_trace_kernel<S, false>), dim3(nu_cdiv(N, 256)), dim3(256), 0, stream, (const char*)bvh, L, \
+                                        rays, N, tmin, tmax, hit, idx, t_out)
+    if (short_env == 8) NU_TRACE1(8); else if (short_env == 12) NU_TRACE1(12);
+    else if (short_env == 24) NU_TRACE1(24); else if (short_env == 32) NU_TRACE1(32); else NU_TRACE1(16);
+#undef NU_TRACE1
+    hipLaunchKernelGGL((lbvh_trace_kernel<NU_STACK, true>), dim3(nu_cdiv(N, 256)), dim3(256), 0, stream, (const char*)bvh, L, rays, N,
+                       tmin, tmax, hit, idx, t_out);
     return nu_launch_status();
 }
 
