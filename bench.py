@@ -157,20 +157,62 @@ def main_stage2(args):
         step(i)
     torch.cuda.synchronize()
     entered.clear()
+    n1, n2 = net.nets()
+    engines = (n1.eng, n2.eng)
+    mid = args.warmup + args.steps // 2
+    step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    gc.collect()
+    gc.disable()
     t0 = time.perf_counter()
+    step_ev[0].record()
     for i in range(args.warmup, n):
+        if i == mid and not args.no_kernel_timing:      # one bracketed step: per-launch HIP events on the GEMMs of both engines
+            for e in engines:
+                e.begin_kernel_timing(reserve=1200)
         last = step(i)
+        if i == mid and not args.no_kernel_timing:
+            kts = [e.end_kernel_timing() for e in engines]
+        step_ev[i - args.warmup + 1].record()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
-    print(json.dumps({
+    gc.enable()
+    step_ms = np.array([step_ev[i].elapsed_time(step_ev[i + 1]) for i in range(args.steps)])
+    res = {
         "metric": "train rays/sec", "value": R / dt, "unit": "rays/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * dt, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-        "data": "synthetic",
+        "ms_per_step": 1e3 * dt, "median_ms_per_step": float(np.median(step_ms)), "p10_ms_per_step": float(np.percentile(step_ms, 10)),
+        "p90_ms_per_step": float(np.percentile(step_ms, 90)), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
         "config": {"workload": "stage-2 train step, %d rays, icosphere 20480 faces (HIP LBVH), 3 bounces, segment samples "
                                "256/128/256, fp32 (BASELINE.json configs[2])" % R,
                    "rays": "object-aimed" if args.object_rays else "Spherepot-shaped cameras",
                    "frac_rays_entering_object": float(np.mean(entered)), "final_loss": float(last.detach()),
-                   "max_mem_GB": torch.cuda.max_memory_allocated() / 2 ** 30}}), flush=True)
+                   "max_mem_GB": torch.cuda.max_memory_allocated() / 2 ** 30}}
+    if not args.no_kernel_timing:
+        fl = sum(k['flops'] for k in kts); sec = sum(k['seconds'] for k in kts); ln = sum(k['launches'] for k in kts)
+        tf = fl / max(sec, 1e-12) / 1e12
+        res["roofline"] = {"bound": "mfma", "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_FP32_MFMA_TFLOPS,
+                           "traffic": None, "kernel": "gemm_nt2_kernel<*> (all NT launches of the bracketed step, both engines)",
+                           "launches": ln, "avg_launch_us": 1e6 * sec / max(ln, 1),
+                           "algorithmic_flops_per_launch": fl / max(ln, 1),
+                           "wgrad": {"achieved": sum(k['tn_flops'] for k in kts) / max(sum(k['tn_seconds'] for k in kts), 1e-12) / 1e12,
+                                     "launches": sum(k['tn_launches'] for k in kts)}}
+    # mesh tracing of this step's shape: the first-bounce rays of one batch against the scene's LBVH (latency-bound kernel;
+    # algorithmic bytes = 24 B in + 8 B out per ray)
+    b = {k: v[:R] for k, v in pool.items()}
+    ray = torch.cat([b['rays_o'], torch.nn.functional.normalize(b['rays_d'], dim=-1)], 1).contiguous()
+    net.scene.bvh.intersect(ray)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        hit, _ = net.scene.bvh.intersect(ray)
+    e1.record()
+    torch.cuda.synchronize()
+    us = 1e3 * e0.elapsed_time(e1) / 20
+    res["lbvh_trace"] = {"rays": R, "faces": int(net.scene.bvh.n_faces), "us_per_launch": us, "rays_per_s": R / us * 1e6,
+                         "algorithmic_GBps": R * 32 / us / 1e3, "hit_fraction": float(hit.mean()),
+                         "note": "at 4096 rays the launch is latency-bound (one wave per 64 rays on 256 CUs); scripts/bench_lbvh.py "
+                                 "reports 1.8-4.2 G rays/s at 2^20 rays"}
+    print(json.dumps(res), flush=True)
 
 
 def main():
