@@ -387,10 +387,12 @@ def main():
             tf = ktime['flops'] / max(ktime['seconds'], 1e-12) / 1e12
             # HBM traffic per launch comes from the committed rocprofv3 PMC passes of this same workload (FETCH_SIZE / WRITE_SIZE
             # in separate --pmc runs, gfx950 corrections applied by scripts/summarize_pmc.py); null if absent or other workload
-            traffic = None
-            tj = os.path.join(ROOT, 'profiles', 'r01', 'traffic_pmc.json')
-            if os.path.exists(tj) and R == 4096 and world == 1 and not args.real_capture and args.mlp_dtype == 'fp32':
-                traffic = json.load(open(tj)).get('gemm_nt_kernel', {}).get('hbm_bytes_per_launch')
+            traffic = traffic_tn = None
+            tj = os.path.join(ROOT, 'profiles', 'r02', 'traffic_pmc.json')
+            if os.path.exists(tj) and R == 4096 and world == 1 and not args.real_capture and args.mlp_dtype == 'fp32' and not args.object_rays:
+                tjd = json.load(open(tj))
+                traffic = tjd.get('gemm_nt_kernel', {}).get('hbm_bytes_per_launch')
+                traffic_tn = tjd.get('gemm_tn_kernel', {}).get('hbm_bytes_per_launch')
             common = {"algorithmic_bytes_per_launch": ktime['bytes'] / max(ktime['launches'], 1),
                       "algorithmic_flops_per_launch": ktime['flops'] / max(ktime['launches'], 1),
                       "launches": ktime['launches'], "avg_launch_us": 1e6 * ktime['seconds'] / max(ktime['launches'], 1),
@@ -398,6 +400,9 @@ def main():
                       "gemm_time_share": ktime['seconds'] / (elapsed * timed_steps / args.steps),
                       "wgrad": {"achieved": ktime['tn_flops'] / max(ktime['tn_seconds'], 1e-12) / 1e12,
                                 "launches": ktime['tn_launches'],
+                                "algorithmic_bytes_per_launch": ktime['tn_bytes'] / max(ktime['tn_launches'], 1),
+                                "avg_launch_us": 1e6 * ktime['tn_seconds'] / max(ktime['tn_launches'], 1),
+                                "traffic": traffic_tn,
                                 "time_share": ktime['tn_seconds'] / (elapsed * timed_steps / args.steps)}}
             if args.mlp_dtype == 'bf16x6':
                 # six bf16 MFMAs per 16-deep k-step: price the achieved rate against the bf16 pipe doing 6x the arithmetic
@@ -413,7 +418,7 @@ def main():
             else:
                 res["roofline"] = {"bound": "mfma", "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                    "frac": tf / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
-                                   "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/r01/traffic_pmc.json)",
+                                   "traffic_unit": "HBM bytes per launch (rocprofv3 PMC of this workload and these kernels, profiles/r02/traffic_pmc.json; re-collect when a GEMM kernel changes)",
                                    "kernel": "gemm_nt2_kernel<*> (fp32 v_mfma_f32_32x32x2_f32, software-pipelined, 2 LDS stages)", **common}
         if world == 1 and not args.no_cpu_baseline and not args.real_capture and args.mlp_dtype == 'fp32':
             res["cpu_baseline"] = cpu_baseline(pool, args.start_step)

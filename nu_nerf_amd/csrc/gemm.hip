@@ -832,9 +832,13 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(NuGemmTN g) {
     const int wid = tid >> 6;
     const int wr = wid >> 1, wc = wid & 1;
     const int t2 = (g.N2 + 127) / 128;
+    // (tile, split) = (blockIdx.x, blockIdx.y).  Every tile of one split reads the same p-range of both operands, and with this
+    // grid a split's tiles land on different XCDs: rocprofv3 FETCH_SIZE (x2-corrected; calibrated on this access width by
+    // scripts/gemm_lab calib) shows 1.9x the algorithmic bytes per launch leaving the L2s.  Giving a split's tiles linear ids
+    // that are congruent mod 8 (one XCD) was measured 7 % SLOWER in the step (108.9 -> 101.7 TFLOP/s) and is not done.
     const int n1t = blockIdx.x / t2, n2t = blockIdx.x - n1t * t2;
-    const int n1_0 = n1t * 128, n2_0 = n2t * 128;
     const int split = blockIdx.y;
+    const int n1_0 = n1t * 128, n2_0 = n2t * 128;
     const int grp = blockIdx.z;
     const int N1p = ((g.N1 + 127) / 128) * 128, N2p = t2 * 128;
 

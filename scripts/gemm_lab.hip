@@ -62,6 +62,19 @@ __global__ __launch_bounds__(256) void bare_mfma_kernel(const float* __restrict_
     if (blockIdx.x == 0 && threadIdx.x == 0) { lab_clk[0] = clock64() - c0; lab_clk[1] = wall_clock64() - w0; }
 }
 
+// FETCH_SIZE calibration (MI355X_MICROARCH.md: "calibrate on a known byte count in your own access pattern"): streaming reads
+// of a known number of bytes with 4 B per lane (the TN kernel's transposing loads) and with 16 B per lane
+__global__ __launch_bounds__(256) void calib_read4_kernel(const float* __restrict__ p, long long n, float* out) {
+    float s = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) s += p[i];
+    if (s == 123.456f) out[0] = s;
+}
+__global__ __launch_bounds__(256) void calib_read16_kernel(const f32x4* __restrict__ p, long long n4, float* out) {
+    float s = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) { const f32x4 v = p[i]; s += v[0] + v[3]; }
+    if (s == 123.456f) out[0] = s;
+}
+
 struct Bufs { float *A, *B, *C, *C2, *H, *D, *bias; int M, N, K; };
 
 static double time_nt(const Bufs& b, int epi, int iters) {
@@ -120,6 +133,15 @@ int main(int argc, char** argv) {
         }
         nu_lab_grid = 0; nu_lab_v1 = 0;
         set_int(nu_lab_skip_epi, 0);
+    } else if (!strcmp(mode, "calib")) {
+        // run under `rocprofv3 --pmc FETCH_SIZE`: each launch reads exactly 553,648,128 bytes (the 540672 x 256 fp32 operand)
+        const long long n = (long long)M * 256;
+        for (int i = 0; i < 3; ++i) {
+            hipLaunchKernelGGL(calib_read4_kernel, dim3(4096), dim3(256), 0, 0, b256.A, n, b256.C);
+            hipLaunchKernelGGL(calib_read16_kernel, dim3(4096), dim3(256), 0, 0, (const f32x4*)b256.A, n / 4, b256.C);
+        }
+        CK(hipDeviceSynchronize());
+        printf("calib: each launch read %lld bytes\n", n * 4);
     } else if (!strcmp(mode, "mem")) {
         // is the lone workgroup's main loop waiting for memory?  A from an 8 MB window vs streamed from HBM
         for (int small = 0; small < 2; ++small) {

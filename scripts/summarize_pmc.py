@@ -8,7 +8,9 @@ def agg(path, name):
     for r in csv.DictReader(open(path)):
         if r['Counter_Name'] != name:
             continue
-        k = 'gemm_nt_kernel' if 'gemm_nt_kernel' in r['Kernel_Name'] else ('gemm_tn_kernel' if 'gemm_tn_kernel' in r['Kernel_Name'] else None)
+        kn = r['Kernel_Name']
+        k = 'gemm_nt_kernel' if ('gemm_nt_kernel' in kn or 'gemm_nt2_kernel' in kn) else ('gemm_tn_kernel' if 'gemm_tn_kernel' in kn else
+             ('calib_read4' if 'calib_read4' in kn else ('calib_read16' if 'calib_read16' in kn else None)))
         if k:
             out[k][0] += 1
             out[k][1] += float(r['Counter_Value'])
