@@ -99,6 +99,8 @@ int nu_gemm_nt_size(void);      /* sizeof(NuGemmNT) / sizeof(NuGemmTN) as compil
 int nu_gemm_tn_size(void);
 int nu_gemm_nt_ex(const NuGemmNT* g, hipStream_t stream);
 long long nu_wgrad_workspace_bytes(int N1, int N2, int S, int groups);
+/* the split (number of deterministic partial slabs) the library's own sequencing uses for a weight gradient of this shape */
+int nu_wgrad_pick_split(int P, int N1, int N2, int groups, int prec);
 /* deferred weight gradient: split GEMM now, reductions appended to descs[*ndesc...] (capacity cap); the workspace must
  * stay untouched until nu_slab_reduce_batched(descs, *ndesc) has been enqueued */
 int nu_wgrad_enqueue(const NuGemmTN* g, float* dW, int ldw, long long sW, float* db, long long sDb, void* workspace,

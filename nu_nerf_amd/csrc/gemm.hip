@@ -1031,9 +1031,181 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(NuGemmTN g) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// TN kernel, exact fp32, 256 x 256 output tile per workgroup (512 threads, 8 waves as 4 x 2, each wave 64 x 128 = 2 x 4
+// MFMA tiles, 128 accumulator VGPRs; one workgroup per CU).  For the dominant weight-gradient shape (N1, N2 multiples of
+// 256) every operand row is fetched ONCE per split instead of once per output-tile row / column (the 128 x 128 kernel above
+// moved 1.9x its algorithmic bytes out of the L2s, profiles/r02/traffic_pmc.json) and the 32 transposing scalar loads per
+// thread and chunk now feed 128 MFMAs per wave instead of 64: half the load-issue time per matrix cycle.
+// Same slab layout, same bias sums, same ragged-tail rules as gemm_tn_kernel.
+// ------------------------------------------------------------------------------------------------
+template <bool BIG>
+__global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(NuGemmTN g) {
+    __shared__ __attribute__((aligned(16))) float smem[2][256 * NT_LDS];      // [A | B][column][k (+4 pad)] = 73,728 B
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = tid >> 6;
+    const int wr = wid >> 1, wc = wid & 1;           // wave tile: rows (N1) 64 wr .. +64, columns (N2) 128 wc .. +128
+    const int t2 = g.N2 / 256;
+    const int n1t = blockIdx.x / t2, n2t = blockIdx.x - n1t * t2;
+    const int n1_0 = n1t * 256, n2_0 = n2t * 256;
+    const int split = blockIdx.y;
+    const int grp = blockIdx.z;
+    const int N1p = g.N1, N2p = g.N2;                // multiples of 256 (launcher)
+
+    int rows_per = (g.P + g.S - 1) / g.S;
+    rows_per = ((rows_per + TBK - 1) / TBK) * TBK;
+    const int p_begin = split * rows_per;
+    int p_end = p_begin + rows_per;
+    p_end = p_end < g.P ? p_end : g.P;
+    const int ntile = p_end > p_begin ? (p_end - p_begin + TBK - 1) / TBK : 0;
+    const int npair = g.A1 ? 2 : 1;
+    const int total = ntile * npair;
+
+    const int c = tid & 255;    // column of the 256-wide operand tile this thread fetches
+    const int kg = tid >> 8;    // which 16 of the chunk's 32 reduced rows (wave-uniform)
+    const bool do_bias = (g.bias_slab != nullptr) && (n2t == 0);
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    f32x4 ra4[4], rb4[4];
+    int nvalid = 16;
+    bool pend_pair0 = true;
+    float bs = 0.f;
+    auto load_tile = [&](int t) {
+        const int pair = t >= ntile ? 1 : 0;
+        const int kt = t - pair * ntile;
+        const char* __restrict__ A = (const char*)(pair ? g.A1 + (long long)grp * g.sA1 : g.A0 + (long long)grp * g.sA0);
+        const char* __restrict__ B = (const char*)(pair ? g.B1 + (long long)grp * g.sB1 : g.B0 + (long long)grp * g.sB0);
+        const int lda = pair ? g.lda1 : g.lda0;
+        const int ldb = pair ? g.ldb1 : g.ldb0;
+        int ca = n1_0 + c, cb = n2_0 + c;
+        ca = ca < lda ? ca : lda - 1;
+        cb = cb < ldb ? cb : ldb - 1;
+        const int pbase = p_begin + kt * TBK + kg * 16;
+        nvalid = p_end - pbase;
+        pend_pair0 = pair == 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                int pr = pbase + 4 * i + e;
+                pr = pr < p_end ? pr : p_end - 1;
+                if (BIG) {
+                    ra4[i][e] = reinterpret_cast<const float*>(A)[(long long)pr * lda + ca];
+                    rb4[i][e] = reinterpret_cast<const float*>(B)[(long long)pr * ldb + cb];
+                } else {
+                    const unsigned oa = ((unsigned)pr * (unsigned)lda + (unsigned)ca) * 4u;
+                    const unsigned ob = ((unsigned)pr * (unsigned)ldb + (unsigned)cb) * 4u;
+                    ra4[i][e] = *reinterpret_cast<const float*>(A + oa);
+                    rb4[i][e] = *reinterpret_cast<const float*>(B + ob);
+                }
+            }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool ok = 4 * i + e < nvalid;
+                ra4[i][e] = ok ? ra4[i][e] : 0.f;
+                rb4[i][e] = ok ? rb4[i][e] : 0.f;
+            }
+        if (do_bias && pend_pair0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bs += (ra4[i][0] + ra4[i][1]) + (ra4[i][2] + ra4[i][3]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<f32x4*>(&smem[0][c * NT_LDS + kg * 16 + 4 * i]) = ra4[i];
+            *reinterpret_cast<f32x4*>(&smem[1][c * NT_LDS + kg * 16 + 4 * i]) = rb4[i];
+        }
+    };
+
+    if (total > 0) {
+        load_tile(0);
+        store_tile();
+    }
+    __syncthreads();
+
+    const int li = lane & 31, lh = lane >> 5;
+    const int a_off = (wr * 64 + li) * NT_LDS + 4 * lh;
+    const int b_off = (wc * 128 + li) * NT_LDS + 4 * lh;
+    for (int t = 0; t < total; ++t) {
+        if (t + 1 < total) load_tile(t + 1);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            f32x4 a[2], b[4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const f32x4*>(&smem[0][a_off + 32 * i * NT_LDS + kk * 8]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const f32x4*>(&smem[1][b_off + 32 * j * NT_LDS + kk * 8]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+        if (t + 1 < total) {
+            store_tile();
+            __syncthreads();
+        }
+    }
+
+    float* __restrict__ slab = g.slab + (long long)grp * g.sSlab + (long long)split * N1p * N2p;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) {
+            const int col = n2_0 + wc * 128 + tn * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = n1_0 + wr * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                slab[(long long)row * N2p + col] = acc[tm][tn][r];
+            }
+        }
+    if (do_bias) {
+        float* red = &smem[0][0];
+        red[kg * 256 + c] = bs;
+        __syncthreads();
+        if (tid < 256) g.bias_slab[(long long)grp * g.sBiasSlab + (long long)split * N1p + n1_0 + tid] = red[tid] + red[256 + tid];
+    }
+}
+
+// The split both launch paths use: enough workgroups for the chip, as few and as large slabs as possible.  The 256-wide kernel
+// takes the shapes whose N1 and N2 are multiples of 256 in exact fp32 (one workgroup per CU: 256 of them).
+extern "C" int nu_wgrad_pick_split(int P, int N1, int N2, int groups, int prec) {
+    if (groups < 1) groups = 1;
+    static const bool tn128_env = getenv("NU_TN_128") && atoi(getenv("NU_TN_128")) != 0;      // development switch (see the launcher)
+    const bool big_tile = prec == 0 && !tn128_env && (N1 % 256) == 0 && (N2 % 256) == 0;
+    const int tiles = big_tile ? (N1 / 256) * (N2 / 256) * groups : nu_cdiv(N1, 128) * nu_cdiv(N2, 128) * groups;
+    int S = (big_tile ? 256 : 512) / tiles;
+    if (S < 1) S = 1;
+    const int cap = (P + 255) / 256;
+    if (S > cap) S = cap;
+    return S < 1 ? 1 : S;
+}
+
 int nu_gemm_tn_launch(const NuGemmTN& g, hipStream_t stream) {
     if (g.N1 <= 0 || g.N2 <= 0 || g.S <= 0) return NU_ERR_ARG;
     if ((g.lda0 & 3) || (g.ldb0 & 3) || (g.A1 && ((g.lda1 & 3) || (g.ldb1 & 3)))) return NU_ERR_ARG;
+    static const bool tn128_env = getenv("NU_TN_128") && atoi(getenv("NU_TN_128")) != 0;      // development switch: 128 x 128 tiles only
+    if ((g.bf16 & 3) == 0 && !tn128_env && (g.N1 % 256) == 0 && (g.N2 % 256) == 0) {
+        dim3 grid2((g.N1 / 256) * (g.N2 / 256), g.S, g.groups > 0 ? g.groups : 1);
+        const long long mld = (g.lda0 > g.ldb0 ? g.lda0 : g.ldb0) > (g.A1 ? (g.lda1 > g.ldb1 ? g.lda1 : g.ldb1) : 0)
+                                  ? (g.lda0 > g.ldb0 ? g.lda0 : g.ldb0) : (g.lda1 > g.ldb1 ? g.lda1 : g.ldb1);
+        if ((long long)g.P * mld * 4 >= (1LL << 32)) hipLaunchKernelGGL((gemm_tn256_kernel<true>), grid2, dim3(512), 0, stream, g);
+        else hipLaunchKernelGGL((gemm_tn256_kernel<false>), grid2, dim3(512), 0, stream, g);
+        return nu_launch_status();
+    }
     dim3 grid(nu_cdiv(g.N1, 128) * nu_cdiv(g.N2, 128), g.S, g.groups > 0 ? g.groups : 1), block(256);
     const long long max_ld = (g.lda0 > g.ldb0 ? g.lda0 : g.ldb0) > (g.A1 ? (g.lda1 > g.ldb1 ? g.lda1 : g.ldb1) : 0)
                                  ? (g.lda0 > g.ldb0 ? g.lda0 : g.ldb0) : (g.lda1 > g.ldb1 ? g.lda1 : g.ldb1);

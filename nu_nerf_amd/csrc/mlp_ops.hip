@@ -67,16 +67,12 @@ static int nt(const NuOpCtx* c, const NtArgs& a, hipStream_t stream) {
     return nu_gemm_nt_launch(g, stream);
 }
 
-// dW[N1, N2] = A0^T B0 (+ A1^T B1), db = column sums of A0; the split follows the host layer's rule (512 workgroups)
+// dW[N1, N2] = A0^T B0 (+ A1^T B1), db = column sums of A0; split: nu_wgrad_pick_split
 static int wgrad(NuOpCtx* c, const float* A0, int lda0, const float* B0, int ldb0, int P, int N1, int N2, float* dW, int ldw, float* db,
                  hipStream_t stream, const float* A1 = nullptr, int lda1 = 0, const float* B1 = nullptr, int ldb1 = 0, int groups = 1,
                  long long sA0 = 0, long long sB0 = 0, long long sW = 0, long long sDb = 0) {
     if (P <= 0) return NU_OK;
-    const int tiles = ((N1 + 127) / 128) * ((N2 + 127) / 128) * groups;
-    int S = 512 / tiles;
-    if (S < 1) S = 1;
-    if (S > (P + 255) / 256) S = (P + 255) / 256;
-    if (S < 1) S = 1;
+    const int S = nu_wgrad_pick_split(P, N1, N2, groups, c->prec);
     float* ws;
     long long nb;
     CHK(ctx_take(c, nu_wgrad_workspace_bytes(N1, N2, S, groups), 2 * groups, stream, &ws, &nb));

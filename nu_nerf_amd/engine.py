@@ -540,8 +540,7 @@ class Stage1Engine:
                              4.0 * groups * (npair * P * (N1 + (n2true or N2)) + N1 * N2)))
 
     def _wgrad(self, A0, lda0, B0, ldb0, P, N1, N2, dW, ldw, db, A1, lda1, B1, ldb1, groups, sA0, sB0, sA1, sB1, sW, sDb):
-        tiles = ((N1 + 127) // 128) * ((N2 + 127) // 128) * groups
-        S = max(1, min((P + 255) // 256, max(1, 512 // tiles)))   # 2 workgroups per CU; fewer, larger slabs
+        S = self.lib.nu_wgrad_pick_split(P, N1, N2, groups, self.bf16)     # the rule the network-level C entries use too
         if self._ctx.ndesc + 2 * groups > self._rd_cap:
             self.flush_reductions()
         ws, nb = self._arena_take(self.lib.nu_wgrad_workspace_bytes(N1, N2, S, groups))
