@@ -47,6 +47,10 @@ enum NuEpi {                   /* epilogue applied to v = alpha * (A . B^T)[row,
     NU_EPI_COUNT = 9
 };
 
+#define NU_GEMM_B16 8
+#define NU_GEMM_A16 16
+#define NU_GEMM_C16 32
+#define NU_GEMM_X16 64
 typedef struct NuGemmNT {      /* C[M,N] = epi(A[M,K] . B[N,K]^T);  K % 32 == 0, lda/ldb % 4 == 0, A/B 16-byte aligned */
     const float* A; int lda;
     const float* B; int ldb;   /* packed weights: >= ceil128(N) rows, zero padded */
@@ -63,8 +67,12 @@ typedef struct NuGemmNT {      /* C[M,N] = epi(A[M,K] . B[N,K]^T);  K % 32 == 0,
     int groups;                /* grouped launch; element strides per group follow */
     long long sA, sB, sC, sC2, sBias, sH, sD, sCadd;
     int epi;                   /* enum NuEpi */
-    int bf16;                  /* 0: exact fp32 MFMA (default).  1: operands rounded to bf16 on load, bf16 MFMA, fp32 accumulate.
-                                  2: exact 3-way bf16 split of both operands, the six partial products >= 2^-16 (fp32-equivalent) */
+    int bf16;                  /* bits 0-1: 0 exact fp32 MFMA (default); 1 bf16 MFMA, fp32 accumulate (operands rounded to bf16);
+                                  2 exact 3-way bf16 split of both operands, the six partial products >= 2^-16 (fp32-equivalent).
+                                  With mode 1, storage flags (bf16 tensors in HBM, `float*` fields then point to __bf16 data,
+                                  leading dimensions stay in ELEMENTS): NU_GEMM_B16 (required: selects the bf16-storage kernel)
+                                  B is a bf16 weight table (NuPackDesc.Wp16 / WpT16); NU_GEMM_A16: A is bf16; NU_GEMM_C16: C and
+                                  C2 are written as bf16; NU_GEMM_X16: H, D, Cadd are bf16 */
     /* ReLU sign bits (optional): NU_EPI_BIAS_RELU writes, NU_EPI_MUL_DRELU / NU_EPI_B_RELU read them INSTEAD of H -- 2 KB per
      * 128x128 tile in place of 64 KB of activations.  Layout is private to the kernel (wave ballots per 4-row group):
      * cdiv(M,128) * mask_nct * 256 words, mask_nct = column tiles of the activation matrix as the WRITER saw it
@@ -79,8 +87,12 @@ typedef struct NuGemmTN {      /* dW[N1,N2] = A0^T B0 (+ A1^T B1), reduced over 
     float* slab; float* bias_slab;                           /* filled by nu_wgrad from the workspace */
     int S, groups;
     long long sA0, sB0, sA1, sB1, sSlab, sBiasSlab;
-    int bf16, pad_;                                          /* as NuGemmNT.bf16 */
+    int bf16, pad_;                                          /* bits 0-1 as NuGemmNT.bf16; storage flags (mode 1): NU_TN_A0_16 ... */
 } NuGemmTN;
+#define NU_TN_A0_16 16
+#define NU_TN_B0_16 32
+#define NU_TN_A1_16 64
+#define NU_TN_B1_16 128
 
 /* One deterministic split reduction: out[n1*ldo + n2] (+)= alpha * sum_{s<S} slab[s*ss + n1*rs + n2], n1 < N1, n2 < N2.
  * Producers (nu_wgrad_enqueue, nu_skinny_bwd_enqueue, nu_colsum_enqueue) append these to a caller-owned HOST array;
@@ -128,6 +140,7 @@ typedef struct NuPackDesc {
     const float* bias; float* bias_p;
     float scale;
     int N, K, Kp, ldT, ldd, row_begin, col_off;
+    void* Wp16; void* WpT16;                  /* optional bf16 copies of Wp / WpT (same shapes, same leading dimensions) */
 } NuPackDesc;
 int nu_pack_desc_size(void);
 int nu_pack_layers(const void* descs_dev, int ndesc, int total_rows, hipStream_t stream);

@@ -38,6 +38,8 @@ __global__ __launch_bounds__(64) void pack_kernel(const NuPackDesc* __restrict__
         const float w = v[k] * s;
         d.Wp[(long long)n * d.Kp + kp] = w;
         if (d.WpT) d.WpT[(long long)kp * d.ldT + n] = w;
+        if (d.Wp16) reinterpret_cast<__bf16*>(d.Wp16)[(long long)n * d.Kp + kp] = (__bf16)w;
+        if (d.WpT16) reinterpret_cast<__bf16*>(d.WpT16)[(long long)kp * d.ldT + n] = (__bf16)w;
     }
     if (lane == 0 && d.bias_p) d.bias_p[n] = d.bias[n];
 }

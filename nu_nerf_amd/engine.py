@@ -58,7 +58,7 @@ class ReduceDesc(ctypes.Structure):
 class PackDesc(ctypes.Structure):
     _fields_ = [("v", c_p), ("g", c_p), ("colmap", c_p), ("Wp", c_p), ("WpT", c_p), ("dWp", c_p), ("dv_off", c_ll),
                 ("dg_off", c_ll), ("bias", c_p), ("bias_p", c_p), ("scale", c_f), ("N", c_int), ("K", c_int),
-                ("Kp", c_int), ("ldT", c_int), ("ldd", c_int), ("row_begin", c_int), ("col_off", c_int)]
+                ("Kp", c_int), ("ldT", c_int), ("ldd", c_int), ("row_begin", c_int), ("col_off", c_int), ("Wp16", c_p), ("WpT16", c_p)]
 
 
 class Lin(ctypes.Structure):
