@@ -410,11 +410,15 @@ def main():
                                    "frac": 6 * tf / 2516.6, "traffic": None, "fp32_equivalent_tflops": tf,
                                    "kernel": "gemm_nt_kernel<*, split> (6 x v_mfma_f32_32x32x16_bf16 per k-step)", **common}
             elif args.mlp_dtype != 'fp32':
-                # bf16 build: the operands stay fp32 in HBM and are rounded on load, so the GEMMs are bound by streaming them
+                # bf16 build: 16x the fp32 MFMA rate, so the GEMMs are bound by streaming their operands; the algorithmic bytes
+                # count each matrix at the width it is stored in (bf16 weight tables and hidden activations, fp32 elsewhere)
                 gbs = ktime['bytes'] / max(ktime['seconds'], 1e-12) / 1e9
+                stored = eng.h16
                 res["roofline"] = {"bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0,
                                    "traffic": None, "mfma_tflops": tf,
-                                   "kernel": "gemm_nt_kernel<*, bf16> (v_mfma_f32_32x32x16_bf16, fp32 operands in HBM)", **common}
+                                   "kernel": ("gemm_nt16_kernel<*> (v_mfma_f32_32x32x16_bf16, bf16 weights and hidden activations in HBM)"
+                                              if stored else "gemm_nt_kernel<*, bf16> (v_mfma_f32_32x32x16_bf16, fp32 operands in HBM)"),
+                                   **common}
             else:
                 res["roofline"] = {"bound": "mfma", "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                    "frac": tf / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,

@@ -282,13 +282,23 @@ typedef struct NuLin {
     const float* Wp; const float* WpT; float* dWp; const float* bias;
     long long db_off;
     int N, K, Kp, ldT, ldd, pad_;
+    const void* Wp16; const void* WpT16;  /* bf16 copies of Wp / WpT (NuPackDesc.Wp16 / WpT16); used when NuOpCtx.h16 */
 } NuLin;
 
+/* NuOpCtx.h16 != 0 (with prec == 1): bf16 STORAGE.  Every NT GEMM reads the bf16 weight tables and the hidden activations
+ * that only GEMMs touch live in HBM as bf16; the caller allocates exactly these buffers as __bf16 (same shapes and leading
+ * dimensions, in elements), everything else stays fp32:
+ *   SDF      H[1..3], H[5..7];  D[0..2], D[4..6];  Q[1..3], Q[5..7];  C[l] / Aux[l] for l in {0,1,2,4,5,6}
+ *   NeRF++   H[1..4], H[6..7];  dA[1..4], dA[6..8]
+ *   shading  M[0], M[1], dM[0], dM[1];  hidden [0], [1] and tmp[0], tmp[1] of every light predictor
+ * Optional per-launch timing: when `ev` is set, every GEMM launch is bracketed by hipEventRecord on ev[nev], ev[nev + 1]
+ * and described in ev_meta[nev / 2] = {kind (0 NT, 1 TN), algorithmic flops, algorithmic bytes} until ev_cap is reached. */
 typedef struct NuOpCtx {
-    int prec, pad_;                       /* NuGemmNT.bf16 of every GEMM */
+    int prec, h16;                        /* NuGemmNT.bf16 arithmetic mode of every GEMM; bf16 storage */
     float* flat;                          /* flat gradient buffer of the current backward */
     float* arena; long long arena_floats; long long arena_off;
     NuReduceDesc* descs; int ndesc, cap;  /* HOST array of deferred reductions */
+    void** ev; double* ev_meta; int nev, ev_cap;      /* HOST arrays: hipEvent_t handles, 3 doubles per launch */
 } NuOpCtx;
 int nu_op_ctx_size(void);
 int nu_ctx_flush(NuOpCtx* ctx, hipStream_t stream);
@@ -334,6 +344,7 @@ typedef struct NuShadeNet {
     NuLin outer_light[4], inner_light[4], inner_weight[4], refrac_light[4];
     const float* lut;
     float exp_max; int sphere, ld_ol, refrac_dim, ld_rl, pad_;
+    const void *WpM0_16, *WpTM0_16; const void* WpM16[3]; const void* WpTM16[3];     /* bf16 copies (NuOpCtx.h16) */
 } NuShadeNet;
 typedef struct NuShadeBufs {
     int P, R;                             /* inner points; per-ray mirror queries riding along the outer_light batch */

@@ -64,6 +64,7 @@ struct NtEpiArgs {       // per launch (and group)
     unsigned long long* mask;
     int zero_to, act_cols;
     bool vec_ok;
+    bool c16, x16;           // bf16-storage kernel only: C / C2 are bf16; H / D / Cadd are bf16
     static constexpr bool kMaskW = (EPI == NU_EPI_BIAS_RELU);                                  // writes ReLU sign bits
     static constexpr bool kMaskR = (EPI == NU_EPI_MUL_DRELU || EPI == NU_EPI_B_RELU);          // reads them instead of H
     static constexpr bool kNeedH = (EPI == NU_EPI_MUL_DRELU || EPI == NU_EPI_MUL_DSP || EPI == NU_EPI_Q_SP ||
@@ -73,26 +74,56 @@ struct NtEpiArgs {       // per launch (and group)
     static constexpr bool kBias = (EPI <= NU_EPI_BIAS_SOFTPLUS);
 };
 
-template <int EPI>
+// H16: the bf16-storage kernel (matrices flagged 16-bit are __bf16 behind their float* fields; strides stay in elements)
+template <int EPI, bool H16 = false>
 static __device__ inline NtEpiArgs<EPI> nt_epi_args(const NuGemmNT& g, int z) {
     typedef NtEpiArgs<EPI> E;
     E a;
-    a.C = g.C + (long long)z * g.sC;
-    a.C2 = g.C2 ? g.C2 + (long long)z * g.sC2 : nullptr;
+    a.c16 = H16 && (g.bf16 & NU_GEMM_C16) != 0;
+    a.x16 = H16 && (g.bf16 & NU_GEMM_X16) != 0;
+    const int ec = a.c16 ? 2 : 4, ex = a.x16 ? 2 : 4;      // element bytes
+    auto off = [](const float* p, long long elems, int eb) { return reinterpret_cast<const float*>(reinterpret_cast<const char*>(p) + elems * eb); };
+    a.C = const_cast<float*>(off(g.C, (long long)z * g.sC, ec));
+    a.C2 = g.C2 ? const_cast<float*>(off(g.C2, (long long)z * g.sC2, ec)) : nullptr;
     a.bias = g.bias ? g.bias + (long long)z * g.sBias : nullptr;
-    a.H = g.H ? g.H + (long long)z * g.sH : nullptr;
-    a.D = g.D ? g.D + (long long)z * g.sD : nullptr;
-    a.Cadd = g.Cadd ? g.Cadd + (long long)z * g.sCadd : nullptr;
+    a.H = g.H ? off(g.H, (long long)z * g.sH, ex) : nullptr;
+    a.D = g.D ? off(g.D, (long long)z * g.sD, ex) : nullptr;
+    a.Cadd = g.Cadd ? off(g.Cadd, (long long)z * g.sCadd, ex) : nullptr;
     a.zero_to = g.zero_to > g.N ? g.zero_to : g.N;
     a.act_cols = g.act_cols > 0 ? g.act_cols : 0x7fffffff;
     a.mask = (E::kMaskW || E::kMaskR) ? g.mask : nullptr;
-    // 16-byte vector path needs every touched matrix 16-B aligned with ld % 4 == 0 (wave-uniform test)
-    bool v = (((uintptr_t)a.C & 15) == 0) && ((g.ldc & 3) == 0);
-    if (E::kNeedH) v = v && (((uintptr_t)a.H & 15) == 0) && ((g.ldh & 3) == 0);
-    if (E::kNeedD) v = v && (((uintptr_t)a.D & 15) == 0) && ((g.ldd & 3) == 0) && (((uintptr_t)a.C2 & 15) == 0) && ((g.ldc2 & 3) == 0);
-    if (E::kNeedAdd) v = v && (((uintptr_t)a.Cadd & 15) == 0) && ((g.ldadd & 3) == 0);
+    // vector path: 4 elements per lane (16 B fp32 / 8 B bf16): every touched matrix aligned to that, ld % 4 == 0 (wave-uniform test)
+    const uintptr_t mc = a.c16 ? 7 : 15, mx = a.x16 ? 7 : 15;
+    bool v = (((uintptr_t)a.C & mc) == 0) && ((g.ldc & 3) == 0);
+    if (E::kNeedH) v = v && (((uintptr_t)a.H & mx) == 0) && ((g.ldh & 3) == 0);
+    if (E::kNeedD) v = v && (((uintptr_t)a.D & mx) == 0) && ((g.ldd & 3) == 0) && (((uintptr_t)a.C2 & mc) == 0) && ((g.ldc2 & 3) == 0);
+    if (E::kNeedAdd) v = v && (((uintptr_t)a.Cadd & mx) == 0) && ((g.ldadd & 3) == 0);
     a.vec_ok = v;
     return a;
+}
+
+// element accessors of the epilogue: `is16` selects __bf16 storage (compiled out of the fp32 kernels)
+static __device__ __forceinline__ f32x4 nu_bf16x4_to_f32(uint2 r) {
+    f32x4 o;
+    o[0] = __uint_as_float(r.x << 16); o[1] = __uint_as_float(r.x & 0xffff0000u);
+    o[2] = __uint_as_float(r.y << 16); o[3] = __uint_as_float(r.y & 0xffff0000u);
+    return o;
+}
+template <bool H16> static __device__ __forceinline__ f32x4 nt_ld4(const char* p, bool is16) {
+    if (H16 && is16) return nu_bf16x4_to_f32(*reinterpret_cast<const uint2*>(p));
+    return *reinterpret_cast<const f32x4*>(p);
+}
+template <bool H16> static __device__ __forceinline__ void nt_st4(char* p, f32x4 v, bool is16) {
+    if (H16 && is16) *reinterpret_cast<bf16x4*>(p) = nu_to_bf16x4(v);
+    else *reinterpret_cast<f32x4*>(p) = v;
+}
+template <bool H16> static __device__ __forceinline__ float nt_ld1(const float* base, long long idx, bool is16) {
+    if (H16 && is16) return __uint_as_float((unsigned)reinterpret_cast<const unsigned short*>(base)[idx] << 16);
+    return base[idx];
+}
+template <bool H16> static __device__ __forceinline__ void nt_st1(float* base, long long idx, float v, bool is16) {
+    if (H16 && is16) reinterpret_cast<__bf16*>(base)[idx] = (__bf16)v;
+    else base[idx] = v;
 }
 
 // sign-bit words of the wave's 64 x 64 slab of tile (mt, nt) of group z (nullptr: no mask for this tile)
@@ -103,7 +134,7 @@ static __device__ inline unsigned long long* nt_mask_words(const NtEpiArgs<EPI>&
 }
 
 // NBH: row groups whose auxiliary loads are in flight together in the fast path (register budget of the caller)
-template <int EPI, int NBH>
+template <int EPI, int NBH, bool H16 = false>
 static __device__ __forceinline__ void nt_epilogue(const NuGemmNT& g, const NtEpiArgs<EPI>& ea, f32x16 (&acc)[2][2], float* scr,
                                                    int m0, int n0, unsigned long long* mwave, unsigned mlo, unsigned mhi,
                                                    int lane, int wid, bool lab_skip) {
@@ -113,6 +144,8 @@ static __device__ __forceinline__ void nt_epilogue(const NuGemmNT& g, const NtEp
     const float* const bias = ea.bias; const float* const H = ea.H; const float* const D = ea.D; const float* const Cadd = ea.Cadd;
     const int zero_to = ea.zero_to, act_cols = ea.act_cols;
     const bool vec_ok = ea.vec_ok;
+    const bool c16 = H16 && ea.c16, x16 = H16 && ea.x16;
+    const int ec = c16 ? 2 : 4, ex = x16 ? 2 : 4;      // element bytes (4 and 4 in the fp32 kernels: folded)
     const int li = lane & 31, lh = lane >> 5;
     const int wr = wid >> 1, wc = wid & 1;
     unsigned wlo = 0, whi = 0;      // writer: lane l accumulates word l
@@ -134,14 +167,14 @@ static __device__ __forceinline__ void nt_epilogue(const NuGemmNT& g, const NtEp
     const int uwid = __builtin_amdgcn_readfirstlane(wid);
     const long long urow0 = m0 + (uwid >> 1) * 64, ucol0 = n0 + (uwid & 1) * 64;
     const unsigned lrow = lane >> 4;
-    char* const Cu = reinterpret_cast<char*>(C + urow0 * g.ldc + ucol0);
-    char* const C2u = kNeedD ? reinterpret_cast<char*>(C2 + urow0 * g.ldc2 + ucol0) : nullptr;
-    const char* const Hu = kNeedH ? reinterpret_cast<const char*>(H + urow0 * g.ldh + ucol0) : nullptr;
-    const char* const Du = kNeedD ? reinterpret_cast<const char*>(D + urow0 * g.ldd + ucol0) : nullptr;
-    const char* const Au = kNeedAdd ? reinterpret_cast<const char*>(Cadd + urow0 * g.ldadd + ucol0) : nullptr;
-    const unsigned oC = (lrow * (unsigned)g.ldc + (unsigned)colq) * 4u, oC2 = (lrow * (unsigned)g.ldc2 + (unsigned)colq) * 4u;
-    const unsigned oH = (lrow * (unsigned)g.ldh + (unsigned)colq) * 4u, oD = (lrow * (unsigned)g.ldd + (unsigned)colq) * 4u;
-    const unsigned oA = (lrow * (unsigned)g.ldadd + (unsigned)colq) * 4u;
+    char* const Cu = reinterpret_cast<char*>(C) + (urow0 * g.ldc + ucol0) * ec;
+    char* const C2u = kNeedD ? reinterpret_cast<char*>(C2) + (urow0 * g.ldc2 + ucol0) * ec : nullptr;
+    const char* const Hu = kNeedH ? reinterpret_cast<const char*>(H) + (urow0 * g.ldh + ucol0) * ex : nullptr;
+    const char* const Du = kNeedD ? reinterpret_cast<const char*>(D) + (urow0 * g.ldd + ucol0) * ex : nullptr;
+    const char* const Au = kNeedAdd ? reinterpret_cast<const char*>(Cadd) + (urow0 * g.ldadd + ucol0) * ex : nullptr;
+    const unsigned oC = (lrow * (unsigned)g.ldc + (unsigned)colq) * (unsigned)ec, oC2 = (lrow * (unsigned)g.ldc2 + (unsigned)colq) * (unsigned)ec;
+    const unsigned oH = (lrow * (unsigned)g.ldh + (unsigned)colq) * (unsigned)ex, oD = (lrow * (unsigned)g.ldd + (unsigned)colq) * (unsigned)ex;
+    const unsigned oA = (lrow * (unsigned)g.ldadd + (unsigned)colq) * (unsigned)ex;
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm) {
 #pragma unroll
@@ -163,9 +196,9 @@ static __device__ __forceinline__ void nt_epilogue(const NuGemmNT& g, const NtEp
                     const int i = hb * NB + ii;
                     const long long roff = (long long)(tm * 32 + i * 4);
                     v4[ii] = *reinterpret_cast<const f32x4*>(&scr[(i * 4 + (lane >> 4)) * EPI_LDS + colq]);
-                    if (kNeedH && !slab_plain && !(kMaskR && mwave)) h4[ii] = *reinterpret_cast<const f32x4*>(Hu + roff * g.ldh * 4 + oH);
-                    if (kNeedD && !slab_plain) d4[ii] = *reinterpret_cast<const f32x4*>(Du + roff * g.ldd * 4 + oD);
-                    if (kNeedAdd && !slab_plain) c4v[ii] = *reinterpret_cast<const f32x4*>(Au + roff * g.ldadd * 4 + oA);
+                    if (kNeedH && !slab_plain && !(kMaskR && mwave)) h4[ii] = nt_ld4<H16>(Hu + roff * g.ldh * ex + oH, x16);
+                    if (kNeedD && !slab_plain) d4[ii] = nt_ld4<H16>(Du + roff * g.ldd * ex + oD, x16);
+                    if (kNeedAdd && !slab_plain) c4v[ii] = nt_ld4<H16>(Au + roff * g.ldadd * ex + oA, x16);
                 }
 #pragma unroll
                 for (int ii = 0; ii < NB; ++ii) {
@@ -185,8 +218,8 @@ static __device__ __forceinline__ void nt_epilogue(const NuGemmNT& g, const NtEp
                                                                    (kNeedAdd && !slab_plain) ? c4v[ii][e] : 0.f, o2);
                         o24[e] = o2;
                     }
-                    *reinterpret_cast<f32x4*>(Cu + roff * g.ldc * 4 + oC) = o4;
-                    if (kNeedD) *reinterpret_cast<f32x4*>(C2u + roff * g.ldc2 * 4 + oC2) = o24;
+                    nt_st4<H16>(Cu + roff * g.ldc * ec + oC, o4, c16);
+                    if (kNeedD) nt_st4<H16>(C2u + roff * g.ldc2 * ec + oC2, o24, c16);
                     if (kMaskW && mwave) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
@@ -218,9 +251,9 @@ static __device__ __forceinline__ void nt_epilogue(const NuGemmNT& g, const NtEp
                                 h4[e] = (((lane < 32 ? lo : hi) >> (lane & 31)) & 1u) ? 1.0f : 0.0f;
                             }
                         }
-                    } else if (kNeedH && !plain) h4 = *reinterpret_cast<const f32x4*>(H + (long long)row * g.ldh + gcol);
-                    if (kNeedD && !plain) d4 = *reinterpret_cast<const f32x4*>(D + (long long)row * g.ldd + gcol);
-                    if (kNeedAdd && !plain) c4v = *reinterpret_cast<const f32x4*>(Cadd + (long long)row * g.ldadd + gcol);
+                    } else if (kNeedH && !plain) h4 = nt_ld4<H16>(reinterpret_cast<const char*>(H) + ((long long)row * g.ldh + gcol) * ex, x16);
+                    if (kNeedD && !plain) d4 = nt_ld4<H16>(reinterpret_cast<const char*>(D) + ((long long)row * g.ldd + gcol) * ex, x16);
+                    if (kNeedAdd && !plain) c4v = nt_ld4<H16>(reinterpret_cast<const char*>(Cadd) + ((long long)row * g.ldadd + gcol) * ex, x16);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         float o2;
@@ -228,8 +261,8 @@ static __device__ __forceinline__ void nt_epilogue(const NuGemmNT& g, const NtEp
                         o4[e] = (kNeedH && plain) ? v : nu_epi_apply<EPI>(v, bv[e], h4[e], d4[e], c4v[e], o2);
                         o24[e] = (kNeedH && plain) ? 0.f : o2;
                     }
-                    *reinterpret_cast<f32x4*>(C + (long long)row * g.ldc + gcol) = o4;
-                    if (kNeedD) *reinterpret_cast<f32x4*>(C2 + (long long)row * g.ldc2 + gcol) = o24;
+                    nt_st4<H16>(reinterpret_cast<char*>(C) + ((long long)row * g.ldc + gcol) * ec, o4, c16);
+                    if (kNeedD) nt_st4<H16>(reinterpret_cast<char*>(C2) + ((long long)row * g.ldc2 + gcol) * ec, o24, c16);
                     if (kMaskW) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) pos[e] = o4[e] > 0.f;
@@ -245,14 +278,14 @@ static __device__ __forceinline__ void nt_epilogue(const NuGemmNT& g, const NtEp
                             if (kNeedH && col >= act_cols) {
                                 out = v;
                             } else {
-                                const float h = kNeedH ? H[(long long)row * g.ldh + col] : 0.f;
-                                const float d = kNeedD ? D[(long long)row * g.ldd + col] : 0.f;
-                                const float ca = kNeedAdd ? Cadd[(long long)row * g.ldadd + col] : 0.f;
+                                const float h = kNeedH ? nt_ld1<H16>(H, (long long)row * g.ldh + col, x16) : 0.f;
+                                const float d = kNeedD ? nt_ld1<H16>(D, (long long)row * g.ldd + col, x16) : 0.f;
+                                const float ca = kNeedAdd ? nt_ld1<H16>(Cadd, (long long)row * g.ldadd + col, x16) : 0.f;
                                 out = nu_epi_apply<EPI>(v, bv[e], h, d, ca, out2);
                             }
                         }
-                        C[(long long)row * g.ldc + col] = out;
-                        if (kNeedD) C2[(long long)row * g.ldc2 + col] = out2;
+                        nt_st1<H16>(C, (long long)row * g.ldc + col, out, c16);
+                        if (kNeedD) nt_st1<H16>(C2, (long long)row * g.ldc2 + col, out2, c16);
                     }
                 }
                 }
@@ -740,6 +773,347 @@ __global__ __launch_bounds__(256, 2) void gemm_nt2_kernel(NuGemmNT g) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// NT kernel, bf16 STORAGE (cfg mlp_dtype 'bf16', BASELINE config 4): hidden activations and the weight tables live in HBM as
+// bf16, products on v_mfma_f32_32x32x16_bf16 with fp32 accumulation, epilogue arithmetic in fp32.  At 16x the fp32 MFMA rate
+// these GEMMs are HBM-bound (a 256 -> 256 layer moves 1 KB per point in bf16 against 131 kFLOP), so the design goal is bytes:
+// every [P, 256] activation crosses HBM as 512 B, once.
+//
+// Same tile walk, staging and pipeline as the second-generation fp32 kernel: a 64-deep bf16 chunk of a 128-row operand is
+// byte-for-byte the geometry of a 32-deep fp32 chunk (128 B per row + 16 B pad), so one 16-byte LDS fragment read IS the
+// 8 x bf16 operand of one MFMA (lane (r, h) holds k = 8h .. 8h+7) and a chunk is 4 k-groups of 4 MFMAs.  Operand A may
+// still be fp32 (NU_GEMM_A16 clear: network inputs, buffers that elementwise kernels also touch): it is then fetched as two
+// 16-byte pieces per slot and rounded (RNE) on its way into LDS.  K % 32 == 0; a trailing half chunk is zero-filled.
+// ------------------------------------------------------------------------------------------------
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_nt16_kernel(NuGemmNT g) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * NT2_STAGE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = tid >> 6;
+    const int wr = wid >> 1, wc = wid & 1;
+    const int z = blockIdx.z;
+    const int ntn = (g.N + TBN - 1) / TBN;
+    const int mtiles = (g.M + TBM - 1) / TBM;
+    const int nslots = ((mtiles + 7) / 8) * 8 * ntn;       // slot order: see gemm_nt_kernel
+    const bool a16 = (g.bf16 & NU_GEMM_A16) != 0;
+    const int ea_b = a16 ? 2 : 4;
+    const char* __restrict__ A = reinterpret_cast<const char*>(g.A) + (long long)z * g.sA * ea_b;
+    const char* __restrict__ B = reinterpret_cast<const char*>(g.B) + (long long)z * g.sB * 2;
+    const int c8 = tid & 7;                                 // 16-byte LDS slot = 8 consecutive k
+    const int r0 = tid >> 3;
+    const int nk = (g.K + 63) / 64;
+    const int li = lane & 31, lh = lane >> 5;
+    const int a_off = (wr * 64 + li) * NT_LDS + 4 * lh;     // in floats (16-byte slots), as in the fp32 kernel
+    const int b_off = TBM * NT_LDS + (wc * 64 + li) * NT_LDS + 4 * lh;
+    const int w_off = r0 * NT_LDS + 4 * c8;
+
+    auto slot_tile = [&](int j, int& mt, int& nt) -> bool {
+        const int grp = j / (8 * ntn);
+        const int rem = j - grp * 8 * ntn;
+        nt = rem >> 3;
+        mt = grp * 8 + (rem & 7);
+        return mt < mtiles;
+    };
+    auto next_valid = [&](int j, int& mt, int& nt) -> int {
+        while (j < nslots && !slot_tile(j, mt, nt)) j += gridDim.x;
+        return j;
+    };
+
+    int mt = 0, nt = 0;
+    int j = next_valid(blockIdx.x, mt, nt);
+    if (j >= nslots) return;
+
+    int ld_j = j, ld_kt = 0;                                // loader cursor: next chunk to fetch
+    const char* ap[4];
+    const char* bp[4];
+    f32x4 ra4[4], ra4b[4], rb4[4];
+    bool rz = false;                                        // the chunk in registers is a half chunk and this slot is past K
+    auto set_ptrs = [&](int mt_, int nt_) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int ra = mt_ * TBM + r0 + 32 * i;
+            ra = ra < g.M ? ra : g.M - 1;
+            ap[i] = A + ((long long)ra * g.lda + 8 * c8) * ea_b;
+            bp[i] = B + ((long long)(nt_ * TBN + r0 + 32 * i) * g.ldb + 8 * c8) * 2;
+        }
+    };
+    int ld_koff = 0;                                        // element offset of this thread's slot in the chunk at the cursor
+    auto load_piece = [&](int i) {
+        if (a16) {
+            ra4[i] = *reinterpret_cast<const f32x4*>(ap[i] + (long long)ld_koff * 2);
+        } else {
+            ra4[i] = *reinterpret_cast<const f32x4*>(ap[i] + (long long)ld_koff * 4);
+            ra4b[i] = *reinterpret_cast<const f32x4*>(ap[i] + (long long)ld_koff * 4 + 16);
+        }
+        rb4[i] = *reinterpret_cast<const f32x4*>(bp[i] + (long long)ld_koff * 2);
+    };
+    auto set_koff = [&]() {
+        const int k0 = ld_kt * 64;
+        rz = k0 + 8 * c8 >= g.K;                            // slots past K re-read the chunk's first half (valid memory), zeroed below
+        ld_koff = rz ? k0 - 8 * c8 + 8 * (c8 & 3) : k0;     // = k0 + 8 (c8 - 4) relative to this thread's own slot
+    };
+    auto advance = [&]() {
+        if (ld_j >= nslots) return;
+        if (++ld_kt == nk) {
+            ld_kt = 0;
+            int m2 = 0, n2 = 0;
+            ld_j = next_valid(ld_j + gridDim.x, m2, n2);
+            if (ld_j < nslots) set_ptrs(m2, n2);
+        }
+    };
+    auto write_piece = [&](int st, int i, bool zero) {
+        float* s0 = &smem[st * NT2_STAGE];
+        f32x4 va = ra4[i], vb = rb4[i];
+        if (!a16) {
+            const bf16x4 lo = nu_to_bf16x4(ra4[i]), hi = nu_to_bf16x4(ra4b[i]);
+            const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+            va = __builtin_bit_cast(f32x4, make_uint4(l2.x, l2.y, h2.x, h2.y));
+        }
+        if (zero) { va = f32x4{0.f, 0.f, 0.f, 0.f}; vb = va; }
+        *reinterpret_cast<f32x4*>(&s0[w_off + 32 * i * NT_LDS]) = va;
+        *reinterpret_cast<f32x4*>(&s0[TBM * NT_LDS + w_off + 32 * i * NT_LDS]) = vb;
+    };
+    struct Frag { f32x4 a0, a1, b0, b1; };
+    auto read_frag = [&](Frag& f, int st, int kk) {
+        const float* s0 = &smem[st * NT2_STAGE];
+        f.a0 = *reinterpret_cast<const f32x4*>(&s0[a_off + kk * 8]);
+        f.a1 = *reinterpret_cast<const f32x4*>(&s0[a_off + 32 * NT_LDS + kk * 8]);
+        f.b0 = *reinterpret_cast<const f32x4*>(&s0[b_off + kk * 8]);
+        f.b1 = *reinterpret_cast<const f32x4*>(&s0[b_off + 32 * NT_LDS + kk * 8]);
+    };
+
+    const NtEpiArgs<EPI> ea = nt_epi_args<EPI, true>(g, z);
+    constexpr bool kMaskR = NtEpiArgs<EPI>::kMaskR;
+
+    // ---- prologue: chunk 0 -> stage 0, chunk 1 -> registers, first fragments ----
+    set_ptrs(mt, nt);
+    set_koff();
+    bool wz = rz;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) load_piece(i);
+    advance();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) write_piece(0, i, wz);
+    set_koff();
+    wz = rz;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) load_piece(i);
+    advance();
+    __syncthreads();
+    Frag F0, F1;
+    read_frag(F0, 0, 0);
+    int cur = 0;
+
+    while (true) {
+        const int m0 = mt * TBM, n0 = nt * TBN;
+        unsigned long long* mwave = nt_mask_words<EPI>(ea, g, mt, nt, z, ntn, wid);
+        unsigned long long mword = 0;
+        if (kMaskR && mwave) mword = mwave[lane];
+        const unsigned mlo = (unsigned)mword, mhi = (unsigned)(mword >> 32);
+
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.0f;
+#define NT16_GROUP(F)                                                                                                           \
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, F.a0), __builtin_bit_cast(bf16x8, F.b0), acc[0][0], 0, 0, 0); \
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, F.a0), __builtin_bit_cast(bf16x8, F.b1), acc[0][1], 0, 0, 0); \
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, F.a1), __builtin_bit_cast(bf16x8, F.b0), acc[1][0], 0, 0, 0); \
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, F.a1), __builtin_bit_cast(bf16x8, F.b1), acc[1][1], 0, 0, 0); \
+    __builtin_amdgcn_sched_barrier(0);
+#define NT16_PIN __builtin_amdgcn_sched_barrier(0);
+        // one chunk = 4 k-groups of 4 MFMAs; the next chunk goes registers -> the other stage under k-groups 0-1, the chunk after
+        // that global -> registers under k-group 2; one barrier per chunk; the next chunk's first fragments land under k-group 3
+        for (int kt = 0; kt < nk; ++kt) {
+            NT16_GROUP(F0)
+            read_frag(F1, cur, 1); NT16_PIN
+            write_piece(cur ^ 1, 0, wz); write_piece(cur ^ 1, 1, wz); NT16_PIN
+            NT16_GROUP(F1)
+            read_frag(F0, cur, 2); NT16_PIN
+            write_piece(cur ^ 1, 2, wz); write_piece(cur ^ 1, 3, wz); NT16_PIN
+            NT16_GROUP(F0)
+            read_frag(F1, cur, 3); NT16_PIN
+            set_koff();
+            wz = rz;
+            load_piece(0); load_piece(1); load_piece(2); load_piece(3); NT16_PIN
+            advance();
+            __syncthreads();        // the other stage is complete; every wave holds its last fragments of this one
+            read_frag(F0, cur ^ 1, 0);      // (after the very last chunk: stale bytes, never used)
+            NT16_PIN
+            NT16_GROUP(F1)
+            cur ^= 1;
+        }
+#undef NT16_GROUP
+#undef NT16_PIN
+        // ---- epilogue: the stage consumed last is free until the next chunk's hand-over ----
+        nt_epilogue<EPI, 4, true>(g, ea, acc, &smem[(cur ^ 1) * NT2_STAGE] + wid * (32 * EPI_LDS), m0, n0, mwave, mlo, mhi, lane, wid, false);
+        int mtn = 0, ntnx = 0;
+        const int jn = next_valid(j + gridDim.x, mtn, ntnx);
+        if (jn >= nslots) break;
+        __syncthreads();            // every wave is done with the scratch before the next hand-over writes that stage
+        j = jn; mt = mtn; nt = ntnx;
+    }
+}
+
+// bf16-storage NT kernel, occupancy variant: ONE LDS buffer (36.9 KB), three workgroups per CU, the next chunk prefetched into
+// registers under the MFMAs (the first-generation flow).  With 2 048 MFMA cycles per K = 256 tile the kernel lives on memory
+// latency and the epilogue, which more resident waves hide better than a deeper per-wave pipeline.
+template <int EPI, bool A16>
+__global__ __launch_bounds__(256, 3) void gemm_nt16b_kernel(NuGemmNT g) {
+    __shared__ __attribute__((aligned(16))) float smem[NT2_STAGE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = tid >> 6;
+    const int wr = wid >> 1, wc = wid & 1;
+    const int z = blockIdx.z;
+    const int ntn = (g.N + TBN - 1) / TBN;
+    const int mtiles = (g.M + TBM - 1) / TBM;
+    const int nslots = ((mtiles + 7) / 8) * 8 * ntn;
+    constexpr bool a16 = A16;
+    constexpr int ea_b = a16 ? 2 : 4;
+    const char* __restrict__ A = reinterpret_cast<const char*>(g.A) + (long long)z * g.sA * ea_b;
+    const char* __restrict__ B = reinterpret_cast<const char*>(g.B) + (long long)z * g.sB * 2;
+    const int c8 = tid & 7;
+    const int r0 = tid >> 3;
+    const int nk = (g.K + 63) / 64;
+    const int li = lane & 31, lh = lane >> 5;
+    const int a_off = (wr * 64 + li) * NT_LDS + 4 * lh;
+    const int b_off = TBM * NT_LDS + (wc * 64 + li) * NT_LDS + 4 * lh;
+    const int w_off = r0 * NT_LDS + 4 * c8;
+
+    auto slot_tile = [&](int j, int& mt, int& nt) -> bool {
+        const int grp = j / (8 * ntn);
+        const int rem = j - grp * 8 * ntn;
+        nt = rem >> 3;
+        mt = grp * 8 + (rem & 7);
+        return mt < mtiles;
+    };
+    auto next_valid = [&](int j, int& mt, int& nt) -> int {
+        while (j < nslots && !slot_tile(j, mt, nt)) j += gridDim.x;
+        return j;
+    };
+
+    int mt = 0, nt = 0;
+    int j = next_valid(blockIdx.x, mt, nt);
+    if (j >= nslots) return;
+
+    // addresses: one wave-uniform base per tile (SGPRs) + a 32-bit byte offset per staged row (the row clamp at the M edge
+    // is the only per-tile part), so no 64-bit per-lane pointer lives in VGPRs
+    const char* abase = A;
+    const char* bbase = B;
+    unsigned oa[4], ob[4];
+    f32x4 ra4[4], ra4b[A16 ? 1 : 4], rb4[4];
+    bool rz = false;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ob[i] = ((unsigned)(r0 + 32 * i) * (unsigned)g.ldb + 8u * c8) * 2u;
+    auto set_ptrs = [&](int mt_, int nt_) {
+        const int mtu = __builtin_amdgcn_readfirstlane(mt_), ntu = __builtin_amdgcn_readfirstlane(nt_);
+        abase = A + (long long)mtu * TBM * g.lda * ea_b;
+        bbase = B + (long long)ntu * TBN * g.ldb * 2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int rl = r0 + 32 * i;
+            rl = mtu * TBM + rl < g.M ? rl : g.M - 1 - mtu * TBM;
+            oa[i] = ((unsigned)rl * (unsigned)g.lda + 8u * c8) * (unsigned)ea_b;
+        }
+    };
+    auto load_regs = [&](int kt) {
+        const int k0 = kt * 64;
+        rz = k0 + 8 * c8 >= g.K;                            // half chunk: slots past K re-read the first half, zeroed at the hand-over
+        const unsigned back = rz ? 32u : 0u;
+        const char* ak = abase + (long long)k0 * ea_b;
+        const char* bk = bbase + (long long)k0 * 2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (a16) {
+                ra4[i] = *reinterpret_cast<const f32x4*>(ak + (oa[i] - back * 2u));
+            } else {
+                ra4[i] = *reinterpret_cast<const f32x4*>(ak + (oa[i] - back * 4u));
+                ra4b[i] = *reinterpret_cast<const f32x4*>(ak + (oa[i] - back * 4u) + 16);
+            }
+            rb4[i] = *reinterpret_cast<const f32x4*>(bk + (ob[i] - back * 2u));
+        }
+    };
+    auto store_regs = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f32x4 va = ra4[i], vb = rb4[i];
+            if constexpr (!A16) {
+                const bf16x4 lo = nu_to_bf16x4(ra4[i]), hi = nu_to_bf16x4(ra4b[i]);
+                const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+                va = __builtin_bit_cast(f32x4, make_uint4(l2.x, l2.y, h2.x, h2.y));
+            }
+            if (rz) { va = f32x4{0.f, 0.f, 0.f, 0.f}; vb = va; }
+            *reinterpret_cast<f32x4*>(&smem[w_off + 32 * i * NT_LDS]) = va;
+            *reinterpret_cast<f32x4*>(&smem[TBM * NT_LDS + w_off + 32 * i * NT_LDS]) = vb;
+        }
+    };
+
+    set_ptrs(mt, nt);
+    load_regs(0);
+    store_regs();
+    __syncthreads();
+
+    const NtEpiArgs<EPI> ea = nt_epi_args<EPI, true>(g, z);
+    constexpr bool kMaskR = NtEpiArgs<EPI>::kMaskR;
+
+    while (true) {
+        int mtn = 0, ntnx = 0;
+        const int jn = next_valid(j + gridDim.x, mtn, ntnx);
+        const bool has_next = jn < nslots;
+        const int m0 = mt * TBM, n0 = nt * TBN;
+        unsigned long long* mwave = nt_mask_words<EPI>(ea, g, mt, nt, z, ntn, wid);
+        unsigned long long mword = 0;
+        if (kMaskR && mwave) mword = mwave[lane];
+        const unsigned mlo = (unsigned)mword, mhi = (unsigned)(mword >> 32);
+
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.0f;
+
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) {
+                load_regs(kt + 1);
+            } else if (has_next) {
+                set_ptrs(mtn, ntnx);
+                load_regs(0);
+            }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const bf16x8 a0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(&smem[a_off + kk * 8]));
+                const bf16x8 a1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(&smem[a_off + 32 * NT_LDS + kk * 8]));
+                const bf16x8 b0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(&smem[b_off + kk * 8]));
+                const bf16x8 b1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(&smem[b_off + 32 * NT_LDS + kk * 8]));
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+            }
+            __syncthreads();   // every wave is done reading this chunk (and, after the last one, the scratch is free)
+            if (kt + 1 < nk) {
+                store_regs();
+                __syncthreads();
+            }
+        }
+        nt_epilogue<EPI, 2, true>(g, ea, acc, smem + wid * (32 * EPI_LDS), m0, n0, mwave, mlo, mhi, lane, wid, false);
+        if (!has_next) break;
+        __syncthreads();   // every wave is done with the scratch
+        store_regs();
+        __syncthreads();
+        j = jn; mt = mtn; nt = ntnx;
+    }
+}
+
 int nu_gemm_nt_launch(const NuGemmNT& g, hipStream_t stream) {
     if (g.M <= 0) return NU_OK;
     if (g.N <= 0 || g.K <= 0 || (g.K % TBK) != 0 || g.lda < g.K || g.ldb < g.K) return NU_ERR_ARG;
@@ -762,7 +1136,9 @@ int nu_gemm_nt_launch(const NuGemmNT& g, hipStream_t stream) {
 #else
     static const int grid_env = getenv("NU_NT_GRID") ? atoi(getenv("NU_NT_GRID")) : 0;
 #endif
-    const int grid_target = grid_env ? grid_env : 256 * (g.bf16 == 2 ? 2 : NT_WPC);   // workgroups the build keeps resident
+    const int prec = g.bf16 & 3;
+    if (prec == 3 || ((g.bf16 & ~3) && !(prec == 1 && (g.bf16 & NU_GEMM_B16)))) return NU_ERR_ARG;   // storage flags need the bf16-storage kernel
+    const int grid_target = grid_env ? grid_env : 256 * (prec == 2 ? 2 : NT_WPC);   // workgroups the build keeps resident
     long long per = nu_rup(nu_cdiv(grid_target, groups), 8);
     if (per > nslots) per = nslots;
     dim3 grid((unsigned)per, 1, groups), block(256);
@@ -771,7 +1147,31 @@ int nu_gemm_nt_launch(const NuGemmNT& g, hipStream_t stream) {
 #ifdef NU_LAB
     v1 = nu_lab_v1 != 0;
 #endif
-    if (g.bf16 == 0 && !v1) {
+    if (prec == 1 && (g.bf16 & NU_GEMM_B16)) {          // bf16 storage
+        if ((g.ldb & 7) || ((g.bf16 & NU_GEMM_A16) && (g.lda & 7))) return NU_ERR_ARG;
+        static const int v16 = getenv("NU_NT16_V") ? atoi(getenv("NU_NT16_V")) : 2;     // development switch: 1 = pipelined, 2 = occupancy
+        long long per2 = nu_rup(nu_cdiv(grid_env ? grid_env : (v16 == 2 ? 768 : 512), groups), 8);
+        if (per2 > nslots) per2 = nslots;
+        dim3 grid2((unsigned)per2, 1, groups);
+        switch (g.epi) {
+#define NU_CASE16(E) case E: if (v16 == 2 && (g.bf16 & NU_GEMM_A16)) hipLaunchKernelGGL((gemm_nt16b_kernel<E, true>), grid2, block, 0, stream, g); \
+                             else if (v16 == 2) hipLaunchKernelGGL((gemm_nt16b_kernel<E, false>), grid2, block, 0, stream, g); \
+                             else hipLaunchKernelGGL((gemm_nt16_kernel<E>), grid2, block, 0, stream, g); break;
+            NU_CASE16(NU_EPI_BIAS_NONE)
+            NU_CASE16(NU_EPI_BIAS_RELU)
+            NU_CASE16(NU_EPI_BIAS_SOFTPLUS)
+            NU_CASE16(NU_EPI_MUL_DRELU)
+            NU_CASE16(NU_EPI_MUL_DSP)
+            NU_CASE16(NU_EPI_Q_SP)
+            NU_CASE16(NU_EPI_B_SP)
+            NU_CASE16(NU_EPI_PLAIN)
+            NU_CASE16(NU_EPI_B_RELU)
+#undef NU_CASE16
+            default: return NU_ERR_ARG;
+        }
+        return nu_launch_status();
+    }
+    if (prec == 0 && !v1) {
         long long per2 = nu_rup(nu_cdiv(grid_env ? grid_env : 512, groups), 8);       // two workgroups per CU
         if (per2 > nslots) per2 = nslots;
         dim3 grid2((unsigned)per2, 1, groups);
@@ -792,8 +1192,8 @@ int nu_gemm_nt_launch(const NuGemmNT& g, hipStream_t stream) {
         return nu_launch_status();
     }
     switch (g.epi) {
-#define NU_CASE(E) case E: if (g.bf16 == 2) hipLaunchKernelGGL((gemm_nt_kernel<E, 2>), grid, block, 0, stream, g); \
-                           else if (g.bf16 == 1) hipLaunchKernelGGL((gemm_nt_kernel<E, 1>), grid, block, 0, stream, g); \
+#define NU_CASE(E) case E: if (prec == 2) hipLaunchKernelGGL((gemm_nt_kernel<E, 2>), grid, block, 0, stream, g); \
+                           else if (prec == 1) hipLaunchKernelGGL((gemm_nt_kernel<E, 1>), grid, block, 0, stream, g); \
                            else hipLaunchKernelGGL((gemm_nt_kernel<E, 0>), grid, block, 0, stream, g); break;
         NU_CASE(NU_EPI_BIAS_NONE)
         NU_CASE(NU_EPI_BIAS_RELU)
@@ -870,8 +1270,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(NuGemmTN g) {
     auto load_tile = [&](int t) {
         const int pair = t >= ntile ? 1 : 0;
         const int kt = t - pair * ntile;
-        const char* __restrict__ A = (const char*)(pair ? g.A1 + (long long)grp * g.sA1 : g.A0 + (long long)grp * g.sA0);
-        const char* __restrict__ B = (const char*)(pair ? g.B1 + (long long)grp * g.sB1 : g.B0 + (long long)grp * g.sB0);
+        // bf16-stored operands (mode 1 only; flags per operand): 2-byte elements, widened exactly on load
+        const bool a16 = BF16 && (g.bf16 & (pair ? NU_TN_A1_16 : NU_TN_A0_16)) != 0;
+        const bool b16 = BF16 && (g.bf16 & (pair ? NU_TN_B1_16 : NU_TN_B0_16)) != 0;
+        const unsigned eA = a16 ? 2u : 4u, eB = b16 ? 2u : 4u;
+        const char* __restrict__ A = (const char*)(pair ? g.A1 : g.A0) + (long long)grp * (pair ? g.sA1 : g.sA0) * eA;
+        const char* __restrict__ B = (const char*)(pair ? g.B1 : g.B0) + (long long)grp * (pair ? g.sB1 : g.sB0) * eB;
         const int lda = pair ? g.lda1 : g.lda0;
         const int ldb = pair ? g.ldb1 : g.ldb0;
         int ca = n1_0 + c, cb = n2_0 + c;
@@ -886,15 +1290,17 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(NuGemmTN g) {
             for (int e = 0; e < 4; ++e) {
                 int pr = pbase + 4 * i + e;
                 pr = pr < p_end ? pr : p_end - 1;   // ragged tail: re-read the last row, zeroed at the hand-over
+                const char* pa;
+                const char* pb;
                 if (BIG) {
-                    ra4[i][e] = reinterpret_cast<const float*>(A)[(long long)pr * lda + ca];
-                    rb4[i][e] = reinterpret_cast<const float*>(B)[(long long)pr * ldb + cb];
+                    pa = A + ((long long)pr * lda + ca) * eA;
+                    pb = B + ((long long)pr * ldb + cb) * eB;
                 } else {
-                    const unsigned oa = ((unsigned)pr * (unsigned)lda + (unsigned)ca) * 4u;
-                    const unsigned ob = ((unsigned)pr * (unsigned)ldb + (unsigned)cb) * 4u;
-                    ra4[i][e] = *reinterpret_cast<const float*>(A + oa);
-                    rb4[i][e] = *reinterpret_cast<const float*>(B + ob);
+                    pa = A + ((unsigned)pr * (unsigned)lda + (unsigned)ca) * eA;
+                    pb = B + ((unsigned)pr * (unsigned)ldb + (unsigned)cb) * eB;
                 }
+                ra4[i][e] = a16 ? __uint_as_float((unsigned)*reinterpret_cast<const unsigned short*>(pa) << 16) : *reinterpret_cast<const float*>(pa);
+                rb4[i][e] = b16 ? __uint_as_float((unsigned)*reinterpret_cast<const unsigned short*>(pb) << 16) : *reinterpret_cast<const float*>(pb);
             }
     };
     auto store_tile = [&]() {
@@ -1028,6 +1434,185 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(NuGemmTN g) {
         red[kg * 128 + c] = bs;
         __syncthreads();
         if (tid < 128) g.bias_slab[(long long)grp * g.sBiasSlab + (long long)split * N1p + n1_0 + tid] = red[tid] + red[128 + tid];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// TN kernel, bf16 arithmetic (mode 1), operands stored as bf16 or fp32 per flag.  The first-generation mode-1 kernel above
+// fetches one scalar per lane and transposes on the way into LDS; with 2-byte elements that is 4x slower than with floats
+// (measured: the load instruction count stays, the bytes per instruction halve).  Here each lane fetches 16 bytes of ONE row
+// (8 bf16 columns, or 2 x 16 bytes of fp32 rounded on the way in), the LDS image stays row-major [p][128 columns] and the
+// MFMA operands -- 8 consecutive p of one column per lane -- come out of it through ds_read_b64_tr_b16, the hardware
+// transposed read: per 16-lane group a 4 (p) x 16 (column) block, lane 4q + c supplying the address of row q, columns
+// 4c .. 4c+3.  Rows are 320 bytes (256 + 64 pad) so the four rows of a block sit 16 banks apart: conflict-free reads.
+// 20 KB of LDS, chunk = 32 reduced rows (two MFMA k-steps), next chunk in registers under the MFMAs.
+// ------------------------------------------------------------------------------------------------
+#define TN16_ROWB 320
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+static __device__ __forceinline__ bf16x8 tn16_frag(const char* p) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + 4 * TN16_ROWB));
+    return __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+__global__ __launch_bounds__(256, 3) void gemm_tn16_kernel(NuGemmTN g) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * TBK * TN16_ROWB];
+    char* const sA = smem;
+    char* const sB = smem + TBK * TN16_ROWB;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = tid >> 6;
+    const int wr = wid >> 1, wc = wid & 1;
+    const int t2 = (g.N2 + 127) / 128;
+    const int n1t = blockIdx.x / t2, n2t = blockIdx.x - n1t * t2;
+    const int split = blockIdx.y;
+    const int n1_0 = n1t * 128, n2_0 = n2t * 128;
+    const int grp = blockIdx.z;
+    const int N1p = ((g.N1 + 127) / 128) * 128, N2p = t2 * 128;
+
+    int rows_per = (g.P + g.S - 1) / g.S;
+    rows_per = ((rows_per + TBK - 1) / TBK) * TBK;
+    const int p_begin = split * rows_per;
+    int p_end = p_begin + rows_per;
+    p_end = p_end < g.P ? p_end : g.P;
+    const int ntile = p_end > p_begin ? (p_end - p_begin + TBK - 1) / TBK : 0;
+    const int npair = g.A1 ? 2 : 1;
+    const int total = ntile * npair;
+
+    const int cg = tid & 15;        // 8-column group of the 128-wide operand tile
+    const int rr = tid >> 4;        // row inside a 16-row pass
+    const bool do_bias = (g.bias_slab != nullptr) && (n2t == 0);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    uint4 ra[2][2], rb[2][2];       // [pass][half]: a bf16 operand uses half 0 only
+    int nvalid = 0;                 // rows of the pending chunk that exist (ragged tail of the last split)
+    bool pend_pair0 = true, pa16 = false, pb16 = false;
+    float bs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto load_tile = [&](int t) {
+        const int pair = t >= ntile ? 1 : 0;
+        const int kt = t - pair * ntile;
+        const bool a16 = (g.bf16 & (pair ? NU_TN_A1_16 : NU_TN_A0_16)) != 0;
+        const bool b16 = (g.bf16 & (pair ? NU_TN_B1_16 : NU_TN_B0_16)) != 0;
+        const int eA = a16 ? 2 : 4, eB = b16 ? 2 : 4;
+        const char* __restrict__ A = (const char*)(pair ? g.A1 : g.A0) + (long long)grp * (pair ? g.sA1 : g.sA0) * eA;
+        const char* __restrict__ B = (const char*)(pair ? g.B1 : g.B0) + (long long)grp * (pair ? g.sB1 : g.sB0) * eB;
+        const int lda = pair ? g.lda1 : g.lda0;
+        const int ldb = pair ? g.ldb1 : g.ldb0;
+        int ca = n1_0 + 8 * cg, cb = n2_0 + 8 * cg;
+        ca = ca <= lda - 8 ? ca : lda - 8;      // column groups past the operand only feed slab rows the reducer never reads
+        cb = cb <= ldb - 8 ? cb : ldb - 8;
+        const int pbase = p_begin + kt * TBK;
+        nvalid = p_end - pbase;
+        pend_pair0 = pair == 0;
+        pa16 = a16; pb16 = b16;
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            int pr = pbase + rr + 16 * ps;
+            pr = pr < p_end ? pr : p_end - 1;   // ragged tail: re-read the last row, zeroed at the hand-over
+            const char* pa = A + ((long long)pr * lda + ca) * eA;
+            const char* pb = B + ((long long)pr * ldb + cb) * eB;
+            ra[ps][0] = *reinterpret_cast<const uint4*>(pa);
+            if (!a16) ra[ps][1] = *reinterpret_cast<const uint4*>(pa + 16);
+            rb[ps][0] = *reinterpret_cast<const uint4*>(pb);
+            if (!b16) rb[ps][1] = *reinterpret_cast<const uint4*>(pb + 16);
+        }
+    };
+    auto pack8 = [](uint4 lo, uint4 hi) -> uint4 {       // 8 fp32 -> 8 bf16 (RNE)
+        const bf16x4 l = nu_to_bf16x4(__builtin_bit_cast(f32x4, lo)), h = nu_to_bf16x4(__builtin_bit_cast(f32x4, hi));
+        const uint2 l2 = __builtin_bit_cast(uint2, l), h2 = __builtin_bit_cast(uint2, h);
+        return make_uint4(l2.x, l2.y, h2.x, h2.y);
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            const bool ok = rr + 16 * ps < nvalid;
+            uint4 va = pa16 ? ra[ps][0] : pack8(ra[ps][0], ra[ps][1]);
+            uint4 vb = pb16 ? rb[ps][0] : pack8(rb[ps][0], rb[ps][1]);
+            if (do_bias && pend_pair0 && ok) {           // column sums of the operand as stored (fp32 operands: unrounded)
+                if (pa16) {
+                    const unsigned w[4] = {ra[ps][0].x, ra[ps][0].y, ra[ps][0].z, ra[ps][0].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        bs[2 * e] += __uint_as_float(w[e] << 16);
+                        bs[2 * e + 1] += __uint_as_float(w[e] & 0xffff0000u);
+                    }
+                } else {
+                    const f32x4 l = __builtin_bit_cast(f32x4, ra[ps][0]), h = __builtin_bit_cast(f32x4, ra[ps][1]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { bs[e] += l[e]; bs[4 + e] += h[e]; }
+                }
+            }
+            if (!ok) { va = make_uint4(0u, 0u, 0u, 0u); vb = va; }
+            *reinterpret_cast<uint4*>(sA + (rr + 16 * ps) * TN16_ROWB + cg * 16) = va;
+            *reinterpret_cast<uint4*>(sB + (rr + 16 * ps) * TN16_ROWB + cg * 16) = vb;
+        }
+    };
+
+    if (total > 0) {
+        load_tile(0);
+        store_tile();
+    }
+    __syncthreads();
+
+    const int li = lane & 31, lh = lane >> 5;
+    const int g4 = lane >> 4, tq = (lane & 15) >> 2, tc = lane & 3;
+    // transposed-read address of this lane: row 8 (g4 >> 1) + q of the k-step, columns 16 (g4 & 1) + 4 c of the 32-column tile
+    const int a_off = (8 * (g4 >> 1) + tq) * TN16_ROWB + (wr * 64 + 16 * (g4 & 1) + 4 * tc) * 2;
+    const int b_off = (8 * (g4 >> 1) + tq) * TN16_ROWB + (wc * 64 + 16 * (g4 & 1) + 4 * tc) * 2;
+    for (int t = 0; t < total; ++t) {
+        if (t + 1 < total) load_tile(t + 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const bf16x8 a0 = tn16_frag(sA + a_off + ks * 16 * TN16_ROWB);
+            const bf16x8 a1 = tn16_frag(sA + a_off + ks * 16 * TN16_ROWB + 64);
+            const bf16x8 b0 = tn16_frag(sB + b_off + ks * 16 * TN16_ROWB);
+            const bf16x8 b1 = tn16_frag(sB + b_off + ks * 16 * TN16_ROWB + 64);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        __syncthreads();
+        if (t + 1 < total) {
+            store_tile();
+            __syncthreads();
+        }
+    }
+
+    float* __restrict__ slab = g.slab + (long long)grp * g.sSlab + (long long)split * N1p * N2p;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+            const int col = n2_0 + wc * 64 + tn * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = n1_0 + wr * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                slab[(long long)row * N2p + col] = acc[tm][tn][r];
+            }
+        }
+
+    if (do_bias) {                  // 16 row-threads hold partial sums of the same 8 columns
+        float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[rr * 128 + 8 * cg + e] = bs[e];
+        __syncthreads();
+        if (tid < 128) {
+            float sum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sum += red[r * 128 + tid];
+            g.bias_slab[(long long)grp * g.sBiasSlab + (long long)split * N1p + n1_0 + tid] = sum;
+        }
     }
 }
 
@@ -1198,6 +1783,8 @@ int nu_gemm_tn_launch(const NuGemmTN& g, hipStream_t stream) {
     if (g.N1 <= 0 || g.N2 <= 0 || g.S <= 0) return NU_ERR_ARG;
     if ((g.lda0 & 3) || (g.ldb0 & 3) || (g.A1 && ((g.lda1 & 3) || (g.ldb1 & 3)))) return NU_ERR_ARG;
     static const bool tn128_env = getenv("NU_TN_128") && atoi(getenv("NU_TN_128")) != 0;      // development switch: 128 x 128 tiles only
+    const int prec = g.bf16 & 3;
+    if (prec == 3 || ((g.bf16 & ~3) && prec != 1)) return NU_ERR_ARG;
     if ((g.bf16 & 3) == 0 && !tn128_env && (g.N1 % 256) == 0 && (g.N2 % 256) == 0) {
         dim3 grid2((g.N1 / 256) * (g.N2 / 256), g.S, g.groups > 0 ? g.groups : 1);
         const long long mld = (g.lda0 > g.ldb0 ? g.lda0 : g.ldb0) > (g.A1 ? (g.lda1 > g.ldb1 ? g.lda1 : g.ldb1) : 0)
@@ -1210,13 +1797,25 @@ int nu_gemm_tn_launch(const NuGemmTN& g, hipStream_t stream) {
     const long long max_ld = (g.lda0 > g.ldb0 ? g.lda0 : g.ldb0) > (g.A1 ? (g.lda1 > g.ldb1 ? g.lda1 : g.ldb1) : 0)
                                  ? (g.lda0 > g.ldb0 ? g.lda0 : g.ldb0) : (g.lda1 > g.ldb1 ? g.lda1 : g.ldb1);
     const bool big = (long long)g.P * max_ld * 4 >= (1LL << 32);
+    if (prec == 1) {
+        // vector-load kernel: 16-byte aligned operands, rows of 8 or more elements (bf16 rows: a multiple of 8)
+        auto ok = [](const float* p, int ld, bool h) { return p == nullptr || ((((uintptr_t)p) & 15) == 0 && ld >= 8 && (!h || (ld & 7) == 0)); };
+        const bool vec = ok(g.A0, g.lda0, g.bf16 & NU_TN_A0_16) && ok(g.B0, g.ldb0, g.bf16 & NU_TN_B0_16) &&
+                         ok(g.A1, g.lda1, g.bf16 & NU_TN_A1_16) && ok(g.B1, g.ldb1, g.bf16 & NU_TN_B1_16) &&
+                         ((g.sA0 | g.sB0 | g.sA1 | g.sB1) & 7) == 0;
+        static const bool tn_scalar_env = getenv("NU_TN_SCALAR") && atoi(getenv("NU_TN_SCALAR")) != 0;      // development switch
+        if (vec && !tn_scalar_env) {
+            hipLaunchKernelGGL(gemm_tn16_kernel, grid, block, 0, stream, g);
+            return nu_launch_status();
+        }
+    }
     if (big) {
-        if (g.bf16 == 2) hipLaunchKernelGGL((gemm_tn_kernel<true, 2>), grid, block, 0, stream, g);
-        else if (g.bf16 == 1) hipLaunchKernelGGL((gemm_tn_kernel<true, 1>), grid, block, 0, stream, g);
+        if (prec == 2) hipLaunchKernelGGL((gemm_tn_kernel<true, 2>), grid, block, 0, stream, g);
+        else if (prec == 1) hipLaunchKernelGGL((gemm_tn_kernel<true, 1>), grid, block, 0, stream, g);
         else hipLaunchKernelGGL((gemm_tn_kernel<true, 0>), grid, block, 0, stream, g);
     } else {
-        if (g.bf16 == 2) hipLaunchKernelGGL((gemm_tn_kernel<false, 2>), grid, block, 0, stream, g);
-        else if (g.bf16 == 1) hipLaunchKernelGGL((gemm_tn_kernel<false, 1>), grid, block, 0, stream, g);
+        if (prec == 2) hipLaunchKernelGGL((gemm_tn_kernel<false, 2>), grid, block, 0, stream, g);
+        else if (prec == 1) hipLaunchKernelGGL((gemm_tn_kernel<false, 1>), grid, block, 0, stream, g);
         else hipLaunchKernelGGL((gemm_tn_kernel<false, 0>), grid, block, 0, stream, g);
     }
     return nu_launch_status();

@@ -51,35 +51,79 @@ static int ctx_take(NuOpCtx* c, long long nbytes, int ndesc_needed, hipStream_t 
     return NU_OK;
 }
 
+// storage flags of one launch under NuOpCtx.h16 (ignored otherwise): which of A, {C, C2}, {H, D, Cadd} are bf16
+#define A16 NU_GEMM_A16
+#define C16 NU_GEMM_C16
+#define X16 NU_GEMM_X16
+typedef unsigned short h16_t;
+static inline const float* w16(const void* tbl, long long elem_off) { return reinterpret_cast<const float*>(static_cast<const h16_t*>(tbl) + elem_off); }
+
+static void ev_begin(NuOpCtx* c, hipStream_t stream) {
+    if (c->ev && c->nev + 2 <= c->ev_cap) (void)hipEventRecord(static_cast<hipEvent_t>(c->ev[c->nev]), stream);
+}
+static void ev_end(NuOpCtx* c, hipStream_t stream, double kind, double flops, double bytes) {
+    if (c->ev && c->nev + 2 <= c->ev_cap) {
+        (void)hipEventRecord(static_cast<hipEvent_t>(c->ev[c->nev + 1]), stream);
+        double* m = c->ev_meta + 3 * (c->nev / 2);
+        m[0] = kind; m[1] = flops; m[2] = bytes;
+        c->nev += 2;
+    }
+}
+
 struct NtArgs {
     const float* A; int lda; const float* B; int ldb; int M, N, K; float* C; int ldc; int epi;
     float* C2 = nullptr; int ldc2 = 0; const float* bias = nullptr; const float* H = nullptr; int ldh = 0; const float* D = nullptr;
     int ldd = 0; const float* Cadd = nullptr; int ldadd = 0; int zero_to = 0; int act_cols = 0; int groups = 1;
     long long sA = 0, sB = 0, sC = 0, sBias = 0, sH = 0; unsigned long long* mask = nullptr; int mask_nct = 0;
+    const float* B16 = nullptr;     // the bf16 copy of B (h16)
+    int st = 0;                     // A16 | C16 | X16 (h16)
+    int ktrue = 0;                  // unpadded reduction extent (roofline accounting only)
 };
-static int nt(const NuOpCtx* c, const NtArgs& a, hipStream_t stream) {
+static int nt(NuOpCtx* c, const NtArgs& a, hipStream_t stream) {
     if (a.M <= 0) return NU_OK;
+    const bool h16 = c->h16 != 0;
+    if (h16 && (c->prec != 1 || a.B16 == nullptr)) return NU_ERR_ARG;
     NuGemmNT g = {};
-    g.A = a.A; g.lda = a.lda; g.B = a.B; g.ldb = a.ldb; g.M = a.M; g.N = a.N; g.K = a.K; g.C = a.C; g.ldc = a.ldc; g.C2 = a.C2;
+    g.A = a.A; g.lda = a.lda; g.B = h16 ? a.B16 : a.B; g.ldb = a.ldb; g.M = a.M; g.N = a.N; g.K = a.K; g.C = a.C; g.ldc = a.ldc; g.C2 = a.C2;
     g.ldc2 = a.ldc2; g.bias = a.bias; g.H = a.H; g.ldh = a.ldh; g.D = a.D; g.ldd = a.ldd; g.Cadd = a.Cadd; g.ldadd = a.ldadd;
     g.zero_to = a.zero_to; g.act_cols = a.act_cols; g.alpha = 1.0f; g.groups = a.groups; g.sA = a.sA; g.sB = a.sB; g.sC = a.sC;
-    g.sBias = a.sBias; g.sH = a.sH; g.epi = a.epi; g.bf16 = c->prec; g.mask = a.mask; g.mask_nct = a.mask ? a.mask_nct : 0;
-    return nu_gemm_nt_launch(g, stream);
+    g.sBias = a.sBias; g.sH = a.sH; g.epi = a.epi; g.bf16 = h16 ? (1 | NU_GEMM_B16 | a.st) : c->prec; g.mask = a.mask;
+    g.mask_nct = a.mask ? a.mask_nct : 0;
+    ev_begin(c, stream);
+    const int rc = nu_gemm_nt_launch(g, stream);
+    if (c->ev) {
+        const double eA = h16 && (a.st & A16) ? 2 : 4, eB = h16 ? 2 : 4, eC = h16 && (a.st & C16) ? 2 : 4, eX = h16 && (a.st & X16) ? 2 : 4;
+        const bool mask_r = a.mask && (a.epi == NU_EPI_MUL_DRELU || a.epi == NU_EPI_B_RELU);      // sign bits replace H
+        const double K = a.ktrue ? a.ktrue : a.K, M = a.M, N = a.N;
+        const double bytes = a.groups * (M * K * eA + N * K * eB + M * N * (eC * (1 + (a.C2 ? 1 : 0)) +
+                                         eX * ((a.H && !mask_r ? 1 : 0) + (a.D ? 1 : 0) + (a.Cadd ? 1 : 0))));
+        ev_end(c, stream, 0.0, 2.0 * M * N * K * a.groups, bytes);
+    }
+    return rc;
 }
 
-// dW[N1, N2] = A0^T B0 (+ A1^T B1), db = column sums of A0; split: nu_wgrad_pick_split
+// dW[N1, N2] = A0^T B0 (+ A1^T B1), db = column sums of A0; split: nu_wgrad_pick_split.  st16: NU_TN_*_16 flags (h16)
 static int wgrad(NuOpCtx* c, const float* A0, int lda0, const float* B0, int ldb0, int P, int N1, int N2, float* dW, int ldw, float* db,
-                 hipStream_t stream, const float* A1 = nullptr, int lda1 = 0, const float* B1 = nullptr, int ldb1 = 0, int groups = 1,
-                 long long sA0 = 0, long long sB0 = 0, long long sW = 0, long long sDb = 0) {
+                 hipStream_t stream, int st16 = 0, const float* A1 = nullptr, int lda1 = 0, const float* B1 = nullptr, int ldb1 = 0,
+                 int groups = 1, long long sA0 = 0, long long sB0 = 0, long long sW = 0, long long sDb = 0) {
     if (P <= 0) return NU_OK;
     const int S = nu_wgrad_pick_split(P, N1, N2, groups, c->prec);
     float* ws;
     long long nb;
     CHK(ctx_take(c, nu_wgrad_workspace_bytes(N1, N2, S, groups), 2 * groups, stream, &ws, &nb));
+    const int st = c->h16 ? st16 : 0;
     NuGemmTN g = {};
     g.A0 = A0; g.lda0 = lda0; g.B0 = B0; g.ldb0 = ldb0; g.A1 = A1; g.lda1 = lda1; g.B1 = B1; g.ldb1 = ldb1; g.P = P; g.N1 = N1;
-    g.N2 = N2; g.S = S; g.groups = groups; g.sA0 = sA0; g.sB0 = sB0; g.bf16 = c->prec;
-    return nu_wgrad_enqueue(&g, dW, ldw, sW, db, sDb, ws, nb, c->descs, &c->ndesc, c->cap, stream);
+    g.N2 = N2; g.S = S; g.groups = groups; g.sA0 = sA0; g.sB0 = sB0; g.bf16 = c->prec | st;
+    ev_begin(c, stream);
+    const int rc = nu_wgrad_enqueue(&g, dW, ldw, sW, db, sDb, ws, nb, c->descs, &c->ndesc, c->cap, stream);
+    if (c->ev) {
+        const double p = P, n1 = N1, n2 = N2;
+        double bytes = p * (n1 * (st & NU_TN_A0_16 ? 2 : 4) + n2 * (st & NU_TN_B0_16 ? 2 : 4)) + 4.0 * n1 * n2;
+        if (A1) bytes += p * (n1 * (st & NU_TN_A1_16 ? 2 : 4) + n2 * (st & NU_TN_B1_16 ? 2 : 4));
+        ev_end(c, stream, 1.0, 2.0 * p * n1 * n2 * groups * (A1 ? 2 : 1), bytes * groups);
+    }
+    return rc;
 }
 
 static int skinny_bwd(NuOpCtx* c, const float* dy, int ldy, const float* H, int ldh, int P, int K, const float* Ws, int ldw, int NO,
@@ -98,6 +142,10 @@ static int skinny_bwd(NuOpCtx* c, const float* dy, int ldy, const float* H, int 
 extern "C" int nu_sdf_net_size(void) { return (int)sizeof(NuSdfNet); }
 extern "C" int nu_sdf_bufs_size(void) { return (int)sizeof(NuSdfBufs); }
 
+// bf16-storage rule (NuOpCtx.h16; include/nu_nerf.h): buffers that an elementwise kernel also touches stay fp32
+static inline bool sdfH16(int l) { return l == 1 || l == 2 || l == 3 || l == 5 || l == 6 || l == 7; }   // H[l], Q[l]
+static inline bool sdfD16(int l) { return l == 0 || l == 1 || l == 2 || l == 4 || l == 5 || l == 6; }   // D[l], C[l], Aux[l]
+
 extern "C" int nu_sdf_mlp_fwd(NuOpCtx* c, const NuSdfNet* net, const float* X, int x_ld, NuSdfBufs* a, int want_feat,
                               hipStream_t stream) {
     const int P = a->P;
@@ -108,7 +156,8 @@ extern "C" int nu_sdf_mlp_fwd(NuOpCtx* c, const NuSdfNet* net, const float* X, i
     for (int l = 0; l < 8; ++l) {
         const NuLin& L = net->lin[l];
         NtArgs g = {src, lds, L.Wp, L.Kp, P, L.N, K, a->H[l + 1], 256, NU_EPI_BIAS_SOFTPLUS};
-        g.bias = L.bias; g.zero_to = L.N;
+        g.bias = L.bias; g.zero_to = L.N; g.ktrue = L.K;
+        g.B16 = w16(L.Wp16, 0); g.st = (sdfH16(l) ? A16 : 0) | (sdfH16(l + 1) ? C16 : 0);
         CHK(nt(c, g, stream));
         src = a->H[l + 1]; lds = 256; K = 256;
     }
@@ -116,7 +165,7 @@ extern "C" int nu_sdf_mlp_fwd(NuOpCtx* c, const NuSdfNet* net, const float* X, i
     if (want_feat) {     // row 0 = sdf (skinny), rows 1..256 = feature
         CHK(nu_skinny_fwd(a->H[8], 256, P, 256, L8.Wp, 256, L8.bias, 1, a->YX, 288, stream));
         NtArgs g = {a->H[8], 256, L8.Wp + 256, 256, P, 256, 256, a->YX + 1, 288, NU_EPI_BIAS_NONE};
-        g.bias = L8.bias + 1;
+        g.bias = L8.bias + 1; g.B16 = w16(L8.Wp16, 256);
         CHK(nt(c, g, stream));
     } else {
         CHK(nu_skinny_fwd(a->H[8], 256, P, 256, L8.Wp, 256, L8.bias, 1, a->sdf, 1, stream));
@@ -136,10 +185,11 @@ extern "C" int nu_sdf_mlp_normal(NuOpCtx* c, const NuSdfNet* net, NuSdfBufs* a, 
         g.H = a->H[l]; g.ldh = 256;
         if (l == 4) g.act_cols = 217;      // columns 217..255 are the skip gradient w.r.t. the embedding: written plain
         else g.zero_to = 256;
+        g.B16 = w16(ls[l].WpT16, 0); g.st = (sdfD16(l) ? A16 : 0) | (sdfD16(l - 1) ? C16 : 0) | (sdfH16(l) ? X16 : 0);
         CHK(nt(c, g, stream));
     }
     NtArgs g0 = {a->D[0], 256, ls[0].WpT, ls[0].ldT, P, 39, 256, a->G0, 64, NU_EPI_PLAIN};
-    g0.zero_to = 64;
+    g0.zero_to = 64; g0.B16 = w16(ls[0].WpT16, 0); g0.st = A16;
     CHK(nt(c, g0, stream));
     return nu_embed_jt(a->E, a->G0, 64, a->D[3] + 217, 256, P, a->n, stream);
 }
@@ -158,6 +208,8 @@ extern "C" int nu_sdf_mlp_bwd(NuOpCtx* c, const NuSdfNet* net, NuSdfBufs* a, con
         for (int l = 0; l < 8; ++l) {
             NtArgs g = {src, lds, ls[l].Wp, ls[l].Kp, P, ls[l].N, K, a->Q[l + 1], 256, NU_EPI_Q_SP};
             g.C2 = a->C[l]; g.ldc2 = 256; g.H = a->H[l + 1]; g.ldh = 256; g.D = a->D[l]; g.ldd = 256; g.zero_to = l == 3 ? ls[l].N : 256;
+            // Q[l + 1] and C[l] share the output flag, H[l + 1] and D[l] the auxiliary flag: the rule makes each pair one dtype
+            g.B16 = w16(ls[l].Wp16, 0); g.st = (sdfH16(l) ? A16 : 0) | (sdfH16(l + 1) ? C16 | X16 : 0);
             CHK(nt(c, g, stream));
             src = a->Q[l + 1]; lds = 256; K = 256;
         }
@@ -165,22 +217,24 @@ extern "C" int nu_sdf_mlp_bwd(NuOpCtx* c, const NuSdfNet* net, NuSdfBufs* a, con
     // B sweep: abar_l (written over C_l when second order)
     float* A[8];
     for (int l = 7; l >= 0; --l) {
-        const float* srcA; int lda, K; const float* WT; int ldT;
-        if (l == 7) { srcA = dYX; lda = 288; K = 288; WT = ls[8].WpT; ldT = ls[8].ldT; }
-        else { srcA = A[l + 1]; lda = 256; K = rup_i(ls[l + 1].N, 32); WT = ls[l + 1].WpT; ldT = ls[l + 1].ldT; }
+        const float* srcA; int lda, K; const float* WT; const float* WT16; int ldT;
+        if (l == 7) { srcA = dYX; lda = 288; K = 288; WT = ls[8].WpT; WT16 = w16(ls[8].WpT16, 0); ldT = ls[8].ldT; }
+        else { srcA = A[l + 1]; lda = 256; K = rup_i(ls[l + 1].N, 32); WT = ls[l + 1].WpT; WT16 = w16(ls[l + 1].WpT16, 0); ldT = ls[l + 1].ldT; }
         A[l] = second ? a->C[l] : a->Aux[l];
         NtArgs g = {srcA, lda, WT, ldT, P, ls[l].N, K, A[l], 256, second ? NU_EPI_B_SP : NU_EPI_MUL_DSP};
         g.H = a->H[l + 1]; g.ldh = 256; g.Cadd = second ? a->C[l] : nullptr; g.ldadd = 256;
         if (l == 3 && dx != nullptr) { g.N = 256; g.act_cols = 217; }     // keep the plain skip columns 217..255
         else g.zero_to = 256;
+        g.B16 = WT16; g.st = ((l < 7 && sdfD16(l + 1)) ? A16 : 0) | (sdfD16(l) ? C16 | X16 : 0);
         CHK(nt(c, g, stream));
     }
     for (int l = 0; l < 8; ++l) {
         const float* u = l == 0 ? a->E : a->H[l];
         const int ldu = l == 0 ? 64 : 256;
-        if (second) CHK(wgrad(c, A[l], 256, u, ldu, P, ls[l].N, ls[l].Kp, ls[l].dWp, ls[l].ldd, c->flat + ls[l].db_off, stream, a->D[l], 256, a->Q[l],
-                              l == 0 ? 64 : 256));
-        else CHK(wgrad(c, A[l], 256, u, ldu, P, ls[l].N, ls[l].Kp, ls[l].dWp, ls[l].ldd, c->flat + ls[l].db_off, stream));
+        const int st = (sdfD16(l) ? NU_TN_A0_16 | NU_TN_A1_16 : 0) | (sdfH16(l) ? NU_TN_B0_16 | NU_TN_B1_16 : 0);
+        if (second) CHK(wgrad(c, A[l], 256, u, ldu, P, ls[l].N, ls[l].Kp, ls[l].dWp, ls[l].ldd, c->flat + ls[l].db_off, stream, st, a->D[l], 256,
+                              a->Q[l], l == 0 ? 64 : 256));
+        else CHK(wgrad(c, A[l], 256, u, ldu, P, ls[l].N, ls[l].Kp, ls[l].dWp, ls[l].ldd, c->flat + ls[l].db_off, stream, st));
     }
     CHK(wgrad(c, dYX, 288, a->H[8], 256, P, 257, 256, ls[8].dWp, 256, c->flat + ls[8].db_off, stream));
     if (second) {          // d W8[sdf row] += sum_p q_8
@@ -190,7 +244,7 @@ extern "C" int nu_sdf_mlp_bwd(NuOpCtx* c, const NuSdfNet* net, NuSdfBufs* a, con
     }
     if (dx != nullptr) {
         NtArgs g = {A[0], 256, ls[0].WpT, ls[0].ldT, P, 39, 256, a->dE0, 64, NU_EPI_PLAIN};
-        g.zero_to = 64;
+        g.zero_to = 64; g.B16 = w16(ls[0].WpT16, 0); g.st = A16;
         CHK(nt(c, g, stream));
         CHK(nu_embed_jt2(a->E, a->dE0, 64, A[3] + 217, 256, second ? a->G0 : nullptr, 64, second ? a->D[3] + 217 : nullptr, 256,
                          second ? nbar : nullptr, P, dx, 0, stream));
@@ -200,6 +254,7 @@ extern "C" int nu_sdf_mlp_bwd(NuOpCtx* c, const NuSdfNet* net, NuSdfBufs* a, con
 
 // ---------------------------------------------------------------------------------------------------------
 // make_predictor stacks (field.py:371-408): 3 hidden ReLU layers + a 1..3-wide head
+// h16: hidden [0], [1] and the backward scratch tmp[0], tmp[1] are bf16; hidden [2] (read by the skinny head) and dH3 fp32
 // ---------------------------------------------------------------------------------------------------------
 static int relu_stack_fwd(NuOpCtx* c, const NuLin* ls, const float* X, int ldx, int rows, float* const* Hs, unsigned long long* const* masks,
                           int nct, hipStream_t stream) {
@@ -208,6 +263,7 @@ static int relu_stack_fwd(NuOpCtx* c, const NuLin* ls, const float* X, int ldx, 
     for (int j = 0; j < 3; ++j) {
         NtArgs g = {src, lds, ls[j].Wp, ls[j].Kp, rows, 256, ls[j].Kp, Hs[j], 256, NU_EPI_BIAS_RELU};
         g.bias = ls[j].bias; g.mask = masks[j]; g.mask_nct = nct;
+        g.B16 = w16(ls[j].Wp16, 0); g.st = (j > 0 ? A16 : 0) | (j < 2 ? C16 : 0);
         CHK(nt(c, g, stream));
         src = Hs[j]; lds = 256;
     }
@@ -221,14 +277,18 @@ static int relu_stack_bwd(NuOpCtx* c, const NuLin* ls, const float* X, int ldx, 
     for (int j = 2; j >= 0; --j) {
         const float* u = j == 0 ? X : Hs[j - 1];
         const int ldu = j == 0 ? ldx : 256;
-        CHK(wgrad(c, dA, 256, u, ldu, rows, 256, ls[j].Kp, ls[j].dWp, ls[j].ldd, c->flat + ls[j].db_off, stream));
+        const int a16 = j < 2;                      // dA is tmp[j] (bf16) below the top layer
+        CHK(wgrad(c, dA, 256, u, ldu, rows, 256, ls[j].Kp, ls[j].dWp, ls[j].ldd, c->flat + ls[j].db_off, stream,
+                  (a16 ? NU_TN_A0_16 : 0) | (j > 0 ? NU_TN_B0_16 : 0)));
         if (j > 0) {
             NtArgs g = {dA, 256, ls[j].WpT, ls[j].ldT, rows, 256, 256, tmp[j - 1], 256, NU_EPI_MUL_DRELU};
             g.H = Hs[j - 1]; g.ldh = 256; g.mask = masks[j - 1]; g.mask_nct = nct;
+            g.B16 = w16(ls[j].WpT16, 0); g.st = (a16 ? A16 : 0) | C16 | X16;
             CHK(nt(c, g, stream));
             dA = tmp[j - 1];
         } else if (dX != nullptr) {
             NtArgs g = {dA, 256, ls[j].WpT, ls[j].ldT, rows, dx_cols, 256, dX, lddx, NU_EPI_PLAIN};
+            g.B16 = w16(ls[j].WpT16, 0); g.st = A16;
             CHK(nt(c, g, stream));
         }
     }
@@ -238,9 +298,12 @@ static int relu_stack_bwd(NuOpCtx* c, const NuLin* ls, const float* X, int ldx, 
 // ---------------------------------------------------------------------------------------------------------
 // NeRF++ (field.py:265-289): 8 x 256 ReLU with the 84-d embedding re-concatenated before layer 5, alpha / feature heads,
 // one 283 -> 128 view layer, rgb head
+// h16: H[1..4], H[6..7] and dA[1..4], dA[6..8] are bf16
 // ---------------------------------------------------------------------------------------------------------
 extern "C" int nu_nerf_net_size(void) { return (int)sizeof(NuNerfNet); }
 extern "C" int nu_nerf_bufs_size(void) { return (int)sizeof(NuNerfBufs); }
+static inline bool nerfH16(int i) { return i == 1 || i == 2 || i == 3 || i == 4 || i == 6 || i == 7; }
+static inline bool nerfdA16(int i) { return nerfH16(i) || i == 8; }
 
 extern "C" int nu_nerfpp_mlp_fwd(NuOpCtx* c, const NuNerfNet* net, const float* pt, int pt_ld, NuNerfBufs* b, hipStream_t stream) {
     const int P = b->P;
@@ -253,15 +316,16 @@ extern "C" int nu_nerfpp_mlp_fwd(NuOpCtx* c, const NuNerfNet* net, const float* 
         const int ldc = i == 4 ? 352 : 256;
         NtArgs g = {src, lds, L.Wp, L.Kp, P, 256, L.Kp, b->H[i + 1], ldc, NU_EPI_BIAS_RELU};
         g.bias = L.bias; g.mask = b->mask[i + 1]; g.mask_nct = 2;
+        g.B16 = w16(L.Wp16, 0); g.st = (nerfH16(i) ? A16 : 0) | (nerfH16(i + 1) ? C16 : 0);
         CHK(nt(c, g, stream));
         src = b->H[i + 1]; lds = ldc;
     }
     CHK(nu_skinny_fwd(b->H[8], 256, P, 256, net->alpha.Wp, 256, net->alpha.bias, 1, b->sig, 1, stream));
     NtArgs gf = {b->H[8], 256, net->feat.Wp, 256, P, 256, 256, b->V, 288, NU_EPI_BIAS_NONE};
-    gf.bias = net->feat.bias;
+    gf.bias = net->feat.bias; gf.B16 = w16(net->feat.Wp16, 0);
     CHK(nt(c, gf, stream));
     NtArgs gv = {b->V, 288, net->view.Wp, 288, P, 128, 288, b->HV, 128, NU_EPI_BIAS_RELU};
-    gv.bias = net->view.bias;
+    gv.bias = net->view.bias; gv.B16 = w16(net->view.Wp16, 0);
     CHK(nt(c, gv, stream));
     return nu_skinny_fwd(b->HV, 128, P, 128, net->rgb.Wp, 128, net->rgb.bias, 3, b->rgb, 4, stream);
 }
@@ -276,35 +340,43 @@ extern "C" int nu_nerfpp_mlp_bwd(NuOpCtx* c, const NuNerfNet* net, const float* 
     CHK(skinny_bwd(c, drgb, 4, b->HV, 128, P, 128, net->rgb.Wp, 128, 3, b->dHV, 128, 1, net->rgb.dWp, 128, c->flat + net->rgb.db_off, stream));
     CHK(wgrad(c, b->dHV, 128, b->V, 288, P, 128, 288, net->view.dWp, 288, c->flat + net->view.db_off, stream));
     NtArgs gF = {b->dHV, 128, net->view.WpT, net->view.ldT, P, ldf, 128, b->dF, ldf, NU_EPI_PLAIN};
+    gF.B16 = w16(net->view.WpT16, 0);
     CHK(nt(c, gF, stream));
     CHK(wgrad(c, b->dF, ldf, b->H[8], 256, P, 256, 256, net->feat.dWp, 256, c->flat + net->feat.db_off, stream));
     CHK(skinny_bwd(c, dsig, 1, b->H[8], 256, P, 256, net->alpha.Wp, 256, 1, b->dH8a, 256, 1, net->alpha.dWp, 256, c->flat + net->alpha.db_off, stream));
     NtArgs g8 = {b->dF, ldf, net->feat.WpT, net->feat.ldT, P, 256, 256, b->dA[8], 256, NU_EPI_B_RELU};
     g8.H = b->H[8]; g8.ldh = 256; g8.Cadd = b->dH8a; g8.ldadd = 256; g8.mask = b->mask[8]; g8.mask_nct = 2;
+    g8.B16 = w16(net->feat.WpT16, 0); g8.st = C16;
     CHK(nt(c, g8, stream));
     const float* dA = b->dA[8];
     int lda = 256;
+    int dA_i = 8;                              // index of the buffer dA points at (its storage type follows nerfdA16)
     const float* dskip = nullptr;
     for (int i = 7; i >= 0; --i) {
         const NuLin& L = net->pts[i];
         const int ldu = i == 0 ? 96 : (i == 5 ? 352 : 256);
-        CHK(wgrad(c, dA, lda, b->H[i], ldu, P, 256, L.Kp, L.dWp, L.ldd, c->flat + L.db_off, stream));
+        CHK(wgrad(c, dA, lda, b->H[i], ldu, P, 256, L.Kp, L.dWp, L.ldd, c->flat + L.db_off, stream,
+                  (nerfdA16(dA_i) ? NU_TN_A0_16 : 0) | (nerfH16(i) ? NU_TN_B0_16 : 0)));
         if (i > 0) {
+            const int st = (nerfdA16(dA_i) ? A16 : 0) | (nerfdA16(i) ? C16 : 0) | (nerfH16(i) ? X16 : 0);
             if (i == 5 && want_in) {       // columns 256..339 of the layer-5 input: the re-concatenated embedding, plain gradient
                 NtArgs g = {dA, lda, L.WpT, L.ldT, P, 340, 256, b->dA[i], 352, NU_EPI_MUL_DRELU};
                 g.H = b->H[i]; g.ldh = ldu; g.act_cols = 256; g.zero_to = 352; g.mask = b->mask[i]; g.mask_nct = 2;
+                g.B16 = w16(L.WpT16, 0); g.st = st;
                 CHK(nt(c, g, stream));
                 dskip = b->dA[i];
                 dA = b->dA[i]; lda = 352;
             } else {
                 NtArgs g = {dA, lda, L.WpT, L.ldT, P, 256, 256, b->dA[i], 256, NU_EPI_MUL_DRELU};
                 g.H = b->H[i]; g.ldh = ldu; g.mask = b->mask[i]; g.mask_nct = 2;
+                g.B16 = w16(L.WpT16, 0); g.st = st;
                 CHK(nt(c, g, stream));
                 dA = b->dA[i]; lda = 256;
             }
+            dA_i = i;
         } else if (want_in) {
             NtArgs g = {dA, lda, L.WpT, L.ldT, P, 84, 256, b->dE4, 96, NU_EPI_PLAIN};
-            g.zero_to = 96;
+            g.zero_to = 96; g.B16 = w16(L.WpT16, 0); g.st = nerfdA16(dA_i) ? A16 : 0;
             CHK(nt(c, g, stream));
             CHK(nu_nerf_embed_bwd(pt, pt_ld, b->H[0], b->V, b->dE4, 96, dskip + 256, 352, b->dF + 256, ldf, P, b->dx, b->ddir, stream));
         }
@@ -314,6 +386,7 @@ extern "C" int nu_nerfpp_mlp_bwd(NuOpCtx* c, const NuNerfNet* net, const float* 
 
 // ---------------------------------------------------------------------------------------------------------
 // Shading stack (field.py:684-777): 4 material predictors (batched), the encodings, 4 light predictors, BRDF combine
+// h16: M[0], M[1], dM[0], dM[1] are bf16 (M[2] feeds the skinny head and stays fp32)
 // ---------------------------------------------------------------------------------------------------------
 extern "C" int nu_shade_net_size(void) { return (int)sizeof(NuShadeNet); }
 extern "C" int nu_shade_bufs_size(void) { return (int)sizeof(NuShadeBufs); }
@@ -325,11 +398,12 @@ extern "C" int nu_shading_stack_fwd(NuOpCtx* c, const NuShadeNet* net, NuShadeBu
     const int rows_ol = 3 * P + R;
     // materials: layer 0 batched (N = 1024), layers 1-2 grouped x4, block-diagonal 6-wide head
     NtArgs m0 = {YX, 288, net->WpM0, 288, P, 1024, 288, s->M[0], 1024, NU_EPI_BIAS_RELU};
-    m0.bias = net->bM0; m0.mask = s->maskM[0]; m0.mask_nct = 8;
+    m0.bias = net->bM0; m0.mask = s->maskM[0]; m0.mask_nct = 8; m0.B16 = w16(net->WpM0_16, 0); m0.st = C16;
     CHK(nt(c, m0, stream));
     for (int j = 1; j <= 2; ++j) {
         NtArgs g = {s->M[j - 1], 1024, net->WpM[j], 256, P, 256, 256, s->M[j], 1024, NU_EPI_BIAS_RELU};
         g.bias = net->bM[j]; g.groups = 4; g.sA = 256; g.sB = 65536; g.sC = 256; g.sBias = 256; g.mask = s->maskM[j]; g.mask_nct = 8;
+        g.B16 = w16(net->WpM16[j], 0); g.st = A16 | (j < 2 ? C16 : 0);
         CHK(nt(c, g, stream));
     }
     CHK(nu_skinny_fwd(s->M[2], 1024, P, 1024, net->Ws6, 1024, net->b6, 6, s->Mraw, 8, stream));
@@ -376,14 +450,17 @@ extern "C" int nu_shading_stack_bwd(NuOpCtx* c, const NuShadeNet* net, NuShadeBu
     CHK(skinny_bwd(c, s->dMraw, 8, s->M[2], 1024, P, 1024, net->Ws6, 1024, 6, s->dM[2], 1024, 1, net->dWs6, 1024, c->flat + net->db6_off, stream));
     const float* dA = s->dM[2];
     for (int j = 2; j >= 1; --j) {
-        CHK(wgrad(c, dA, 1024, s->M[j - 1], 1024, P, 256, 256, net->dWpM[j], 256, c->flat + net->dbM_off[j], stream, nullptr, 0, nullptr, 0, 4, 256, 256,
-                  65536, 256));
+        const int a16 = j < 2;                     // dM[2] comes from the skinny head (fp32); dM[1], dM[0] are bf16
+        CHK(wgrad(c, dA, 1024, s->M[j - 1], 1024, P, 256, 256, net->dWpM[j], 256, c->flat + net->dbM_off[j], stream,
+                  (a16 ? NU_TN_A0_16 : 0) | NU_TN_B0_16, nullptr, 0, nullptr, 0, 4, 256, 256, 65536, 256));
         NtArgs g = {dA, 1024, net->WpTM[j], 256, P, 256, 256, s->dM[j - 1], 1024, NU_EPI_MUL_DRELU};
         g.H = s->M[j - 1]; g.ldh = 1024; g.groups = 4; g.sA = 256; g.sB = 65536; g.sC = 256; g.sH = 256; g.mask = s->maskM[j - 1]; g.mask_nct = 8;
+        g.B16 = w16(net->WpTM16[j], 0); g.st = (a16 ? A16 : 0) | C16 | X16;
         CHK(nt(c, g, stream));
         dA = s->dM[j - 1];
     }
-    CHK(wgrad(c, dA, 1024, YX, 288, P, 1024, 288, net->dWpM0, 288, c->flat + net->dbM_off[0], stream));
+    CHK(wgrad(c, dA, 1024, YX, 288, P, 1024, 288, net->dWpM0, 288, c->flat + net->dbM_off[0], stream, NU_TN_A0_16));
     NtArgs gy = {dA, 1024, net->WpTM0, 1024, P, 288, 1024, s->dYX, 288, NU_EPI_PLAIN};
+    gy.B16 = w16(net->WpTM0_16, 0); gy.st = A16;
     return nt(c, gy, stream);
 }

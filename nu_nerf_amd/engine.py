@@ -64,13 +64,13 @@ class PackDesc(ctypes.Structure):
 class Lin(ctypes.Structure):
     """Mirror of NuLin (include/nu_nerf.h): one packed layer."""
     _fields_ = [("Wp", c_p), ("WpT", c_p), ("dWp", c_p), ("bias", c_p), ("db_off", c_ll), ("N", c_int), ("K", c_int), ("Kp", c_int),
-                ("ldT", c_int), ("ldd", c_int), ("pad_", c_int)]
+                ("ldT", c_int), ("ldd", c_int), ("pad_", c_int), ("Wp16", c_p), ("WpT16", c_p)]
 
 
 class OpCtx(ctypes.Structure):
     """Mirror of NuOpCtx: arithmetic mode, flat gradient buffer, deferred-reduction arena (shared by the Python-sequenced path)."""
-    _fields_ = [("prec", c_int), ("pad_", c_int), ("flat", c_p), ("arena", c_p), ("arena_floats", c_ll), ("arena_off", c_ll),
-                ("descs", c_p), ("ndesc", c_int), ("cap", c_int)]
+    _fields_ = [("prec", c_int), ("h16", c_int), ("flat", c_p), ("arena", c_p), ("arena_floats", c_ll), ("arena_off", c_ll),
+                ("descs", c_p), ("ndesc", c_int), ("cap", c_int), ("ev", c_p), ("ev_meta", c_p), ("nev", c_int), ("ev_cap", c_int)]
 
 
 class SdfNet(ctypes.Structure):
@@ -95,7 +95,8 @@ class ShadeNet(ctypes.Structure):
     _fields_ = [("WpM0", c_p), ("WpTM0", c_p), ("bM0", c_p), ("dWpM0", c_p), ("WpM", c_p * 3), ("WpTM", c_p * 3), ("bM", c_p * 3),
                 ("dWpM", c_p * 3), ("dbM_off", c_ll * 3), ("Ws6", c_p), ("b6", c_p), ("dWs6", c_p), ("db6_off", c_ll),
                 ("outer_light", Lin * 4), ("inner_light", Lin * 4), ("inner_weight", Lin * 4), ("refrac_light", Lin * 4),
-                ("lut", c_p), ("exp_max", c_f), ("sphere", c_int), ("ld_ol", c_int), ("refrac_dim", c_int), ("ld_rl", c_int), ("pad_", c_int)]
+                ("lut", c_p), ("exp_max", c_f), ("sphere", c_int), ("ld_ol", c_int), ("refrac_dim", c_int), ("ld_rl", c_int), ("pad_", c_int),
+                ("WpM0_16", c_p), ("WpTM0_16", c_p), ("WpM16", c_p * 3), ("WpTM16", c_p * 3)]
 
 
 class ShadeBufs(ctypes.Structure):
@@ -114,10 +115,10 @@ def rup(a, b):
 
 
 def addr(t, off=0):
-    """Device address of element `off` (in floats/ints of 4 bytes) of tensor t; 0 for None."""
+    """Device address of element `off` of tensor t (fp32 / int32, or bf16 in the bf16-storage mode); 0 for None."""
     if t is None:
         return 0
-    return t.data_ptr() + 4 * off
+    return t.data_ptr() + t.element_size() * off
 
 
 class _Layer:
@@ -162,6 +163,10 @@ class Stage1Engine:
             raise ValueError(f"mlp_dtype {md!r}: expected 'fp32', 'bf16' or 'bf16x6'")
         # 'bf16x6': fp32-equivalent products on the bf16 pipe (exact 3-way split of both operands, six partial products)
         self.bf16 = 2 if md == 'bf16x6' else (1 if md.startswith('b') else 0)
+        # 'bf16' stores what only GEMMs touch as bf16 in HBM (weight tables + most hidden activations, include/nu_nerf.h
+        # NuOpCtx.h16); NU_BF16_STORAGE=0 keeps the round-1 behaviour (fp32 in HBM, rounded on load) for A/B runs
+        self.h16 = self.bf16 == 1 and os.environ.get('NU_BF16_STORAGE', '1') != '0'
+        self.hdt = torch.bfloat16 if self.h16 else torch.float32
         # deferred split reductions (weight gradients, skinny heads, column sums): partial slabs live in a bump arena
         # until flush_reductions() sums them all in a few batched launches (before unpack_grads reads the results)
         self._rd_cap = 1024
@@ -169,18 +174,20 @@ class Stage1Engine:
         self._arena = None
         # one context for both sequencing paths (network-level C entries and the launch-by-launch Python path below): the
         # descriptor count and the arena offset live in the struct
-        self._ctx = OpCtx(prec=self.bf16, flat=0, arena=0, arena_floats=0, arena_off=0,
-                          descs=ctypes.cast(self._rd, c_p).value, ndesc=0, cap=self._rd_cap)
+        self._ctx = OpCtx(prec=self.bf16, h16=1 if self.h16 else 0, flat=0, arena=0, arena_floats=0, arena_off=0,
+                          descs=ctypes.cast(self._rd, c_p).value, ndesc=0, cap=self._rd_cap, ev=0, ev_meta=0, nev=0, ev_cap=0)
         self._ndesc_p = ctypes.cast(ctypes.addressof(self._ctx) + OpCtx.ndesc.offset, ctypes.POINTER(c_int))
         for fn, st in (("nu_op_ctx_size", OpCtx), ("nu_sdf_net_size", SdfNet), ("nu_sdf_bufs_size", SdfBufs), ("nu_nerf_net_size", NerfNet),
                        ("nu_nerf_bufs_size", NerfBufs), ("nu_shade_net_size", ShadeNet), ("nu_shade_bufs_size", ShadeBufs)):
             assert getattr(lib, fn)() == ctypes.sizeof(st), f"{st.__name__} ABI mismatch"
         # NU_PY_SEQ=1: sequence every launch from Python (the path bench.py's per-launch event timing uses)
         self.py_seq = os.environ.get('NU_PY_SEQ', '0') != '0'
+        if self.py_seq and self.h16:
+            raise ValueError("NU_PY_SEQ=1 (launch-by-launch sequencing) has no bf16-storage mode: unset it or set NU_BF16_STORAGE=0")
         self._ws = None
         self._ptr_sig = None
         self._ktime = None
-        self.ktime_on = True
+        self._ktime_on = True
         self._ev_pool = []
         self._cap_classes = []
         self.last_ctx = None
@@ -219,6 +226,10 @@ class Stage1Engine:
         if cap is None:
             return torch.empty(*shape, dtype=dtype, device=self.dev)
         return torch.empty(cap, *shape[1:], dtype=dtype, device=self.dev)[:shape[0]]
+
+    def empty_h(self, *shape):
+        """A hidden activation that only GEMMs touch: bf16 in the bf16-storage mode (rule: include/nu_nerf.h NuOpCtx)."""
+        return self.empty(*shape, dtype=self.hdt)
 
     def workspace(self, nbytes):
         n = (int(nbytes) + 3) // 4
@@ -396,6 +407,13 @@ class Stage1Engine:
         layers += self.outer_light + self.inner_light + self.inner_weight + self.refrac_light
         self.layers = layers
         self.n_grad = self._goff
+        # bf16 copies of every NT-side weight table (written by the same pack launch): same shapes, same element offsets
+        self._tw = {}
+        if self.h16:
+            for lay in layers:
+                for tab in (lay.Wp, lay.WpT):
+                    if tab is not None and id(tab[0]) not in self._tw:
+                        self._tw[id(tab[0])] = torch.zeros_like(tab[0], dtype=torch.bfloat16)
         self.lut = p['color_network.FG_LUT']
         # parameters that never receive a gradient in stage 1: color_network.iors.*, infinity_far_bkgr.*
         self._desc_dev = None
@@ -414,6 +432,7 @@ class Stage1Engine:
             d.Wp = addr(*l.Wp)
             d.WpT = addr(*l.WpT) if l.WpT is not None else 0
             d.dWp = addr(*l.dWp)
+            d.Wp16, d.WpT16 = self._a16(l.Wp), self._a16(l.WpT)
             d.dv_off, d.dg_off = l.dv_off, l.dg_off
             d.bias = addr(l.b) if (l.bias_p is not None) else 0
             d.bias_p = addr(*l.bias_p) if l.bias_p is not None else 0
@@ -426,10 +445,15 @@ class Stage1Engine:
         self._ptr_sig = self._signature()
         self._build_net_structs()
 
-    @staticmethod
-    def _lin(lay):
+    def _a16(self, tab):
+        """Device address of the bf16 twin of a (tensor, element offset) weight table; 0 outside the bf16-storage mode."""
+        if tab is None or not self.h16:
+            return 0
+        return addr(self._tw[id(tab[0])], tab[1])
+
+    def _lin(self, lay):
         return Lin(addr(*lay.Wp), addr(*lay.WpT) if lay.WpT is not None else 0, addr(*lay.dWp), addr(lay.b), lay.db_off, lay.N, lay.K,
-                   lay.Kp, lay.ldT, lay.ldd, 0)
+                   lay.Kp, lay.ldT, lay.ldd, 0, self._a16(lay.Wp), self._a16(lay.WpT))
 
     def _build_net_structs(self):
         """Packed-layer tables of the network-level C entries (include/nu_nerf.h: NuSdfNet, NuNerfNet, NuShadeNet)."""
@@ -449,6 +473,9 @@ class Stage1Engine:
             n.dbM_off[j] = db12[j]
         n.dbM_off[0] = db0
         n.Ws6, n.b6, n.dWs6, n.db6_off = addr(self.Ws6), addr(self.b6), addr(self.dWs6), db6
+        n.WpM0_16, n.WpTM0_16 = self._a16((self.WpM0, 0)), self._a16((self.WpTM0, 0))
+        for j in (1, 2):
+            n.WpM16[j], n.WpTM16[j] = self._a16((self.WpM[j], 0)), self._a16((self.WpTM[j], 0))
         for name in ('outer_light', 'inner_light', 'inner_weight', 'refrac_light'):
             arr = getattr(n, name)
             for j, lay in enumerate(getattr(self, name)):
@@ -460,7 +487,7 @@ class Stage1Engine:
     def _use_c(self):
         """Network-level C entries unless launch-by-launch sequencing is asked for (NU_PY_SEQ=1, or bench.py's per-launch
         event timing, which brackets individual GEMM launches)."""
-        return not self.py_seq and not (self._ktime is not None and self.ktime_on)
+        return not self.py_seq
 
     def pack(self):
         """Fold weight-norm, pad/permute and transpose every layer's weight: one launch."""
@@ -498,16 +525,32 @@ class Stage1Engine:
             kt['nt'].append((e0, e1, 2.0 * M * (ntrue or N) * (ktrue or K) * groups, abytes))
 
     def begin_kernel_timing(self, reserve=0):
-        """Bracket every GEMM launch with HIP events on the launch stream (bench.py's roofline leg).  The event pairs cost
+        """Bracket every GEMM launch with HIP events on the launch stream (bench.py's roofline leg).  The network-level C
+        entries record the events themselves (NuOpCtx.ev); the Python-sequenced path records them here.  The event pairs cost
         about 4 ms per step (two queue barriers per launch), so the bench switches `ktime_on` per step to sample."""
         self._ktime = {'nt': [], 'tn': []}
-        self.ktime_on = True
         # events are created here, outside the timed region: torch makes the HIP event at the first record(), and creating
         # the ~650 events of one bracketed step used to cost that step 70 ms
-        self._ev_pool = [torch.cuda.Event(enable_timing=True) for _ in range(int(reserve))]
+        n = max(int(reserve), 2) // 2 * 2
+        self._ev_pool = [torch.cuda.Event(enable_timing=True) for _ in range(n)]
         for ev in self._ev_pool:
             ev.record()
         torch.cuda.synchronize(self.dev)
+        self._ev_c = list(self._ev_pool)                      # the C path uses them in order; the Python path pops from the end
+        self._ev_handles = (c_p * n)(*[ev.cuda_event for ev in self._ev_c])
+        self._ev_meta = (ctypes.c_double * (3 * (n // 2)))()
+        self._ctx.nev, self._ctx.ev_cap, self._ctx.ev_meta = 0, (0 if self.py_seq else n), ctypes.addressof(self._ev_meta)
+        self.ktime_on = True
+
+    @property
+    def ktime_on(self):
+        return self._ktime_on
+
+    @ktime_on.setter
+    def ktime_on(self, on):
+        self._ktime_on = bool(on)
+        live = self._ktime_on and self._ktime is not None and not self.py_seq
+        self._ctx.ev = ctypes.addressof(self._ev_handles) if live else 0
 
     def _event_pair(self):
         pool = self._ev_pool
@@ -517,8 +560,13 @@ class Stage1Engine:
 
     def end_kernel_timing(self):
         kt, self._ktime = self._ktime, None
+        self._ctx.ev = 0
         torch.cuda.synchronize(self.dev)
-        out = {}
+        for i in range(self._ctx.nev // 2):                  # launches the C entries bracketed
+            kind, flops, nbytes = self._ev_meta[3 * i:3 * i + 3]
+            kt['tn' if kind else 'nt'].append((self._ev_c[2 * i], self._ev_c[2 * i + 1], flops, nbytes))
+        out = {'event_capacity_reached': bool(self._ctx.ev_cap and self._ctx.nev >= self._ctx.ev_cap)}
+        self._ctx.nev = 0
         for key, pre in (('nt', ''), ('tn', 'tn_')):
             out[pre + 'seconds'] = sum(a.elapsed_time(b) for a, b, _, _ in kt[key]) * 1e-3
             out[pre + 'flops'] = sum(f for _, _, f, _ in kt[key])
@@ -579,11 +627,12 @@ class Stage1Engine:
         a['U4'] = e(P, 256)
         a['YX'] = e(P, 288) if want_feat else None
         ls = self.sdf
+        eh = self.empty_h               # H[1..3], H[5..7]: bf16 in the bf16-storage mode; U4 (= H[4]) and H[8] fp32
         if keep:
-            H = [None] + [e(P, 256) for _ in range(3)] + [a['U4']] + [e(P, 256) for _ in range(4)]
+            H = [None] + [eh(P, 256) for _ in range(3)] + [a['U4']] + [eh(P, 256) for _ in range(3)] + [e(P, 256)]
         else:
-            t0, t1 = e(P, 256), e(P, 256)
-            H = [None, t0, t1, t0, a['U4'], t0, t1, t0, t1]
+            t0, t1 = eh(P, 256), eh(P, 256)
+            H = [None, t0, t1, t0, a['U4'], t0, t1, t0, e(P, 256) if self.h16 else t1]
         a['H'] = H
         if self._use_c():          # one C call sequences the embedding, the eight hidden GEMMs and the output layer
             cb = SdfBufs(P=P, E=addr(a['E']), U4=addr(a['U4']), YX=addr(a['YX']))
@@ -618,7 +667,7 @@ class Stage1Engine:
         """Reverse sweep: n = d sdf / d x  (field.py:158-170), keeping delta_l for the second-order backward."""
         lib, S, P, ls, H = self.lib, self.stream(), a['P'], self.sdf, a['H']
         e = self.empty
-        D = [e(P, 256) for _ in range(8)]
+        D = [self.empty_h(P, 256) if l in (0, 1, 2, 4, 5, 6) else e(P, 256) for l in range(8)]
         a['D'] = D
         if self._use_c():
             cb = self._sdf_cb(a)
@@ -659,18 +708,19 @@ class Stage1Engine:
         if self._use_c():
             cb = self._sdf_cb(a)
             keep = []
+            eh = self.empty_h          # bf16-storage rule: C[l] / Aux[l] like D[l], Q[l] like H[l]
             if second:
                 for l in range(8):
-                    t = e(P, 256)
+                    t = eh(P, 256) if l in (0, 1, 2, 4, 5, 6) else e(P, 256)
                     keep.append(t)
                     cb.C[l] = addr(t)
                 for l in range(9):
-                    t = e(P, 64 if l == 0 else 256)
+                    t = e(P, 64) if l == 0 else (eh(P, 256) if l in (1, 2, 3, 5, 6, 7) else e(P, 256))
                     keep.append(t)
                     cb.Q[l] = addr(t)
             else:
                 for l in range(8):
-                    t = e(P, 256)
+                    t = eh(P, 256) if l in (0, 1, 2, 4, 5, 6) else e(P, 256)
                     keep.append(t)
                     cb.Aux[l] = addr(t)
             if dx is not None:
@@ -839,7 +889,8 @@ class Stage1Engine:
         ld_ol, ld_rl = self.ld_ol, self.ld_rl
         s = {'P': P, 'R': R, 'rows_ol': rows_ol}
         cb = ShadeBufs(P=P, R=R, extra_dirs=addr(extra_dirs), extra_pts=addr(extra_pts))
-        M = [e(P, 1024) for _ in range(3)]
+        eh = self.empty_h              # M[0], M[1] and hidden [0], [1] of the light predictors: bf16 in the bf16-storage mode
+        M = [eh(P, 1024), eh(P, 1024), e(P, 1024)]
         for j in range(3):
             cb.M[j], cb.maskM[j] = addr(M[j]), addr(self.relu_mask(M[j], P, 1024))
         s.update(M1=M[0], M2=M[1], M3=M[2], Mraw=e(P, 8), OLin=e(rows_ol, ld_ol), ILin=e(2 * P, 128), IWin=e(P, 96), RLin=e(P, ld_rl),
@@ -848,7 +899,7 @@ class Stage1Engine:
             setattr(cb, k, addr(s[k]))
         for key, rows, arr, marr in (('OLh', rows_ol, cb.OLh, cb.maskOL), ('ILh', 2 * P, cb.ILh, cb.maskIL),
                                      ('IWh', P, cb.IWh, cb.maskIW), ('RLh', P, cb.RLh, cb.maskRL)):
-            Hs = [e(rows, 256) for _ in range(3)]
+            Hs = [eh(rows, 256), eh(rows, 256), e(rows, 256)]
             for j in range(3):
                 arr[j], marr[j] = addr(Hs[j]), addr(self.relu_mask(Hs[j], rows, 256))
             s[key] = Hs
@@ -882,11 +933,11 @@ class Stage1Engine:
             cb.dH3[i] = addr(t)
         for arr, rows in ((cb.tmpOL, rows_ol), (cb.tmpIL, 2 * P), (cb.tmpIW, P), (cb.tmpRL, P)):
             for j in range(2):
-                t = e(rows, 256)
+                t = self.empty_h(rows, 256)
                 keep.append(t)
                 arr[j] = addr(t)
         dOLin, dILin, dn, dYX = e(rows_ol, self.ld_ol), e(2 * P, 128), e(P, 3), e(P, 288)
-        dM = [e(P, 1024) for _ in range(3)]
+        dM = [self.empty_h(P, 1024), self.empty_h(P, 1024), e(P, 1024)]
         cb.dOLin, cb.dILin, cb.dn, cb.dYX = addr(dOLin), addr(dILin), addr(dn), addr(dYX)
         for j in range(3):
             cb.dM[j] = addr(dM[j])
@@ -960,7 +1011,8 @@ class Stage1Engine:
         b = {'P': P}
         E4, U5, V = e(P, 96), e(P, 352), e(P, 288)
         if self._use_c():
-            H = [E4] + [U5 if i == 4 else e(P, 256) for i in range(8)]
+            # H[1..4], H[6..7]: bf16 in the bf16-storage mode (H[5] = U5 carries the embedding, H[8] feeds the skinny head)
+            H = [E4] + [U5 if i == 4 else (e(P, 256) if i == 7 else self.empty_h(P, 256)) for i in range(8)]
             cb = NerfBufs(P=P)
             for i in range(9):
                 cb.H[i] = addr(H[i])
@@ -1026,7 +1078,7 @@ class Stage1Engine:
             keep = [e(P, 128), e(P, ldf), e(P, 256)]
             cb.dHV, cb.dF, cb.dH8a = (addr(t) for t in keep)
             for i in range(1, 9):
-                t = e(P, 352 if (i == 5 and want_in) else 256)
+                t = e(P, 352 if want_in else 256) if i == 5 else self.empty_h(P, 256)
                 keep.append(t)
                 cb.dA[i] = addr(t)
             if want_in:

@@ -175,6 +175,8 @@ class Stage1Nets:
     """Differentiable callables over one Stage1Engine (SDF, variance, NeRF++, the shading predictors)."""
 
     def __init__(self, eng, named, prefix_map=None):
+        if getattr(eng, 'h16', False):
+            raise NotImplementedError("stage 2 runs the fp32 / bf16x6 MLP modes; mlp_dtype 'bf16' (bf16 storage) is a stage-1 mode")
         self.eng = eng
         g = list(eng.grad_views.keys())
         self.named = named

@@ -246,6 +246,117 @@ def test_bf16_tn_weight_grad(gpu, P, N1, N2, S):
     torch.testing.assert_close(bo.double(), A0[:, :N1].double().sum(0), rtol=2e-5, atol=tol)   # bias sums stay fp32
 
 
+NU_B16, NU_A16, NU_C16, NU_X16 = 8, 16, 32, 64
+
+
+@pytest.mark.parametrize("M,N,K,a16", [(1, 1, 32, False), (300, 217, 256, True), (1000, 257, 288, False), (4099, 256, 96, False),
+                                       (4099, 256, 96, True), (2048, 256, 1024, True), (513, 128, 64, False), (777, 340, 352, True)])
+def test_bf16_storage_nt(gpu, M, N, K, a16):
+    """mlp_dtype 'bf16' as the engine runs it: weights (always), A / C / auxiliary matrices (per launch flags) are stored
+    as bf16.  bf16 x bf16 products are exact in fp32, so against fp64 on the stored values only the fp32 accumulation order
+    and -- for bf16 outputs -- ONE final rounding (rel 2^-8) are left.  Covers K tails (K % 64 == 32), M / N edges, every
+    epilogue that takes an auxiliary matrix, fp32 and bf16 output."""
+    from nu_nerf_amd import _lib as L
+    from nu_nerf_amd.engine import GemmNT, addr
+    lib = L.load()
+    torch.manual_seed(M + N + K)
+    A = torch.randn(M, K, device=gpu)
+    W = torch.randn(N, K, device=gpu) / K ** 0.5
+    B16 = _packB(W, K).bfloat16()
+    A_st = A.bfloat16() if a16 else A
+    bias = torch.randn(N, device=gpu)
+    ldx = (N + 7) // 8 * 8
+    H = torch.zeros(M, ldx, device=gpu)
+    H[:, :N] = torch.rand(M, N, device=gpu) * 0.02            # softplus(beta = 100) outputs live at this scale
+    D = torch.randn(M, ldx, device=gpu)
+    Cadd = torch.randn(M, ldx, device=gpu)
+    ref = _bf(A).double() @ _bf(W).double().t()
+    for x16 in (False, True):
+        Hs, Ds, Cs = (H.bfloat16(), D.bfloat16(), Cadd.bfloat16()) if x16 else (H, D, Cadd)
+        h, d, ca = Hs.double()[:, :N], Ds.double()[:, :N], Cs.double()[:, :N]
+        e = torch.exp(-100.0 * h)
+        cases = {7: (ref, None), 0: (ref + bias.double(), None), 1: (torch.relu(ref + bias.double()), None),
+                 2: (torch.nn.functional.softplus((ref + bias.double()), beta=100), None), 3: (ref * (h > 0), None),
+                 4: (ref * (1 - e), None), 5: (ref * (1 - e), ref * d * 100.0 * e), 6: (ref * (1 - e) + ca, None),
+                 8: (ref * (h > 0) + ca, None)}
+        for c16 in (False, True):
+            for epi, (want, want2) in cases.items():
+                if x16 and epi in (7, 0, 1, 2):
+                    continue                                   # no auxiliary matrix: covered by the x16 = False pass
+                dt = torch.bfloat16 if c16 else torch.float32
+                C = torch.full((M, ldx), float("nan"), device=gpu, dtype=dt)
+                C2 = torch.full((M, ldx), float("nan"), device=gpu, dtype=dt)
+                flags = 1 | NU_B16 | (NU_A16 if a16 else 0) | (NU_C16 if c16 else 0) | (NU_X16 if x16 else 0)
+                g = GemmNT(addr(A_st), K, addr(B16), K, M, N, K, addr(C), ldx, addr(C2), ldx, addr(bias), addr(Hs), ldx, addr(Ds), ldx,
+                           addr(Cs), ldx, 0, 0, 1.0, 1, 0, 0, 0, 0, 0, 0, 0, 0, epi, flags)
+                L.check(lib.nu_gemm_nt_ex(ctypes.byref(g), L.stream()), "nu_gemm_nt_ex")
+                rt, at = (8e-3, 2e-5 * K ** 0.5 + 1e-6) if c16 else (2e-5, 2e-5 * K ** 0.5)
+                torch.testing.assert_close(C[:, :N].double(), want, rtol=rt, atol=at, msg=lambda m: f"epi {epi} c16 {c16} x16 {x16}: {m}")
+                if want2 is not None:
+                    torch.testing.assert_close(C2[:, :N].double(), want2, rtol=rt, atol=(4e-2 if c16 else 2e-3) * K ** 0.5 / 16)
+                assert bool(torch.isnan(C[:, N:].float()).all()) or N == ldx          # nothing written past N
+
+
+def test_bf16_storage_nt_grouped_and_sign_bits(gpu):
+    """Grouped launch (the four material predictors side by side) with bf16 A and C, and the ReLU sign-bit words written by a
+    bf16-storage BIAS_RELU launch feeding a bf16-storage MUL_DRELU launch."""
+    from nu_nerf_amd import _lib as L
+    from nu_nerf_amd.engine import GemmNT, addr
+    lib = L.load()
+    torch.manual_seed(5)
+    M = 1500
+    A = torch.randn(M, 1024, device=gpu).bfloat16()
+    W = (torch.randn(4, 256, 256, device=gpu) / 16).bfloat16()
+    bias = torch.randn(1024, device=gpu)
+    C = torch.full((M, 1024), float("nan"), device=gpu, dtype=torch.bfloat16)
+    nct = 8
+    mask = torch.zeros(((M + 127) // 128) * nct * 256, dtype=torch.int64, device=gpu)
+    g = GemmNT(addr(A), 1024, addr(W), 256, M, 256, 256, addr(C), 1024, 0, 0, addr(bias), 0, 0, 0, 0, 0, 0, 0, 0, 1.0, 4,
+               256, 65536, 256, 0, 256, 0, 0, 0, 1, 1 | NU_B16 | NU_A16 | NU_C16, addr(mask), nct)
+    L.check(lib.nu_gemm_nt_ex(ctypes.byref(g), L.stream()), "nu_gemm_nt_ex")
+    want = torch.cat([torch.relu(A[:, 256 * i:256 * i + 256].double() @ W[i].double().t() + bias[256 * i:256 * i + 256].double())
+                      for i in range(4)], 1)
+    torch.testing.assert_close(C.double(), want, rtol=8e-3, atol=1e-3)
+    # backward epilogue reading the sign bits (H pointer poisoned: it must not be read)
+    dA = torch.randn(M, 1024, device=gpu).bfloat16()
+    WT = (torch.randn(4, 256, 256, device=gpu) / 16).bfloat16()
+    poison = torch.full((M, 1024), float("nan"), device=gpu, dtype=torch.bfloat16)
+    out = torch.full((M, 1024), float("nan"), device=gpu, dtype=torch.bfloat16)
+    g = GemmNT(addr(dA), 1024, addr(WT), 256, M, 256, 256, addr(out), 1024, 0, 0, 0, addr(poison), 1024, 0, 0, 0, 0, 0, 0, 1.0, 4,
+               256, 65536, 256, 0, 0, 256, 0, 0, 3, 1 | NU_B16 | NU_A16 | NU_C16 | NU_X16, addr(mask), nct)
+    L.check(lib.nu_gemm_nt_ex(ctypes.byref(g), L.stream()), "nu_gemm_nt_ex")
+    # the sign bits describe the fp32 epilogue value before its rounding to bf16: > 0 there <=> stored bf16 > 0 except for
+    # values that round to zero (none at this scale)
+    want = torch.cat([(dA[:, 256 * i:256 * i + 256].double() @ WT[i].double().t()) * (C[:, 256 * i:256 * i + 256].double() > 0)
+                      for i in range(4)], 1)
+    torch.testing.assert_close(out.double(), want, rtol=8e-3, atol=1e-3)
+
+
+@pytest.mark.parametrize("P,N1,N2,S,flags", [(1000, 257, 256, 7, 16 | 32 | 64 | 128), (5000, 256, 96, 16, 16 | 128), (333, 3, 256, 4, 32 | 64)])
+def test_bf16_storage_tn_weight_grad(gpu, P, N1, N2, S, flags):
+    from nu_nerf_amd import _lib as L
+    from nu_nerf_amd.engine import GemmTN, addr
+    lib = L.load()
+    lib.nu_wgrad_workspace_bytes.restype = ctypes.c_longlong
+    torch.manual_seed(P)
+    lda, ldb = (N1 + 7) // 8 * 8 + 8, (N2 + 7) // 8 * 8
+    ops = [torch.randn(P, ld, device=gpu) for ld in (lda, ldb, lda, ldb)]
+    st = [o.bfloat16() if flags & f else o for o, f in zip(ops, (16, 32, 64, 128))]
+    wsb = lib.nu_wgrad_workspace_bytes(N1, N2, S, 1)
+    ws = torch.empty(wsb // 4, device=gpu)
+    C = torch.full((N1, N2), float("nan"), device=gpu)
+    bo = torch.full((N1,), float("nan"), device=gpu)
+    g = GemmTN(addr(st[0]), lda, addr(st[1]), ldb, addr(st[2]), lda, addr(st[3]), ldb, P, N1, N2, 0, 0, S, 1, 0, 0, 0, 0, 0, 0, 1 | flags, 0)
+    L.check(lib.nu_wgrad(ctypes.byref(g), L.ptr(C), N2, ctypes.c_longlong(0), L.ptr(bo), ctypes.c_longlong(0), L.ptr(ws),
+                         ctypes.c_longlong(wsb), L.stream()), "nu_wgrad")
+    A0, B0, A1, B1 = [_bf(o) for o in ops]
+    ref = A0[:, :N1].double().t() @ B0[:, :N2].double() + A1[:, :N1].double().t() @ B1[:, :N2].double()
+    tol = 3e-5 * P ** 0.5
+    torch.testing.assert_close(C.double(), ref, rtol=2e-5, atol=tol)
+    bsrc = st[0].float()[:, :N1].double().sum(0)             # bias sums: of the STORED operand, in fp32
+    torch.testing.assert_close(bo.double(), bsrc, rtol=2e-5, atol=tol)
+
+
 @pytest.mark.parametrize("M,N,K", [(1, 1, 32), (300, 217, 256), (1000, 257, 288), (4099, 256, 96), (2048, 256, 1024)])
 def test_bf16x6_nt_is_fp32_equivalent(gpu, M, N, K):
     """mlp_dtype 'bf16x6': exact 3-way bf16 split of both operands, six partial products.  Against fp64 on the UNROUNDED
