@@ -1616,6 +1616,177 @@ __global__ __launch_bounds__(256, 3) void gemm_tn16_kernel(NuGemmTN g) {
     }
 }
 
+// The same kernel with a 256 x 256 output tile (512 threads, 8 waves as 4 x 2, wave tile 64 x 128, 128 accumulator VGPRs) for the
+// shapes whose N1 and N2 are multiples of 256: every operand row crosses HBM ONCE per split instead of once per output-tile row /
+// column -- these launches are HBM-bound, the 128-wide kernel's doubled operand traffic is what they wait for.  Rows are 576 bytes.
+#define TN16B_ROWB 576
+static __device__ __forceinline__ bf16x8 tn16b_frag(const char* p) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + 4 * TN16B_ROWB));
+    return __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+__global__ __launch_bounds__(512, 1) void gemm_tn16x256_kernel(NuGemmTN g) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * TBK * TN16B_ROWB];
+    char* const sA = smem;
+    char* const sB = smem + TBK * TN16B_ROWB;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = tid >> 6;
+    const int wr = wid >> 1, wc = wid & 1;     // 8 waves as 4 (n1) x 2 (n2); wave tile 64 x 128
+    const int t2 = g.N2 / 256;
+    const int n1t = blockIdx.x / t2, n2t = blockIdx.x - n1t * t2;
+    const int split = blockIdx.y;
+    const int n1_0 = n1t * 256, n2_0 = n2t * 256;
+    const int grp = blockIdx.z;
+    const int N1p = g.N1, N2p = g.N2;                 // multiples of 256
+
+    int rows_per = (g.P + g.S - 1) / g.S;
+    rows_per = ((rows_per + TBK - 1) / TBK) * TBK;
+    const int p_begin = split * rows_per;
+    int p_end = p_begin + rows_per;
+    p_end = p_end < g.P ? p_end : g.P;
+    const int ntile = p_end > p_begin ? (p_end - p_begin + TBK - 1) / TBK : 0;
+    const int npair = g.A1 ? 2 : 1;
+    const int total = ntile * npair;
+
+    const int cg = tid & 31;        // 8-column group of the 256-wide operand tile
+    const int rr = tid >> 5;        // row inside a 16-row pass
+    const bool do_bias = (g.bias_slab != nullptr) && (n2t == 0);
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    uint4 ra[2][2], rb[2][2];       // [pass][half]: a bf16 operand uses half 0 only
+    int nvalid = 0;                 // rows of the pending chunk that exist (ragged tail of the last split)
+    bool pend_pair0 = true, pa16 = false, pb16 = false;
+    float bs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto load_tile = [&](int t) {
+        const int pair = t >= ntile ? 1 : 0;
+        const int kt = t - pair * ntile;
+        const bool a16 = (g.bf16 & (pair ? NU_TN_A1_16 : NU_TN_A0_16)) != 0;
+        const bool b16 = (g.bf16 & (pair ? NU_TN_B1_16 : NU_TN_B0_16)) != 0;
+        const int eA = a16 ? 2 : 4, eB = b16 ? 2 : 4;
+        const char* __restrict__ A = (const char*)(pair ? g.A1 : g.A0) + (long long)grp * (pair ? g.sA1 : g.sA0) * eA;
+        const char* __restrict__ B = (const char*)(pair ? g.B1 : g.B0) + (long long)grp * (pair ? g.sB1 : g.sB0) * eB;
+        const int lda = pair ? g.lda1 : g.lda0;
+        const int ldb = pair ? g.ldb1 : g.ldb0;
+        int ca = n1_0 + 8 * cg, cb = n2_0 + 8 * cg;
+        ca = ca <= lda - 8 ? ca : lda - 8;      // column groups past the operand only feed slab rows the reducer never reads
+        cb = cb <= ldb - 8 ? cb : ldb - 8;
+        const int pbase = p_begin + kt * TBK;
+        nvalid = p_end - pbase;
+        pend_pair0 = pair == 0;
+        pa16 = a16; pb16 = b16;
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            int pr = pbase + rr + 16 * ps;
+            pr = pr < p_end ? pr : p_end - 1;   // ragged tail: re-read the last row, zeroed at the hand-over
+            const char* pa = A + ((long long)pr * lda + ca) * eA;
+            const char* pb = B + ((long long)pr * ldb + cb) * eB;
+            ra[ps][0] = *reinterpret_cast<const uint4*>(pa);
+            if (!a16) ra[ps][1] = *reinterpret_cast<const uint4*>(pa + 16);
+            rb[ps][0] = *reinterpret_cast<const uint4*>(pb);
+            if (!b16) rb[ps][1] = *reinterpret_cast<const uint4*>(pb + 16);
+        }
+    };
+    auto pack8 = [](uint4 lo, uint4 hi) -> uint4 {       // 8 fp32 -> 8 bf16 (RNE)
+        const bf16x4 l = nu_to_bf16x4(__builtin_bit_cast(f32x4, lo)), h = nu_to_bf16x4(__builtin_bit_cast(f32x4, hi));
+        const uint2 l2 = __builtin_bit_cast(uint2, l), h2 = __builtin_bit_cast(uint2, h);
+        return make_uint4(l2.x, l2.y, h2.x, h2.y);
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            const bool ok = rr + 16 * ps < nvalid;
+            uint4 va = pa16 ? ra[ps][0] : pack8(ra[ps][0], ra[ps][1]);
+            uint4 vb = pb16 ? rb[ps][0] : pack8(rb[ps][0], rb[ps][1]);
+            if (do_bias && pend_pair0 && ok) {           // column sums of the operand as stored (fp32 operands: unrounded)
+                if (pa16) {
+                    const unsigned w[4] = {ra[ps][0].x, ra[ps][0].y, ra[ps][0].z, ra[ps][0].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        bs[2 * e] += __uint_as_float(w[e] << 16);
+                        bs[2 * e + 1] += __uint_as_float(w[e] & 0xffff0000u);
+                    }
+                } else {
+                    const f32x4 l = __builtin_bit_cast(f32x4, ra[ps][0]), h = __builtin_bit_cast(f32x4, ra[ps][1]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { bs[e] += l[e]; bs[4 + e] += h[e]; }
+                }
+            }
+            if (!ok) { va = make_uint4(0u, 0u, 0u, 0u); vb = va; }
+            *reinterpret_cast<uint4*>(sA + (rr + 16 * ps) * TN16B_ROWB + cg * 16) = va;
+            *reinterpret_cast<uint4*>(sB + (rr + 16 * ps) * TN16B_ROWB + cg * 16) = vb;
+        }
+    };
+
+    if (total > 0) {
+        load_tile(0);
+        store_tile();
+    }
+    __syncthreads();
+
+    const int li = lane & 31, lh = lane >> 5;
+    const int g4 = lane >> 4, tq = (lane & 15) >> 2, tc = lane & 3;
+    // transposed-read address of this lane: row 8 (g4 >> 1) + q of the k-step, columns 16 (g4 & 1) + 4 c of the 32-column tile
+    const int a_off = (8 * (g4 >> 1) + tq) * TN16B_ROWB + (wr * 64 + 16 * (g4 & 1) + 4 * tc) * 2;
+    const int b_off = (8 * (g4 >> 1) + tq) * TN16B_ROWB + (wc * 128 + 16 * (g4 & 1) + 4 * tc) * 2;
+    for (int t = 0; t < total; ++t) {
+        if (t + 1 < total) load_tile(t + 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const bf16x8 a0 = tn16b_frag(sA + a_off + ks * 16 * TN16B_ROWB);
+            const bf16x8 a1 = tn16b_frag(sA + a_off + ks * 16 * TN16B_ROWB + 64);
+            bf16x8 b[4];
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn) b[tn] = tn16b_frag(sB + b_off + ks * 16 * TN16B_ROWB + 64 * tn);
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn) {
+                acc[0][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b[tn], acc[0][tn], 0, 0, 0);
+                acc[1][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b[tn], acc[1][tn], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+        if (t + 1 < total) {
+            store_tile();
+            __syncthreads();
+        }
+    }
+
+    float* __restrict__ slab = g.slab + (long long)grp * g.sSlab + (long long)split * N1p * N2p;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) {
+            const int col = n2_0 + wc * 128 + tn * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = n1_0 + wr * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                slab[(long long)row * N2p + col] = acc[tm][tn][r];
+            }
+        }
+
+    if (do_bias) {                  // 16 row-threads hold partial sums of the same 8 columns
+        float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[rr * 256 + 8 * cg + e] = bs[e];
+        __syncthreads();
+        if (tid < 256) {
+            float sum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sum += red[r * 256 + tid];
+            g.bias_slab[(long long)grp * g.sBiasSlab + (long long)split * N1p + n1_0 + tid] = sum;
+        }
+    }
+}
+
+
 // ------------------------------------------------------------------------------------------------
 // TN kernel, exact fp32, 256 x 256 output tile per workgroup (512 threads, 8 waves as 4 x 2, each wave 64 x 128 = 2 x 4
 // MFMA tiles, 128 accumulator VGPRs; one workgroup per CU).  For the dominant weight-gradient shape (N1, N2 multiples of
@@ -1770,7 +1941,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(NuGemmTN g) {
 extern "C" int nu_wgrad_pick_split(int P, int N1, int N2, int groups, int prec) {
     if (groups < 1) groups = 1;
     static const bool tn128_env = getenv("NU_TN_128") && atoi(getenv("NU_TN_128")) != 0;      // development switch (see the launcher)
-    const bool big_tile = prec == 0 && !tn128_env && (N1 % 256) == 0 && (N2 % 256) == 0;
+    const bool big_tile = (prec & 3) != 2 && !tn128_env && (N1 % 256) == 0 && (N2 % 256) == 0;
     const int tiles = big_tile ? (N1 / 256) * (N2 / 256) * groups : nu_cdiv(N1, 128) * nu_cdiv(N2, 128) * groups;
     int S = (big_tile ? 256 : 512) / tiles;
     if (S < 1) S = 1;
@@ -1805,7 +1976,12 @@ int nu_gemm_tn_launch(const NuGemmTN& g, hipStream_t stream) {
                          ((g.sA0 | g.sB0 | g.sA1 | g.sB1) & 7) == 0;
         static const bool tn_scalar_env = getenv("NU_TN_SCALAR") && atoi(getenv("NU_TN_SCALAR")) != 0;      // development switch
         if (vec && !tn_scalar_env) {
-            hipLaunchKernelGGL(gemm_tn16_kernel, grid, block, 0, stream, g);
+            if (!tn128_env && (g.N1 % 256) == 0 && (g.N2 % 256) == 0) {
+                dim3 grid2((g.N1 / 256) * (g.N2 / 256), g.S, g.groups > 0 ? g.groups : 1);
+                hipLaunchKernelGGL(gemm_tn16x256_kernel, grid2, dim3(512), 0, stream, g);
+            } else {
+                hipLaunchKernelGGL(gemm_tn16_kernel, grid, block, 0, stream, g);
+            }
             return nu_launch_status();
         }
     }

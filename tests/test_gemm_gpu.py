@@ -223,7 +223,7 @@ def test_bf16_nt_matches_bf16_rounded_operands(gpu, M, N, K):
         assert (ref - exact).abs().max() > 1e-4
 
 
-@pytest.mark.parametrize("P,N1,N2,S", [(1000, 257, 256, 7), (5000, 256, 39, 16), (333, 3, 256, 4)])
+@pytest.mark.parametrize("P,N1,N2,S", [(1000, 257, 256, 7), (5000, 256, 39, 16), (333, 3, 256, 4), (4000, 256, 256, 8)])
 def test_bf16_tn_weight_grad(gpu, P, N1, N2, S):
     from nu_nerf_amd import _lib as L
     from nu_nerf_amd.engine import GemmTN, addr
@@ -332,7 +332,8 @@ def test_bf16_storage_nt_grouped_and_sign_bits(gpu):
     torch.testing.assert_close(out.double(), want, rtol=8e-3, atol=1e-3)
 
 
-@pytest.mark.parametrize("P,N1,N2,S,flags", [(1000, 257, 256, 7, 16 | 32 | 64 | 128), (5000, 256, 96, 16, 16 | 128), (333, 3, 256, 4, 32 | 64)])
+@pytest.mark.parametrize("P,N1,N2,S,flags", [(1000, 257, 256, 7, 16 | 32 | 64 | 128), (5000, 256, 96, 16, 16 | 128), (333, 3, 256, 4, 32 | 64),
+                                             (3001, 256, 256, 5, 16 | 32 | 64 | 128), (2000, 512, 256, 3, 32 | 64), (777, 256, 512, 2, 0)])
 def test_bf16_storage_tn_weight_grad(gpu, P, N1, N2, S, flags):
     from nu_nerf_amd import _lib as L
     from nu_nerf_amd.engine import GemmTN, addr
