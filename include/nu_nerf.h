@@ -388,6 +388,33 @@ int nu_loss_bwd(const float* rgb, const float* acc, const float* rgb_bg, const f
                 hipStream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * Stage 2 (zero-thickness Stage2Renderer, network/renderer_zerothick.py:1571-2011): kernels of the renderer's own logic.
+ * A segment is a set of N rays with S1 nodes x_{n,j} = start_n + v_n * z_{n,j}; its S = S1 - 1 samples sit at the nodes
+ * j < S, section length |x_{j+1} - x_j| (the last one repeats its predecessor).
+ *   nu_s2_seg_count / nu_s2_seg_write   outer samples (|x| > 1) compacted in (ray, sample) order into 32-byte point records
+ *                                       (x, dist, dir) for nu_nerfpp_mlp_fwd; idx = ray-major scatter target (idx_base + n S + j),
+ *                                       pos_rm = compact index per (ray, sample) or -1          (:1835-1870)
+ *   nu_s2_ddist                         d alpha / d dist of compute_density_alpha               (:1531-1540)
+ *   nu_s2_seg_bwd                       cotangents of the point records -> d start, d v, d dirs
+ *   nu_s2_composite_fwd / _bwd          linear-RGB composite with the running transmittance     (:1976-1990); colour [N,S,4] sRGB
+ *   nu_s2_refract_fwd / _bwd            Snell refraction / total internal reflection per hit ray (:1642-1684)
+ * --------------------------------------------------------------------------------------------------------- */
+int nu_s2_seg_count(const float* start, const float* v, const float* z, int N, int S1, int* cnt, int* off, int* total, hipStream_t stream);
+int nu_s2_seg_write(const float* start, const float* v, const float* z, const float* dirs, int N, int S1, const int* off, int pt_base,
+                    int idx_base, float* pt, int* idx, int* pos_rm, hipStream_t stream);
+int nu_s2_ddist(const float* sigma, const float* pt, const int* idx, int P, const float* dalpha_rm, float* ddist, hipStream_t stream);
+int nu_s2_seg_bwd(const float* start, const float* v, const float* z, int N, int S1, int idx_base, const int* pos_rm, const float* dx,
+                  const float* ddist, const float* ddir, float* dstart, float* dv, float* ddirs, hipStream_t stream);
+int nu_s2_composite_fwd(const float* alpha, const float* color, const float* Tin, int N, int S, float* out, float* Tout, hipStream_t stream);
+int nu_s2_composite_bwd(const float* alpha, const float* color, const float* Tin, int N, int S, const float* dout, const float* dTout,
+                        float* dalpha, float* dcolor, float* dTin, hipStream_t stream);
+int nu_s2_refract_fwd(const float* d, const float* nrm, const float* ior, const float* point, int M, int outside, unsigned char* flag,
+                      float* eta, float* nd, float* ns, hipStream_t stream);
+int nu_s2_refract_bwd(const float* d, const float* nrm, const float* ior, int M, int outside, const float* g_nd, const float* g_ns,
+                      const float* g_eta, float* dd, float* dn, float* dior, float* dpoint, hipStream_t stream);
+
+
+/* ---------------------------------------------------------------------------------------------------------
  * Trainer glue: torch.optim.Adam's update (train/trainer_zero.py:74-85, lr from
  * train/lr_common_manager.py:22-46) over many parameter tensors in one launch per NU_ADAM_MAX tensors.
  * p, g, m (exp_avg), v (exp_avg_sq): contiguous fp32 of n elements; step >= 1 is the count AFTER this update.

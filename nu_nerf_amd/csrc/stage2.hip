@@ -1,0 +1,506 @@
+// stage2.hip -- kernels of the stage-2 renderer's own logic (zero-thickness variant): per-segment sample bookkeeping, the
+// multi-segment linear-RGB composite with a running transmittance, and the refraction bounce -- forward and hand-derived
+// backward (stage 2 needs d L / d position: every sample position depends on the learned index of refraction).
+//
+// Reference code replaced (paths relative to /root/reference):
+//   Stage2Renderer.render_core   network/renderer_zerothick.py:1835-2011   (segment points, dists, inner/outer split, composite)
+//   Stage2Renderer.ray_trace     network/renderer_zerothick.py:1571-1828   (refraction, total internal reflection, next origin)
+//   compute_density_alpha        network/renderer_zerothick.py:1531-1540
+//
+// A SEGMENT is a set of rays n with S1 nodes x_{n,j} = start_n + v_n * z_{n,j} (j = 0 .. S1-1; z carries no gradient: linspace,
+// or the no-grad inverse-CDF samplers).  Its S = S1 - 1 samples sit AT the nodes j < S (`pfn = cp[:, :-1]`), with section length
+// dist_j = |x_{j+1} - x_j| for j < S - 1 and dist_{S-1} = dist_{S-2} (`cat([dists, dists[..., -1:]])`).
+#include "nu_common.h"
+#include "nu_nerf.h"
+
+#define NU_PT 8   // floats per point record: x(3), dist, unit direction(3), pad (as csrc/render.hip)
+
+static __device__ inline float s2_norm3(const float* x) {
+#pragma clang fp contract(off)
+    return sqrtf((x[0] * x[0] + x[1] * x[1]) + x[2] * x[2]);
+}
+// node position, rounded like the reference's eager `start + v * z` (the inner/outer decision |x| <= 1 depends on it)
+static __device__ inline void s2_node(const float* st, const float* v, float z, float* x) {
+#pragma clang fp contract(off)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float m = v[c] * z;
+        x[c] = st[c] + m;
+    }
+}
+static __device__ inline float s2_dist(const float* a, const float* b) {
+#pragma clang fp contract(off)
+    const float d[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]};
+    return s2_norm3(d);
+}
+
+// ------------------------------------------------------------------------------------------------
+// outer points of a segment (|x| > 1), compacted in (ray, sample) order -- the order boolean-mask indexing gives
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void s2_seg_count_kernel(const float* __restrict__ start, const float* __restrict__ v,
+                                                           const float* __restrict__ z, int N, int S1, int* __restrict__ cnt) {
+    const int lane = threadIdx.x & 63;
+    const int n = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (n >= N) return;
+    const int S = S1 - 1;
+    float st[3], vv[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { st[c] = start[n * 3LL + c]; vv[c] = v[n * 3LL + c]; }
+    int k = 0;
+    for (int j = lane; j < S; j += 64) {
+        float x[3];
+        s2_node(st, vv, z[(long long)n * S1 + j], x);
+        k += s2_norm3(x) <= 1.0f ? 0 : 1;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) k += __shfl_xor(k, off, 64);
+    if (lane == 0) cnt[n] = k;
+}
+
+// single-block exclusive scan (n <= 1M) + total
+__global__ __launch_bounds__(1024) void s2_scan_kernel(const int* __restrict__ in, int n, int* __restrict__ out, int* __restrict__ total) {
+    __shared__ int part[1024];
+    const int tid = threadIdx.x;
+    const int per = (n + 1023) / 1024;
+    const int b = tid * per;
+    int e = b + per;
+    e = e < n ? e : n;
+    int s = 0;
+    for (int i = b; i < e; ++i) s += in[i];
+    part[tid] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int t = tid >= off ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += t;
+        __syncthreads();
+    }
+    int run = tid ? part[tid - 1] : 0;
+    for (int i = b; i < e; ++i) {
+        out[i] = run;
+        run += in[i];
+    }
+    if (tid == 1023) total[0] = part[1023];
+}
+
+__global__ __launch_bounds__(256) void s2_seg_write_kernel(const float* __restrict__ start, const float* __restrict__ v,
+                                                           const float* __restrict__ z, const float* __restrict__ dirs, int N, int S1,
+                                                           const int* __restrict__ off, int pt_base, int idx_base,
+                                                           float* __restrict__ pt, int* __restrict__ idx, int* __restrict__ pos_rm) {
+    const int lane = threadIdx.x & 63;
+    const int n = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (n >= N) return;
+    const int S = S1 - 1;
+    float st[3], vv[3], dd[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { st[c] = start[n * 3LL + c]; vv[c] = v[n * 3LL + c]; dd[c] = dirs[n * 3LL + c]; }
+    const float* zr = z + (long long)n * S1;
+    int base = pt_base + off[n];
+    for (int j0 = 0; j0 < S; j0 += 64) {
+        const int j = j0 + lane;
+        float x[3] = {0.f, 0.f, 0.f}, dist = 0.f;
+        bool outer = false;
+        if (j < S) {
+            s2_node(st, vv, zr[j], x);
+            outer = !(s2_norm3(x) <= 1.0f);
+            if (S >= 2) {                            // dist_j = |x_{j+1} - x_j|, the last one repeats its predecessor
+                const int ja = j < S - 1 ? j : S - 2;
+                float xa[3], xb[3];
+                s2_node(st, vv, zr[ja], xa);
+                s2_node(st, vv, zr[ja + 1], xb);
+                dist = s2_dist(xa, xb);
+            }
+        }
+        const unsigned long long m = __ballot(outer);
+        const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
+        if (j < S) {
+            const int flat = idx_base + n * S + j;
+            int k = -1;
+            if (outer) {
+                k = base + __popcll(m & below);
+                idx[k] = flat;
+                float* rec = pt + (long long)k * NU_PT;
+                *reinterpret_cast<f32x4*>(rec) = f32x4{x[0], x[1], x[2], dist};
+                *reinterpret_cast<f32x4*>(rec + 4) = f32x4{dd[0], dd[1], dd[2], 0.f};
+            }
+            pos_rm[flat] = k;
+        }
+        base += __popcll(m);
+    }
+}
+
+extern "C" int nu_s2_seg_count(const float* start, const float* v, const float* z, int N, int S1, int* cnt, int* off, int* total,
+                               hipStream_t stream) {
+    if (N <= 0 || S1 < 2 || N > (1 << 20)) return NU_ERR_ARG;
+    hipLaunchKernelGGL(s2_seg_count_kernel, dim3(nu_cdiv(N, 4)), dim3(256), 0, stream, start, v, z, N, S1, cnt);
+    hipLaunchKernelGGL(s2_scan_kernel, dim3(1), dim3(1024), 0, stream, cnt, N, off, total);
+    return nu_launch_status();
+}
+extern "C" int nu_s2_seg_write(const float* start, const float* v, const float* z, const float* dirs, int N, int S1, const int* off,
+                               int pt_base, int idx_base, float* pt, int* idx, int* pos_rm, hipStream_t stream) {
+    if (N <= 0 || S1 < 2) return NU_ERR_ARG;
+    hipLaunchKernelGGL(s2_seg_write_kernel, dim3(nu_cdiv(N, 4)), dim3(256), 0, stream, start, v, z, dirs, N, S1, off, pt_base,
+                       idx_base, pt, idx, pos_rm);
+    return nu_launch_status();
+}
+
+// d alpha / d dist of compute_density_alpha (alpha = 1 - exp(-softplus(sigma) dist)); the sigma / rgb parts are nu_nerf_act_bwd
+__global__ __launch_bounds__(256) void s2_ddist_kernel(const float* __restrict__ sigma, const float* __restrict__ pt,
+                                                       const int* __restrict__ idx, int P, const float* __restrict__ dalpha_rm,
+                                                       float* __restrict__ ddist) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const float s = sigma[p];
+    const float sp = s > 20.f ? s : log1pf(expf(s));
+    ddist[p] = dalpha_rm[idx[p]] * expf(-sp * pt[(long long)p * NU_PT + 3]) * sp;
+}
+extern "C" int nu_s2_ddist(const float* sigma, const float* pt, const int* idx, int P, const float* dalpha_rm, float* ddist,
+                           hipStream_t stream) {
+    if (P <= 0) return NU_OK;
+    hipLaunchKernelGGL(s2_ddist_kernel, dim3(nu_cdiv(P, 256)), dim3(256), 0, stream, sigma, pt, idx, P, dalpha_rm, ddist);
+    return nu_launch_status();
+}
+
+// backward of the sample bookkeeping: cotangents of the compacted point records -> d start, d v, d dirs (one wave per ray)
+__global__ __launch_bounds__(256) void s2_seg_bwd_kernel(const float* __restrict__ start, const float* __restrict__ v,
+                                                         const float* __restrict__ z, int N, int S1, int idx_base,
+                                                         const int* __restrict__ pos_rm, const float* __restrict__ dx,
+                                                         const float* __restrict__ ddist, const float* __restrict__ ddir,
+                                                         float* __restrict__ dstart, float* __restrict__ dv, float* __restrict__ ddirs) {
+    const int lane = threadIdx.x & 63;
+    const int n = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (n >= N) return;
+    const int S = S1 - 1;
+    float st[3], vv[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { st[c] = start[n * 3LL + c]; vv[c] = v[n * 3LL + c]; }
+    const float* zr = z + (long long)n * S1;
+    float gs[3] = {0.f, 0.f, 0.f}, gv[3] = {0.f, 0.f, 0.f}, gd[3] = {0.f, 0.f, 0.f};
+    for (int j = lane; j < S; j += 64) {
+        const int k = pos_rm[idx_base + n * S + j];
+        if (k < 0) continue;
+        const float zj = zr[j];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float g = dx[k * 3LL + c];
+            gs[c] += g;
+            gv[c] += g * zj;
+            gd[c] += ddir[k * 3LL + c];
+        }
+        if (S >= 2) {
+            const int ja = j < S - 1 ? j : S - 2;
+            float xa[3], xb[3];
+            s2_node(st, vv, zr[ja], xa);
+            s2_node(st, vv, zr[ja + 1], xb);
+            const float dist = s2_dist(xa, xb);
+            if (dist > 0.f) {
+                const float s = ddist[k] / dist, dz = zr[ja + 1] - zr[ja];
+                // +g u at node ja+1, -g u at node ja: d start cancels, d v gets g u (z_{ja+1} - z_ja)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) gv[c] += s * (xb[c] - xa[c]) * dz;
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { gs[c] = nu_wave_sum(gs[c]); gv[c] = nu_wave_sum(gv[c]); gd[c] = nu_wave_sum(gd[c]); }
+    if (lane == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { dstart[n * 3LL + c] = gs[c]; dv[n * 3LL + c] = gv[c]; ddirs[n * 3LL + c] = gd[c]; }
+    }
+}
+extern "C" int nu_s2_seg_bwd(const float* start, const float* v, const float* z, int N, int S1, int idx_base, const int* pos_rm,
+                             const float* dx, const float* ddist, const float* ddir, float* dstart, float* dv, float* ddirs,
+                             hipStream_t stream) {
+    if (N <= 0 || S1 < 2) return NU_ERR_ARG;
+    hipLaunchKernelGGL(s2_seg_bwd_kernel, dim3(nu_cdiv(N, 4)), dim3(256), 0, stream, start, v, z, N, S1, idx_base, pos_rm, dx, ddist,
+                       ddir, dstart, dv, ddirs);
+    return nu_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Segment composite (renderer_zerothick.py:1976-1990): colours arrive in sRGB, the sum runs in LINEAR RGB,
+//   w_j = alpha_j prod_{k<j}(1 - alpha_k + 1e-7);  colour = T_in * sum_j w_j lin(c_j);  T_out = T_in * prod_j (1 - alpha_j + 1e-7)
+// ------------------------------------------------------------------------------------------------
+static __device__ inline float s2_srgb_to_linear(float s) {
+    const float eps = 1.1920928955078125e-07f;
+    return s <= 0.04045f ? (25.0f / 323.0f) * s : powf(fmaxf((200.0f * s + 11.0f) / 211.0f, eps), 12.0f / 5.0f);
+}
+static __device__ inline float s2_srgb_to_linear_grad(float s) {
+    const float eps = 1.1920928955078125e-07f;
+    if (s <= 0.04045f) return 25.0f / 323.0f;
+    const float b = (200.0f * s + 11.0f) / 211.0f;
+    return b < eps ? 0.0f : (12.0f / 5.0f) * powf(b, 7.0f / 5.0f) * (200.0f / 211.0f);
+}
+static __device__ inline float s2_wave_excl_prod(float v, int lane) {
+    const float inc = nu_wave_incl_prod(v, lane);
+    const float ex = __shfl_up(inc, 1, 64);
+    return lane == 0 ? 1.0f : ex;
+}
+static __device__ inline float s2_wave_excl_suffix_sum(float v, int lane) {
+    float inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float t = __shfl_down(inc, o, 64);
+        if (lane + o < 64) inc += t;
+    }
+    return inc - v;
+}
+
+template <int CH>
+__global__ __launch_bounds__(256) void s2_composite_fwd_kernel(const float* __restrict__ alpha, const float* __restrict__ color,
+                                                               const float* __restrict__ Tin, int N, int S,
+                                                               float* __restrict__ out, float* __restrict__ Tout) {
+    const int lane = threadIdx.x & 63;
+    const int n = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (n >= N) return;
+    const long long base = (long long)n * S;
+    float a[CH];
+    float pl = 1.f;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+        const int j = lane * CH + i;
+        a[i] = j < S ? alpha[base + j] : 0.f;
+        if (j < S) pl *= (1.0f - a[i] + 1e-7f);
+    }
+    const float tot = nu_wave_incl_prod(pl, lane);
+    float T = s2_wave_excl_prod(pl, lane);
+    float s[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+        const int j = lane * CH + i;
+        if (j < S) {
+            const float w = a[i] * T;
+            const f32x4 c = *reinterpret_cast<const f32x4*>(color + (base + j) * 4);
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) s[ch] += w * s2_srgb_to_linear(c[ch]);
+            T *= (1.0f - a[i] + 1e-7f);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) s[c] = nu_wave_sum(s[c]);
+    const float tend = __shfl(tot, 63, 64);
+    if (lane == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float t = Tin[n * 3LL + c];
+            out[n * 3LL + c] = s[c] * t;
+            Tout[n * 3LL + c] = t * tend;
+        }
+    }
+}
+
+template <int CH>
+__global__ __launch_bounds__(256) void s2_composite_bwd_kernel(const float* __restrict__ alpha, const float* __restrict__ color,
+                                                               const float* __restrict__ Tin, int N, int S,
+                                                               const float* __restrict__ dout, const float* __restrict__ dTout,
+                                                               float* __restrict__ dalpha, float* __restrict__ dcolor,
+                                                               float* __restrict__ dTin) {
+    const int lane = threadIdx.x & 63;
+    const int n = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (n >= N) return;
+    const long long base = (long long)n * S;
+    float tin[3], go[3], gt[3], G[3];
+    float gtend = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        tin[c] = Tin[n * 3LL + c];
+        go[c] = dout ? dout[n * 3LL + c] : 0.f;
+        gt[c] = dTout ? dTout[n * 3LL + c] : 0.f;
+        G[c] = go[c] * tin[c];
+        gtend += gt[c] * tin[c];
+    }
+    float a[CH], gw[CH], Tj[CH];
+    float pl = 1.f;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+        const int j = lane * CH + i;
+        a[i] = j < S ? alpha[base + j] : 0.f;
+        if (j < S) pl *= (1.0f - a[i] + 1e-7f);
+    }
+    const float tend = __shfl(nu_wave_incl_prod(pl, lane), 63, 64);
+    float T = s2_wave_excl_prod(pl, lane);
+    float ls = 0.f, cs[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+        const int j = lane * CH + i;
+        Tj[i] = T;
+        gw[i] = 0.f;
+        if (j < S) {
+            const f32x4 c = *reinterpret_cast<const f32x4*>(color + (base + j) * 4);
+            const float w = a[i] * T;
+            f32x4 dc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                const float lin = s2_srgb_to_linear(c[ch]);
+                gw[i] += G[ch] * lin;
+                cs[ch] += w * lin;
+                dc[ch] = w * G[ch] * s2_srgb_to_linear_grad(c[ch]);
+            }
+            *reinterpret_cast<f32x4*>(dcolor + (base + j) * 4) = dc;
+            ls += gw[i] * w;
+            T *= (1.0f - a[i] + 1e-7f);
+        }
+    }
+    // d alpha_j = T_j gw_j - (sum_{k>j} gw_k w_k + gtend T_end) / (1 - alpha_j + 1e-7)
+    float suf = s2_wave_excl_suffix_sum(ls, lane) + gtend * tend;
+#pragma unroll
+    for (int i = CH - 1; i >= 0; --i) {
+        const int j = lane * CH + i;
+        if (j < S) {
+            dalpha[base + j] = Tj[i] * gw[i] - suf / (1.0f - a[i] + 1e-7f);
+            suf += gw[i] * a[i] * Tj[i];
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) cs[c] = nu_wave_sum(cs[c]);
+    if (lane == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) dTin[n * 3LL + c] = go[c] * cs[c] + gt[c] * tend;
+    }
+}
+
+extern "C" int nu_s2_composite_fwd(const float* alpha, const float* color, const float* Tin, int N, int S, float* out, float* Tout,
+                                   hipStream_t stream) {
+    if (N <= 0 || S <= 0 || S > 256) return NU_ERR_ARG;
+    dim3 grid(nu_cdiv(N, 4)), block(256);
+#define NU_CASE(c) case c: hipLaunchKernelGGL(s2_composite_fwd_kernel<c>, grid, block, 0, stream, alpha, color, Tin, N, S, out, Tout); break;
+    switch (nu_cdiv(S, 64)) { NU_CASE(1) NU_CASE(2) NU_CASE(3) NU_CASE(4) default: return NU_ERR_ARG; }
+#undef NU_CASE
+    return nu_launch_status();
+}
+extern "C" int nu_s2_composite_bwd(const float* alpha, const float* color, const float* Tin, int N, int S, const float* dout,
+                                   const float* dTout, float* dalpha, float* dcolor, float* dTin, hipStream_t stream) {
+    if (N <= 0 || S <= 0 || S > 256) return NU_ERR_ARG;
+    dim3 grid(nu_cdiv(N, 4)), block(256);
+#define NU_CASE(c) case c: hipLaunchKernelGGL(s2_composite_bwd_kernel<c>, grid, block, 0, stream, alpha, color, Tin, N, S, dout, dTout, dalpha, dcolor, dTin); break;
+    switch (nu_cdiv(S, 64)) { NU_CASE(1) NU_CASE(2) NU_CASE(3) NU_CASE(4) default: return NU_ERR_ARG; }
+#undef NU_CASE
+    return nu_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Refraction bounce (renderer_zerothick.py:1642-1684), one thread per ray that hit the mesh.
+//   nrm: unit surface normal facing the incoming ray (the caller flips it inside the object); d: incoming direction;
+//   ior: the IoR network's output in (0, 1); eta = 1 / (ior + 1) entering, ior + 1 leaving.
+//   cos_i = -n.d;  k = 1 - eta^2 (1 - cos_i^2);  refract = !(eta^2 (1 - cos_i^2) > 0.999)
+//   t = eta d + (eta cos_i - sqrt(k)) n;  next origin = point + 1e-5 t;  next direction = t / (|t| + 1e-4)
+// Outputs for every hit ray (total internal reflection: flag 0, outputs zero); the backward returns d d, d nrm, d ior, d point.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void s2_refract_fwd_kernel(const float* __restrict__ d, const float* __restrict__ nrm,
+                                                             const float* __restrict__ ior, const float* __restrict__ point, int M,
+                                                             int outside, unsigned char* __restrict__ flag, float* __restrict__ eta_out,
+                                                             float* __restrict__ nd, float* __restrict__ ns) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    const float dd[3] = {d[m * 3LL], d[m * 3LL + 1], d[m * 3LL + 2]};
+    const float nn[3] = {nrm[m * 3LL], nrm[m * 3LL + 1], nrm[m * 3LL + 2]};
+    const float cos_i = -(nn[0] * dd[0] + nn[1] * dd[1] + nn[2] * dd[2]);
+    const float sin2_i = 1.0f - cos_i * cos_i;
+    float eta = 1.0f / (ior[m] * 1.0f + 1.0f);
+    if (!outside) eta = 1.0f / eta;
+    const bool refr = !(eta * eta * sin2_i > 0.999f);
+    flag[m] = refr ? 1 : 0;
+    eta_out[m] = eta;
+    float t[3] = {0.f, 0.f, 0.f}, o[3] = {0.f, 0.f, 0.f}, u[3] = {0.f, 0.f, 0.f};
+    if (refr) {
+        const float sin2_t = sin2_i * eta * eta;
+        const float f = eta * cos_i - sqrtf(1.0f - sin2_t);
+        float len2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            t[c] = eta * dd[c] + f * nn[c];
+            o[c] = point[m * 3LL + c] + t[c] * 1e-5f;
+            len2 += t[c] * t[c];
+        }
+        const float inv = 1.0f / (sqrtf(len2) + 0.0001f);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) u[c] = t[c] * inv;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { nd[m * 3LL + c] = u[c]; ns[m * 3LL + c] = o[c]; }
+}
+
+__global__ __launch_bounds__(256) void s2_refract_bwd_kernel(const float* __restrict__ d, const float* __restrict__ nrm,
+                                                             const float* __restrict__ ior, int M, int outside,
+                                                             const float* __restrict__ g_nd, const float* __restrict__ g_ns,
+                                                             const float* __restrict__ g_eta, float* __restrict__ dd_out,
+                                                             float* __restrict__ dn_out, float* __restrict__ dior,
+                                                             float* __restrict__ dpoint) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    const float dd[3] = {d[m * 3LL], d[m * 3LL + 1], d[m * 3LL + 2]};
+    const float nn[3] = {nrm[m * 3LL], nrm[m * 3LL + 1], nrm[m * 3LL + 2]};
+    const float cos_i = -(nn[0] * dd[0] + nn[1] * dd[1] + nn[2] * dd[2]);
+    const float sin2_i = 1.0f - cos_i * cos_i;
+    const float b = ior[m] * 1.0f + 1.0f;
+    const float eta = outside ? 1.0f / b : b;
+    const bool refr = !(eta * eta * sin2_i > 0.999f);
+    float gd[3] = {0.f, 0.f, 0.f}, gn[3] = {0.f, 0.f, 0.f}, gp[3] = {0.f, 0.f, 0.f};
+    float geta = g_eta ? g_eta[m] : 0.f;      // the ratio itself is an output (ior_ratios); cotangent of non-refracting rays is zero
+    if (refr) {
+        const float sin2_t = sin2_i * eta * eta;
+        const float root = sqrtf(1.0f - sin2_t);
+        const float f = eta * cos_i - root;
+        float t[3], len2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { t[c] = eta * dd[c] + f * nn[c]; len2 += t[c] * t[c]; }
+        const float len = sqrtf(len2), den = len + 0.0001f;
+        // u = t / den: g_t = g_u / den - (g_u . t) t / (den^2 len)   (+ 1e-5 g_o)
+        float gu_t = 0.f;
+        float gu[3], go[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            gu[c] = g_nd ? g_nd[m * 3LL + c] : 0.f;
+            go[c] = g_ns ? g_ns[m * 3LL + c] : 0.f;
+            gu_t += gu[c] * t[c];
+            gp[c] = go[c];
+        }
+        float gt[3];
+        const float k2 = len > 0.f ? gu_t / (den * den * len) : 0.f;
+        float gf = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            gt[c] = gu[c] / den - k2 * t[c] + 1e-5f * go[c];
+            gd[c] = eta * gt[c];
+            gn[c] = f * gt[c];
+            geta += gt[c] * dd[c];
+            gf += gt[c] * nn[c];
+        }
+        // f = eta cos_i - sqrt(1 - sin2_i eta^2);  sin2_i = 1 - cos_i^2
+        const float groot = -gf;
+        const float gs2t = root > 0.f ? -0.5f * groot / root : 0.f;
+        float gcos = gf * eta;
+        geta += gf * cos_i + gs2t * sin2_i * 2.0f * eta;
+        const float gs2i = gs2t * eta * eta;
+        gcos += gs2i * (-2.0f * cos_i);
+        // cos_i = -(n . d)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            gd[c] += -gcos * nn[c];
+            gn[c] += -gcos * dd[c];
+        }
+    }
+    // eta = 1 / b (entering) or b (leaving); b = ior + 1
+    dior[m] = outside ? -geta / (b * b) : geta;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        dd_out[m * 3LL + c] = gd[c];
+        dn_out[m * 3LL + c] = gn[c];
+        dpoint[m * 3LL + c] = gp[c];
+    }
+}
+
+extern "C" int nu_s2_refract_fwd(const float* d, const float* nrm, const float* ior, const float* point, int M, int outside,
+                                 unsigned char* flag, float* eta, float* nd, float* ns, hipStream_t stream) {
+    if (M <= 0) return NU_OK;
+    hipLaunchKernelGGL(s2_refract_fwd_kernel, dim3(nu_cdiv(M, 256)), dim3(256), 0, stream, d, nrm, ior, point, M, outside, flag, eta, nd, ns);
+    return nu_launch_status();
+}
+extern "C" int nu_s2_refract_bwd(const float* d, const float* nrm, const float* ior, int M, int outside, const float* g_nd,
+                                 const float* g_ns, const float* g_eta, float* dd, float* dn, float* dior, float* dpoint,
+                                 hipStream_t stream) {
+    if (M <= 0) return NU_OK;
+    hipLaunchKernelGGL(s2_refract_bwd_kernel, dim3(nu_cdiv(M, 256)), dim3(256), 0, stream, d, nrm, ior, M, outside, g_nd, g_ns, g_eta, dd,
+                       dn, dior, dpoint);
+    return nu_launch_status();
+}

@@ -19,6 +19,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _lib as L
+from . import stage2_ops as O
 from . import torch_glue as G
 from .engine import Stage1Engine, addr
 from .lbvh import Scene
@@ -228,7 +229,8 @@ class Stage2Renderer(nn.Module):
 
     # ---- ray_trace --------------------------------------------------------------------------------
     def ray_trace(self, rays_o, rays_d):
-        """Up to 3 refraction bounces against the mesh + per-segment sample placement (renderer_zerothick.py:1571-1828)."""
+        """Up to 3 refraction bounces against the mesh + per-segment sample placement (renderer_zerothick.py:1571-1828).
+        Segments come back as (start, v, z): nodes x_j = start + v * z_j (z without gradient), never materialised here."""
         n1, n2 = self.nets()
         scene, dev = self.scene, rays_o.device
         next_start, next_dir = rays_o, rays_d
@@ -244,23 +246,13 @@ class Stage2Renderer(nn.Module):
             normal = F.normalize(inter['n'], dim=-1) if outside else -F.normalize(inter['n'], dim=-1)
             infinity_bkgr.append(~converged)
             mask = converged.flatten()
-            cos_i = torch.sum(normal * -next_dir[mask], dim=-1, keepdim=True)
-            sin2_i = 1 - cos_i * cos_i
-            ratio = 1 / (self.IORs_pred(point.reshape(-1, 3)).reshape(-1, 1) * 1.0 + 1)
-            if not outside:
-                ratio = 1 / ratio
-            refr = ~(ratio * ratio * sin2_i > 0.999)
+            ior = self.IORs_pred(point.reshape(-1, 3)).reshape(-1)
+            refr, eta, nd_all, ns_all = O.refract(n1.eng, next_dir[mask], normal, ior, point, outside)   # HIP, fwd + bwd
             converged_out = converged.clone()
-            converged_out[mask] = refr
-            tir[mask] = refr.detach()
+            converged_out[mask] = refr[:, None]
+            tir[mask] = refr[:, None]
             tirs.append(tir)
-            sel = refr.flatten()
-            ratio = ratio[sel]
-            sin2_t = sin2_i[sel] * ratio * ratio
-            nd = ratio * next_dir[converged_out.flatten()] + (ratio * cos_i[sel] - torch.sqrt(1 - sin2_t)) * normal[sel]
-            ns = point[sel] + nd * 1e-5
-            nd = nd / (torch.linalg.norm(nd, dim=-1, keepdim=True) + 0.0001)
-            gm = normal[sel]
+            nd, ns, ratio, gm = nd_all[refr], ns_all[refr], eta[refr][:, None], normal[refr]
             next_dir, next_start = nd, ns
             directions.append(nd)
             starts.append(ns)
@@ -278,21 +270,17 @@ class Stage2Renderer(nn.Module):
         for k in range(len(converges)):
             start = starts[k].reshape(-1, 3)
             dk = directions[k]
-            end = start + dk * 4.5
+            N = start.shape[0]
+            S1 = 256 if k != 1 else 128
             hitk = ~infinity_bkgr[k].flatten()
-            z = torch.linspace(0, 1, 256 if k != 1 else 128, device=dev)
-            sv = start[:, None, :] + (end - start)[:, None, :] * z[None, :, None]
+            v = (start + dk * 4.5) - start                      # rounded like the reference's end - start
+            z = torch.linspace(0, 1, S1, device=dev)[None, :].repeat(N, 1)
             if hitk.any():
-                end = end.clone()
-                end[hitk] = intersections[k]
-                sh, eh = start[hitk], end[hitk]
-                sv = sv.clone()
-                if k != 1:
-                    sv[hitk] = sh[:, None, :] + (eh - sh)[:, None, :] * z[None, :, None]
-                else:
+                sh, eh = start[hitk], intersections[k]
+                v = v.index_put((hitk,), eh - sh)
+                if k == 1:
                     with torch.no_grad():
-                        zz = self._upsample_inner(n2, sh.detach(), dk[hitk].detach(), eh.detach())
-                    sv[hitk] = sh[:, None, :] + (eh - sh)[:, None, :] * zz[..., None]
+                        z[hitk] = self._upsample_inner(n2, sh.detach(), dk[hitk].detach(), eh.detach())
             if (~hitk).any() and k != 1:
                 miss = ~hitk
                 sm, dm = start[miss], dk[miss]
@@ -308,16 +296,22 @@ class Stage2Renderer(nn.Module):
                     alpha = alpha.reshape(M, 192)
                     w = alpha * G.cumprod_excl(alpha)[:, :-1]
                     newz = G.sample_pdf_det(zo2.contiguous(), w[:, :-1], 64)
-                    zo2 = torch.sort(torch.cat([zo2, newz], -1), dim=-1)[0]
-                sv = sv.clone()
-                sv[miss] = sm[:, None, :] + dm[:, None, :] * zo2[..., None]
-            paths.append(sv)
+                    z[miss] = torch.sort(torch.cat([zo2, newz], -1), dim=-1)[0]
+                v = v.index_put((miss,), dm)
+            paths.append((start, v, z))
         return paths, converges, directions, ior_ratios, infinity_bkgr, gradient_mesh, tirs[0]
+
+    @staticmethod
+    def path_points(seg):
+        start, v, z = seg
+        return start[:, None, :] + v[:, None, :] * z[..., None]
 
     # ---- render_core ------------------------------------------------------------------------------
     def render_core(self, rays_o, rays_d, paths, converges, directions, infinity_bkgr, gradient_mesh, ior_ratios,
                     human_poses=None, cos_anneal_ratio=0.0, step=None, is_train=True, is_nerf=False):
-        """Per-segment composite in linear RGB with a running transmittance (renderer_zerothick.py:1835-2011, training)."""
+        """Per-segment composite in linear RGB with a running transmittance (renderer_zerothick.py:1835-2011, training).
+        The outer (|x| > 1) samples of ALL segments go through the NeRF++ in one pass of HIP kernels (stage2_ops.outer_segments);
+        each segment's composite is one kernel pair (stage2_ops.segment_composite)."""
         n1, n2 = self.nets()
         dev = rays_o.device
         N0 = converges[0].shape[0]
@@ -325,52 +319,45 @@ class Stage2Renderer(nn.Module):
         colors = []
         out = {'gradient_error': torch.zeros(1, device=dev), 'std': torch.zeros(1, device=dev)}
         s1c = self.stage1_network.color_network
+        outer = O.outer_segments(n1, [(st, v, z, directions[i]) for i, (st, v, z) in enumerate(paths)])
         for i in range(len(paths)):
-            cp, cd, cc = paths[i], directions[i], converges[i].flatten()
-            N = cp.shape[0]
-            color_now = torch.zeros(N, 3, device=dev)
-            pfn = cp[:, :-1, :]
-            dists = torch.linalg.norm(pfn[:, 1:] - pfn[:, :-1], dim=-1)
-            dists = torch.cat([dists, dists[..., -1:]], -1)
-            ns = pfn.shape[1]
-            p_neus = cp[cc][:, -1, :]
-            inner = torch.norm(pfn, dim=-1) <= 1.0
-            outer = ~inner
-            dirs = cd[:, None, :].expand(N, ns, 3)
-            alpha = torch.zeros(N, ns, device=dev)
-            col = torch.zeros(N, ns, 3, device=dev)
-            if outer.any():
-                a, c = self._density_alpha(n1, pfn[outer], dists[outer], dirs[outer])
-                alpha = alpha.index_put((outer,), a)
-                col = col.index_put((outer,), c)
-            if i == 1 and inner.any():
-                pin, din, dsin = pfn[inner], dirs[inner], dists[inner]
-                y, grads = n2.sdf(pin)
-                sdf, feats = y[:, 0], y[:, 1:]
-                s = torch.exp(self.deviation_network_inner.variance * 10.0).clip(1e-6, 1e6)
-                if self.cfg['freeze_inv_s_step'] is not None and step < self.cfg['freeze_inv_s_step']:
-                    s = s.detach()
-                cosv = (din * grads).sum(-1)
-                it = -(F.relu(-cosv * 0.5 + 0.5) * (1.0 - cos_anneal_ratio) + F.relu(-cosv) * cos_anneal_ratio)
-                pc = torch.sigmoid((sdf - it * dsin * 0.5) * s)
-                nc = torch.sigmoid((sdf + it * dsin * 0.5) * s)
-                a = ((pc - nc + 1e-5) / (pc + 1e-5)).clip(0.0, 1.0)
-                c, _ = self._shading(n2, self.color_network_inner.cfg, self.color_network_inner.FG_LUT, pin, grads, -din, feats)
-                alpha = alpha.index_put((inner,), a)
-                col = col.index_put((inner,), c)
-                out['std'] = torch.mean(1 / s)
-                out['gradient_error'] = (torch.linalg.norm(grads, dim=-1) - 1.0) ** 2
-            have_hit = p_neus.numel() > 0
+            start, v, z = paths[i]
+            cd, cc = directions[i], converges[i].flatten()
+            N = start.shape[0]
+            alpha, col = outer[i]
+            if i == 1 and N > 0:
+                cp = self.path_points(paths[i])
+                pfn = cp[:, :-1, :]
+                inner = torch.norm(pfn, dim=-1) <= 1.0
+                if inner.any():
+                    dists = torch.linalg.norm(pfn[:, 1:] - pfn[:, :-1], dim=-1)
+                    dists = torch.cat([dists, dists[..., -1:]], -1)
+                    ns = pfn.shape[1]
+                    dirs = cd[:, None, :].expand(N, ns, 3)
+                    pin, din, dsin = pfn[inner], dirs[inner], dists[inner]
+                    y, grads = n2.sdf(pin)
+                    sdf, feats = y[:, 0], y[:, 1:]
+                    s = torch.exp(self.deviation_network_inner.variance * 10.0).clip(1e-6, 1e6)
+                    if self.cfg['freeze_inv_s_step'] is not None and step < self.cfg['freeze_inv_s_step']:
+                        s = s.detach()
+                    cosv = (din * grads).sum(-1)
+                    it = -(F.relu(-cosv * 0.5 + 0.5) * (1.0 - cos_anneal_ratio) + F.relu(-cosv) * cos_anneal_ratio)
+                    pc = torch.sigmoid((sdf - it * dsin * 0.5) * s)
+                    nc = torch.sigmoid((sdf + it * dsin * 0.5) * s)
+                    a = ((pc - nc + 1e-5) / (pc + 1e-5)).clip(0.0, 1.0)
+                    c, _ = self._shading(n2, self.color_network_inner.cfg, self.color_network_inner.FG_LUT, pin, grads, -din, feats)
+                    alpha = alpha.index_put((inner,), a)
+                    col = col.index_put((inner,), torch.cat([c, torch.zeros_like(c[:, :1])], -1))
+                    out['std'] = torch.mean(1 / s)
+                    out['gradient_error'] = (torch.linalg.norm(grads, dim=-1) - 1.0) ** 2
+            color_now, T_end = O.segment_composite(n1.eng, alpha, col, T)
+            T = T_end
+            have_hit = bool(cc.any()) if N > 0 else False
             if have_hit:
+                p_neus = start[cc] + v[cc] * z[cc][:, -1:]
                 y, _ = n1.sdf(p_neus)
                 col_sdf, refr_coeff = self._shading(n1, s1c.cfg, s1c.FG_LUT, p_neus, gradient_mesh[i], -cd[cc], y[:, 1:],
                                                     s2=True, is_internal=(i % 2 != 0))
-            col = G.srgb_to_linear(col)
-            cpx = G.cumprod_excl(alpha)
-            w = alpha * cpx[:, :-1]
-            color_now = color_now + (col * w[..., None]).sum(dim=1) * T
-            T = T * cpx[:, -1:]
-            if have_hit:
                 color_now = color_now + torch.zeros_like(color_now).index_put((cc,), G.srgb_to_linear(col_sdf) * T[cc])
                 T = T[cc] * refr_coeff
                 colors.append(color_now)
@@ -394,7 +381,9 @@ class Stage2Renderer(nn.Module):
         ret = self.render_core(rays_o, rays_d, paths, conv, dirs, inf_b, gmesh, iors, human_poses,
                                cos_anneal_ratio=cos_anneal_ratio, step=step, is_train=is_train, is_nerf=is_nerf)
         ret['tir_mask'] = tir
-        ret['_paths'], ret['_ior_ratios'], ret['_directions'] = paths, iors, dirs
+        with torch.no_grad():
+            ret['_paths'] = [self.path_points(p) for p in paths]       # materialised for inspection only
+        ret['_ior_ratios'], ret['_directions'] = iors, dirs
         return ret
 
     def train_step_rays(self, batch, step):

@@ -1,0 +1,170 @@
+"""Differentiable stage-2 ops on the HIP kernels of csrc/stage2.hip (forward + hand-derived backward, WITH input gradients).
+
+  OuterSegments   all |x| > 1 samples of every ray segment through the stage-1 NeRF++ in ONE network pass:
+                  per-segment sample bookkeeping (nu_s2_seg_count / _write: node positions, section lengths, inner/outer split,
+                  compaction in (ray, sample) order), nu_nerfpp_mlp_fwd + fused activation scattered ray-major, and on the way
+                  back d alpha / d dist, the network backward with input gradients and nu_s2_seg_bwd (-> d start, d v, d dirs)
+                  (renderer_zerothick.py:1835-1870, :1531-1540)
+  SegmentComposite  linear-RGB composite of one segment with the running transmittance (renderer_zerothick.py:1976-1990)
+  Refract         Snell refraction / total internal reflection of the rays that hit the mesh (renderer_zerothick.py:1642-1684)
+
+A segment is (start [N,3], v [N,3], z [N,S1]): nodes x_j = start + v * z_j, z without gradient (csrc/stage2.hip).
+"""
+import ctypes
+
+import torch
+
+from . import _lib as L
+from .engine import addr
+from .nets import _grads_from_flat
+
+c_p = ctypes.c_void_p
+
+
+class _OuterSegmentsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, eng, names, nseg, *args):
+        segs = [tuple(t.detach().contiguous() for t in args[4 * i:4 * i + 4]) for i in range(nseg)]   # start, v, z, dirs
+        lib, S_ = eng.lib, eng.stream()
+        dev = eng.dev
+        dims = [(s[0].shape[0], s[2].shape[1]) for s in segs]                     # (N, S1)
+        rows = [n * (s1 - 1) for n, s1 in dims]
+        row_base = [sum(rows[:i]) for i in range(nseg)]
+        tot_rows = sum(rows)
+        alpha_all = eng.zeros(max(tot_rows, 1))
+        color_all = eng.zeros(max(tot_rows, 1), 4)
+        pos = torch.empty(max(tot_rows, 1), dtype=torch.int32, device=dev)
+        totals = torch.zeros(nseg, dtype=torch.int32, device=dev)
+        offs = []
+        for i, ((st, v, z, d), (n, s1)) in enumerate(zip(segs, dims)):
+            cnt, off = torch.empty(max(n, 1), dtype=torch.int32, device=dev), torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+            offs.append(off)
+            if n > 0:
+                L.check(lib.nu_s2_seg_count(c_p(addr(st)), c_p(addr(v)), c_p(addr(z)), n, s1, c_p(addr(cnt)), c_p(addr(off)),
+                                            c_p(addr(totals, i)), S_), "nu_s2_seg_count")
+        P_seg = [int(x) for x in totals.tolist()]          # the one device -> host read of the pass (buffer sizes)
+        P = sum(P_seg)
+        pt = eng.empty(max(P, 1), 8)
+        idx = torch.empty(max(P, 1), dtype=torch.int32, device=dev)
+        pbase = 0
+        for i, ((st, v, z, d), (n, s1)) in enumerate(zip(segs, dims)):
+            if n > 0:
+                L.check(lib.nu_s2_seg_write(c_p(addr(st)), c_p(addr(v)), c_p(addr(z)), c_p(addr(d)), n, s1, c_p(addr(offs[i])), pbase,
+                                            row_base[i], c_p(addr(pt)), c_p(addr(idx)), c_p(addr(pos)), S_), "nu_s2_seg_write")
+            pbase += P_seg[i]
+        b = eng.nerf_forward(pt[:P], idx, P, alpha_all, color_all) if P > 0 else None
+        ctx.eng, ctx.names, ctx.segs, ctx.dims, ctx.row_base = eng, names, segs, dims, row_base
+        ctx.b, ctx.pt, ctx.idx, ctx.pos, ctx.P = b, pt, idx, pos, P
+        ctx.set_materialize_grads(False)
+        return alpha_all, color_all
+
+    @staticmethod
+    def backward(ctx, dalpha, dcolor):
+        eng, segs, dims = ctx.eng, ctx.segs, ctx.dims
+        lib, S_ = eng.lib, eng.stream()
+        P, pt, idx = ctx.P, ctx.pt, ctx.idx
+        nseg = len(segs)
+        flat = eng.zeros(eng.n_grad)
+        out = []
+        if P > 0:
+            tot_rows = sum(n * (s1 - 1) for n, s1 in dims)
+            da = dalpha.contiguous() if dalpha is not None else eng.zeros(tot_rows)
+            dc = dcolor.contiguous() if dcolor is not None else eng.zeros(tot_rows, 4)
+            ddist, dx, dd = eng.empty(P), eng.empty(P, 3), eng.empty(P, 3)
+            L.check(lib.nu_s2_ddist(c_p(addr(ctx.b['sig'])), c_p(addr(pt)), c_p(addr(idx)), P, c_p(addr(da)), c_p(addr(ddist)), S_),
+                    "nu_s2_ddist")
+            eng.nerf_backward(ctx.b, pt[:P], idx, da, dc, flat, dx=dx, ddir=dd)
+            eng.unpack_grads(flat)
+        for i, ((st, v, z, d), (n, s1)) in enumerate(zip(segs, dims)):
+            gs, gv, gd = torch.zeros_like(st), torch.zeros_like(v), torch.zeros_like(d)
+            if n > 0 and P > 0:
+                L.check(lib.nu_s2_seg_bwd(c_p(addr(st)), c_p(addr(v)), c_p(addr(z)), n, s1, ctx.row_base[i], c_p(addr(ctx.pos)),
+                                          c_p(addr(dx)), c_p(addr(ddist)), c_p(addr(dd)), c_p(addr(gs)), c_p(addr(gv)), c_p(addr(gd)), S_),
+                        "nu_s2_seg_bwd")
+            out += [gs, gv, None, gd]
+        ctx.b = None
+        return (None, None, None) + tuple(out) + tuple(_grads_from_flat(eng, flat, ctx.names))
+
+
+def outer_segments(nets, segs):
+    """segs: list of (start [N,3], v [N,3], z [N,S1], dirs [N,3]).  Returns per segment (alpha [N,S], colour [N,S,4] sRGB): the
+    NeRF++ density / colour of the samples outside the unit sphere, zero elsewhere."""
+    flat_in = []
+    for s in segs:
+        flat_in += list(s)
+    alpha_all, color_all = _OuterSegmentsFn.apply(nets.eng, nets.nerf_names, len(segs), *flat_in, *nets.nerf_params)
+    out, base = [], 0
+    for st, v, z, d in segs:
+        n, s = st.shape[0], z.shape[1] - 1
+        out.append((alpha_all[base:base + n * s].view(n, s), color_all[base:base + n * s].view(n, s, 4)))
+        base += n * s
+    return out
+
+
+class _CompositeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, eng, alpha, color, T):
+        alpha, color, T = alpha.detach().contiguous(), color.detach().contiguous(), T.detach().contiguous()
+        N, S = alpha.shape
+        out, Tout = torch.empty(N, 3, device=alpha.device), torch.empty(N, 3, device=alpha.device)
+        if N > 0:
+            L.check(eng.lib.nu_s2_composite_fwd(c_p(addr(alpha)), c_p(addr(color)), c_p(addr(T)), N, S, c_p(addr(out)), c_p(addr(Tout)),
+                                                eng.stream()), "nu_s2_composite_fwd")
+        ctx.eng = eng
+        ctx.save_for_backward(alpha, color, T)
+        ctx.set_materialize_grads(False)
+        return out, Tout
+
+    @staticmethod
+    def backward(ctx, dout, dTout):
+        alpha, color, T = ctx.saved_tensors
+        N, S = alpha.shape
+        dalpha, dcolor, dT = torch.empty_like(alpha), torch.empty_like(color), torch.empty_like(T)
+        if N > 0:
+            L.check(ctx.eng.lib.nu_s2_composite_bwd(c_p(addr(alpha)), c_p(addr(color)), c_p(addr(T)), N, S,
+                                                    c_p(addr(dout.contiguous() if dout is not None else None)),
+                                                    c_p(addr(dTout.contiguous() if dTout is not None else None)),
+                                                    c_p(addr(dalpha)), c_p(addr(dcolor)), c_p(addr(dT)), ctx.eng.stream()),
+                    "nu_s2_composite_bwd")
+        return None, dalpha, dcolor, dT
+
+
+def segment_composite(eng, alpha, color4, T):
+    """alpha [N,S], colour [N,S,4] (sRGB in channels 0..2), T [N,3] -> (T * sum_j w_j lin(c_j), T * prod_j (1 - alpha_j + 1e-7))."""
+    return _CompositeFn.apply(eng, alpha, color4, T)
+
+
+class _RefractFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, eng, d, nrm, ior, point, outside):
+        d, nrm, ior, point = (t.detach().contiguous() for t in (d, nrm, ior, point))
+        M = d.shape[0]
+        dev = d.device
+        flag = torch.zeros(M, dtype=torch.uint8, device=dev)
+        eta, nd, ns = torch.zeros(M, device=dev), torch.zeros(M, 3, device=dev), torch.zeros(M, 3, device=dev)
+        L.check(eng.lib.nu_s2_refract_fwd(c_p(addr(d)), c_p(addr(nrm)), c_p(addr(ior)), c_p(addr(point)), M, 1 if outside else 0,
+                                          c_p(addr(flag)), c_p(addr(eta)), c_p(addr(nd)), c_p(addr(ns)), eng.stream()), "nu_s2_refract_fwd")
+        ctx.eng, ctx.outside = eng, outside
+        ctx.save_for_backward(d, nrm, ior)
+        ctx.mark_non_differentiable(flag)
+        ctx.set_materialize_grads(False)
+        return flag, eta, nd, ns
+
+    @staticmethod
+    def backward(ctx, _gflag, g_eta, g_nd, g_ns):
+        d, nrm, ior = ctx.saved_tensors
+        M = d.shape[0]
+        dd, dn, dior, dpoint = torch.zeros_like(d), torch.zeros_like(nrm), torch.zeros_like(ior), torch.zeros_like(d)
+        cg = lambda t: t.contiguous() if t is not None else None
+        g_eta, g_nd, g_ns = cg(g_eta), cg(g_nd), cg(g_ns)
+        L.check(ctx.eng.lib.nu_s2_refract_bwd(c_p(addr(d)), c_p(addr(nrm)), c_p(addr(ior)), M, 1 if ctx.outside else 0, c_p(addr(g_nd)),
+                                              c_p(addr(g_ns)), c_p(addr(g_eta)), c_p(addr(dd)), c_p(addr(dn)), c_p(addr(dior)),
+                                              c_p(addr(dpoint)), ctx.eng.stream()), "nu_s2_refract_bwd")
+        return None, dd, dn, dior, dpoint, None
+
+
+def refract(eng, d, nrm, ior, point, outside):
+    """Rays that hit the mesh: d [M,3] incoming directions, nrm [M,3] unit normals facing them, ior [M] network output,
+    point [M,3].  -> (refracts [M] bool, eta [M], next direction [M,3], next origin [M,3]); rows of totally reflected rays are 0."""
+    flag, eta, nd, ns = _RefractFn.apply(eng, d, nrm, ior, point, outside)
+    return flag.bool(), eta, nd, ns

@@ -1,0 +1,131 @@
+"""Op-level parity of the stage-2 HIP kernels (csrc/stage2.hip via nu_nerf_amd/stage2_ops.py), forward AND backward, against
+the eager torch formulation of the same reference lines (renderer_zerothick.py:1531-1540, :1642-1684, :1835-1870, :1976-1990).
+The end-to-end check against the reference's own golden step is tests/test_stage2_gpu.py."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _eng(gpu):
+    from test_stage2_gpu import build
+    net, _ = build(gpu)
+    n1, n2 = net.nets()
+    n1.eng.pack()
+    return net, n1
+
+
+def test_segment_composite_matches_torch(gpu):
+    from nu_nerf_amd import stage2_ops as O
+    from nu_nerf_amd import torch_glue as G
+    net, n1 = _eng(gpu)
+    torch.manual_seed(3)
+    for N, S in ((37, 255), (5, 127), (64, 1), (9, 70)):
+        alpha = (torch.rand(N, S, device=gpu) ** 4).requires_grad_(True)
+        alpha.data[0, : S // 2] = 0.0
+        col = torch.rand(N, S, 4, device=gpu)
+        col.data[1] *= 0.03                                    # the linear branch of the sRGB curve
+        col.requires_grad_(True)
+        T = torch.rand(N, 3, device=gpu).requires_grad_(True)
+        out, Tend = O.segment_composite(n1.eng, alpha, col, T)
+        g1, g2 = torch.randn_like(out), torch.randn_like(Tend)
+        ga, gc, gT = torch.autograd.grad((out * g1).sum() + (Tend * g2).sum(), (alpha, col, T))
+        lin = G.srgb_to_linear(col[..., :3])
+        cpx = G.cumprod_excl(alpha)
+        w = alpha * cpx[:, :-1]
+        ref, Tref = (lin * w[..., None]).sum(1) * T, T * cpx[:, -1:]
+        ra, rc, rT = torch.autograd.grad((ref * g1).sum() + (Tref * g2).sum(), (alpha, col, T))
+        torch.testing.assert_close(out, ref, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(Tend, Tref, rtol=1e-5, atol=1e-7)
+        torch.testing.assert_close(ga, ra, rtol=2e-4, atol=2e-5)
+        torch.testing.assert_close(gc[..., :3], rc[..., :3], rtol=1e-4, atol=1e-6)
+        assert float(gc[..., 3].abs().max()) == 0.0
+        torch.testing.assert_close(gT, rT, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("outside", [True, False])
+def test_refract_matches_torch(gpu, outside):
+    from nu_nerf_amd import stage2_ops as O
+    net, n1 = _eng(gpu)
+    torch.manual_seed(5 + int(outside))
+    M = 300
+    d = F.normalize(torch.randn(M, 3, device=gpu), dim=-1).requires_grad_(True)
+    nrm = F.normalize(-d.detach() + 0.9 * torch.randn(M, 3, device=gpu), dim=-1).requires_grad_(True)
+    ior = torch.rand(M, device=gpu).requires_grad_(True)
+    point = torch.randn(M, 3, device=gpu).requires_grad_(True)
+    refr, eta, nd, ns = O.refract(n1.eng, d, nrm, ior, point, outside)
+    cos_i = torch.sum(nrm * -d, dim=-1, keepdim=True)
+    sin2_i = 1 - cos_i * cos_i
+    ratio = 1 / (ior[:, None] * 1.0 + 1)
+    if not outside:
+        ratio = 1 / ratio
+    r_ref = ~(ratio * ratio * sin2_i > 0.999)
+    assert torch.equal(refr, r_ref.flatten())
+    if not outside:
+        assert int((~refr).sum()) > 0                         # total internal reflection really occurs leaving the object
+    sel = r_ref.flatten()
+    sin2_t = sin2_i[sel] * ratio[sel] * ratio[sel]
+    t = ratio[sel] * d[sel] + (ratio[sel] * cos_i[sel] - torch.sqrt(1 - sin2_t)) * nrm[sel]
+    ns_ref = point[sel] + t * 1e-5
+    nd_ref = t / (torch.linalg.norm(t, dim=-1, keepdim=True) + 0.0001)
+    torch.testing.assert_close(nd[sel], nd_ref, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(ns[sel], ns_ref, rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(eta[sel], ratio[sel].flatten(), rtol=1e-6, atol=0)
+    assert float(nd.detach()[~sel].abs().max() if (~sel).any() else 0.0) == 0.0
+    g1, g2, g3 = torch.randn_like(nd_ref), torch.randn_like(ns_ref), torch.randn(int(sel.sum()), device=gpu)
+    got = torch.autograd.grad((nd[sel] * g1).sum() + (ns[sel] * g2).sum() + (eta[sel] * g3).sum(), (d, nrm, ior, point))
+    want = torch.autograd.grad((nd_ref * g1).sum() + (ns_ref * g2).sum() + (ratio[sel].flatten() * g3).sum(), (d, nrm, ior, point))
+    for a, b, name in zip(got, want, ('d', 'nrm', 'ior', 'point')):
+        torch.testing.assert_close(a, b, rtol=2e-4, atol=2e-5, msg=lambda m, name=name: f"{name}: {m}")
+
+
+def test_outer_segments_match_the_eager_formulation(gpu):
+    """Two segments with different sample counts, rays that straddle the unit sphere: alpha / colour and the gradients w.r.t.
+    start, v, dirs and every NeRF++ parameter against boolean-mask indexing + the network op + torch activations."""
+    from nu_nerf_amd import stage2_ops as O
+    net, n1 = _eng(gpu)
+    torch.manual_seed(11)
+    segs = []
+    for N, S1 in ((50, 256), (17, 128), (0, 256)):
+        start = (F.normalize(torch.randn(N, 3, device=gpu), dim=-1) * (1.6 + torch.rand(N, 1, device=gpu))).requires_grad_(True)
+        v = (-start.detach() * (0.5 + torch.rand(N, 1, device=gpu)) + 0.3 * torch.randn(N, 3, device=gpu)).requires_grad_(True)
+        z = torch.sort(torch.rand(N, S1, device=gpu), dim=-1)[0]
+        dirs = F.normalize(v.detach() + 0.01 * torch.randn(N, 3, device=gpu), dim=-1).requires_grad_(True)
+        segs.append((start, v, z, dirs))
+    res = O.outer_segments(n1, segs)
+    gs = [(torch.randn_like(a), torch.randn_like(c[..., :3])) for a, c in res]
+    loss = sum((a * ga).sum() + (c[..., :3] * gc).sum() for (a, c), (ga, gc) in zip(res, gs))
+    inputs = [t for s in segs for t in (s[0], s[1], s[3])]
+    params = list(n1.nerf_params)
+    got = torch.autograd.grad(loss, inputs + params, allow_unused=True)
+    # eager formulation (what nu_nerf_amd/stage2.py did before these kernels)
+    ref_loss = 0.0
+    n_outer = 0
+    for (start, v, z, dirs), (a_hip, c_hip), (ga, gc) in zip(segs, res, gs):
+        N = start.shape[0]
+        if N == 0:
+            assert a_hip.numel() == 0
+            continue
+        cp = start[:, None, :] + v[:, None, :] * z[..., None]
+        pfn = cp[:, :-1, :]
+        dists = torch.linalg.norm(pfn[:, 1:] - pfn[:, :-1], dim=-1)
+        dists = torch.cat([dists, dists[..., -1:]], -1)
+        ns = pfn.shape[1]
+        outer = ~(torch.norm(pfn, dim=-1) <= 1.0)
+        n_outer += int(outer.sum())
+        assert 0 < int(outer.sum()) < outer.numel()
+        dd = dirs[:, None, :].expand(N, ns, 3)
+        a, c = net._density_alpha(n1, pfn[outer], dists[outer], dd[outer])
+        alpha = torch.zeros(N, ns, device=gpu).index_put((outer,), a)
+        col = torch.zeros(N, ns, 3, device=gpu).index_put((outer,), c)
+        torch.testing.assert_close(a_hip, alpha, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(c_hip[..., :3], col, rtol=1e-5, atol=1e-6)
+        ref_loss = ref_loss + (alpha * ga).sum() + (col * gc).sum()
+    want = torch.autograd.grad(ref_loss, inputs + params, allow_unused=True)
+    for k, (a, b) in enumerate(zip(got, want)):
+        if b is None:
+            assert a is None or a.numel() == 0 or float(a.abs().max()) == 0.0
+            continue
+        scale = float(b.abs().max()) + 1e-12
+        assert float((a - b).abs().max()) <= 2e-4 * scale + 1e-7, (k, float((a - b).abs().max()), scale)
