@@ -26,9 +26,52 @@ def _grads_from_flat(eng, flat, names):
     return out
 
 
+def _own_range(eng, names):
+    """[lo, hi) of the flat gradient buffer that the parameters `names` occupy (one network's parameters are contiguous)."""
+    lo, hi, tot = None, 0, 0
+    for n in names:
+        off, shape = eng.grad_views[n]
+        numel = int(np.prod(shape)) if len(shape) else 1
+        lo = off if lo is None else min(lo, off)
+        hi = max(hi, off + numel)
+        tot += numel
+    assert lo is not None and tot == hi - lo, "a network's parameters are expected to be contiguous in the flat gradient buffer"
+    return lo, hi
+
+
+def _token_grad(eng, flat, names):
+    """This op's share of the flat gradient buffer: its own parameters' range, zero elsewhere (unpack_grads rewrites every
+    layer's slots from the packed tables, which may hold another op's values)."""
+    lo, hi = _own_range(eng, names)
+    g = torch.zeros_like(flat)
+    g[lo:hi] = flat[lo:hi]
+    eng._hub_touched.update(names)           # parameters no op touched keep grad None (optimizer state is created lazily)
+    return g
+
+
+class ParamHubFn(torch.autograd.Function):
+    """All parameters of one engine -> one token of the flat gradient buffer's shape.  Every network op of a pass takes the token
+    instead of its ~50 parameters and returns its flat gradient contribution for it; autograd sums those (one add per op) and
+    this node hands each parameter its slice ONCE -- instead of one small accumulation per parameter per op."""
+
+    @staticmethod
+    def forward(ctx, eng, names, *params):
+        ctx.eng, ctx.names = eng, names
+        eng._hub_touched = set()
+        return torch.empty(eng.n_grad, device=eng.dev)
+
+    @staticmethod
+    def backward(ctx, g):
+        if g is None:
+            return (None, None) + (None,) * len(ctx.names)
+        touched = ctx.eng._hub_touched
+        grads = _grads_from_flat(ctx.eng, g, ctx.names)
+        return (None, None) + tuple(gr if n in touched else None for n, gr in zip(ctx.names, grads))
+
+
 class SdfFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, eng, x, names, *params):
+    def forward(ctx, eng, x, names, token):
         x = x.detach().contiguous()
         P = x.shape[0]
         a = eng.sdf_forward(addr(x), 3, P, keep=True, want_feat=True)
@@ -50,12 +93,12 @@ class SdfFn(torch.autograd.Function):
         eng.sdf_backward(a, dYX, nbar, flat, dx=dx)
         eng.unpack_grads(flat)
         ctx.a = None
-        return (None, dx, None) + tuple(_grads_from_flat(eng, flat, ctx.names))
+        return None, dx, None, _token_grad(eng, flat, ctx.names)
 
 
 class NerfFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, eng, x, d, names, *params):
+    def forward(ctx, eng, x, d, names, token):
         P = x.shape[0]
         pt = eng.zeros(P, 8)
         pt[:, :3] = x.detach()
@@ -78,14 +121,14 @@ class NerfFn(torch.autograd.Function):
         eng.nerf_backward(b, pt, None, None, None, flat, dsig=ds, drgb=dr, dx=dx, ddir=dd)
         eng.unpack_grads(flat)
         ctx.b = None
-        return (None, dx, dd, None) + tuple(_grads_from_flat(eng, flat, ctx.names))
+        return None, dx, dd, None, _token_grad(eng, flat, ctx.names)
 
 
 class StackFn(torch.autograd.Function):
     """One make_predictor stack (3 hidden ReLU layers + skinny head) on already-encoded inputs."""
 
     @staticmethod
-    def forward(ctx, eng, layers, X, names, *params):
+    def forward(ctx, eng, layers, X, names, token):
         rows, K = X.shape
         Kp = layers[0].Kp
         Xp = eng.zeros(rows, Kp)
@@ -115,14 +158,14 @@ class StackFn(torch.autograd.Function):
         eng.relu_stack_bwd(layers, Xp, Kp, rows, Hs, dH3, flat, dX, Kp, Kp)
         eng.unpack_grads(flat)
         ctx.Hs = ctx.Xp = None
-        return (None, None, dX[:, :ctx.K], None) + tuple(_grads_from_flat(eng, flat, ctx.names))
+        return None, None, dX[:, :ctx.K], None, _token_grad(eng, flat, ctx.names)
 
 
 class MaterialsFn(torch.autograd.Function):
     """The four material predictors batched (metallic, roughness, albedo, transmission) on [feature, x]."""
 
     @staticmethod
-    def forward(ctx, eng, feat, x, names, *params):
+    def forward(ctx, eng, feat, x, names, token):
         from .engine import EPI_BIAS_RELU
         P = feat.shape[0]
         YX = eng.zeros(P, 288)
@@ -168,7 +211,7 @@ class MaterialsFn(torch.autograd.Function):
         eng.nt(addr(dA), 1024, addr(eng.WpTM0), 1024, P, 288, 1024, addr(dYX), 288, EPI_PLAIN)
         eng.unpack_grads(flat)
         ctx.s = None
-        return (None, dYX[:, 1:257], dYX[:, 257:260], None) + tuple(_grads_from_flat(eng, flat, ctx.names))
+        return None, dYX[:, 1:257], dYX[:, 257:260], None, _token_grad(eng, flat, ctx.names)
 
 
 class Stage1Nets:
@@ -193,16 +236,31 @@ class Stage1Nets:
                            ('inner_weight', eng.inner_weight), ('refrac_light', eng.refrac_light)):
             names, params = sel(lambda n, nm=nm: n.startswith('color_network.' + nm + '.'))
             self.stack[nm] = (layers, names, params)
+        self.all_names = [n for n in g if n in named and isinstance(named[n], torch.nn.Parameter)]
+        self._token = None
+
+    def begin_pass(self):
+        """Start of a forward pass (a new autograd graph): the next network op makes a fresh parameter hub."""
+        self._token = None
+
+    def token(self):
+        """The pass's parameter-hub token (ParamHubFn): what every network op differentiates instead of its parameters."""
+        if self._token is None or not torch.is_grad_enabled():
+            tok = ParamHubFn.apply(self.eng, self.all_names, *[self.named[n] for n in self.all_names])
+            if not torch.is_grad_enabled():
+                return tok
+            self._token = tok
+        return self._token
 
     def sdf(self, x):
-        return SdfFn.apply(self.eng, x, self.sdf_names, *self.sdf_params)
+        return SdfFn.apply(self.eng, x, self.sdf_names, self.token())
 
     def nerf(self, x, d):
-        return NerfFn.apply(self.eng, x, d, self.nerf_names, *self.nerf_params)
+        return NerfFn.apply(self.eng, x, d, self.nerf_names, self.token())
 
     def materials(self, feat, x):
-        return MaterialsFn.apply(self.eng, feat, x, self.mat_names, *self.mat_params)
+        return MaterialsFn.apply(self.eng, feat, x, self.mat_names, self.token())
 
     def predictor(self, name, X):
         layers, names, params = self.stack[name]
-        return StackFn.apply(self.eng, layers, X, names, *params)
+        return StackFn.apply(self.eng, layers, X, names, self.token())

@@ -377,6 +377,8 @@ class Stage2Renderer(nn.Module):
         n1, n2 = self.nets()
         n1.eng.pack()
         n2.eng.pack()
+        n1.begin_pass()
+        n2.begin_pass()
         paths, conv, dirs, iors, inf_b, gmesh, tir = self.ray_trace(rays_o, rays_d)
         ret = self.render_core(rays_o, rays_d, paths, conv, dirs, inf_b, gmesh, iors, human_poses,
                                cos_anneal_ratio=cos_anneal_ratio, step=step, is_train=is_train, is_nerf=is_nerf)

@@ -16,14 +16,14 @@ import torch
 
 from . import _lib as L
 from .engine import addr
-from .nets import _grads_from_flat
+from .nets import _token_grad
 
 c_p = ctypes.c_void_p
 
 
 class _OuterSegmentsFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, eng, names, nseg, *args):
+    def forward(ctx, eng, names, nseg, token, *args):
         segs = [tuple(t.detach().contiguous() for t in args[4 * i:4 * i + 4]) for i in range(nseg)]   # start, v, z, dirs
         lib, S_ = eng.lib, eng.stream()
         dev = eng.dev
@@ -83,7 +83,7 @@ class _OuterSegmentsFn(torch.autograd.Function):
                         "nu_s2_seg_bwd")
             out += [gs, gv, None, gd]
         ctx.b = None
-        return (None, None, None) + tuple(out) + tuple(_grads_from_flat(eng, flat, ctx.names))
+        return (None, None, None, _token_grad(eng, flat, ctx.names)) + tuple(out)
 
 
 def outer_segments(nets, segs):
@@ -92,7 +92,7 @@ def outer_segments(nets, segs):
     flat_in = []
     for s in segs:
         flat_in += list(s)
-    alpha_all, color_all = _OuterSegmentsFn.apply(nets.eng, nets.nerf_names, len(segs), *flat_in, *nets.nerf_params)
+    alpha_all, color_all = _OuterSegmentsFn.apply(nets.eng, nets.nerf_names, len(segs), nets.token(), *flat_in)
     out, base = [], 0
     for st, v, z, d in segs:
         n, s = st.shape[0], z.shape[1] - 1
