@@ -412,6 +412,17 @@ int nu_s2_refract_fwd(const float* d, const float* nrm, const float* ior, const 
                       float* eta, float* nd, float* ns, hipStream_t stream);
 int nu_s2_refract_bwd(const float* d, const float* nrm, const float* ior, int M, int outside, const float* g_nd, const float* g_ns,
                       const float* g_eta, float* dd, float* dn, float* dior, float* dpoint, hipStream_t stream);
+/*   nu_s2_hit_fwd / _bwd                differentiable Moeller-Trumbore + vertex-normal interpolation of the rays that hit
+ *                                       (Scene.Dintersect, network/DiffRender.py:61-125): face [M] int64 from nu_lbvh_trace, faces [F,3]
+ *                                       int64, verts / vnrm [V,3] constants; backward -> d o, d d
+ *   nu_s2_far_points / _far_resample    importance pass of the rays that miss the mesh (:1786-1812, no gradient): 192 coarse nodes
+ *                                       -> point records; alpha [M,192] -> 64 inverse-CDF samples merged in: zout [M,256] sorted */
+int nu_s2_hit_fwd(const float* o, const float* d, const long long* face, const float* verts, const float* vnrm, const long long* faces,
+                  int M, float* point, float* nrm, float* t, hipStream_t stream);
+int nu_s2_hit_bwd(const float* o, const float* d, const long long* face, const float* verts, const float* vnrm, const long long* faces,
+                  int M, const float* g_point, const float* g_nrm, const float* g_t, float* g_o, float* g_d, hipStream_t stream);
+int nu_s2_far_points(const float* start, const float* dirs, const float* zo, int M, int S, float* pt, int* idx, hipStream_t stream);
+int nu_s2_far_resample(const float* alpha, const float* zo, int M, int S, int n_new, float* zout, hipStream_t stream);
 
 
 /* ---------------------------------------------------------------------------------------------------------

@@ -504,3 +504,278 @@ extern "C" int nu_s2_refract_bwd(const float* d, const float* nrm, const float* 
                        dn, dior, dpoint);
     return nu_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------
+// Differentiable ray / triangle intersection of the rays that hit (Scene.Dintersect, network/DiffRender.py:61-125, :539-549):
+// Moeller-Trumbore u, v, t against the face the LBVH found, the vertex-normal interpolation, point = o + t d.  Vertices and
+// vertex normals are constants of stage 2 (the stage-1 mesh); the backward returns d o and d d.
+// ------------------------------------------------------------------------------------------------
+static __device__ inline void s2_cross(const float* a, const float* b, float* c) {
+    c[0] = a[1] * b[2] - a[2] * b[1];
+    c[1] = a[2] * b[0] - a[0] * b[2];
+    c[2] = a[0] * b[1] - a[1] * b[0];
+}
+static __device__ inline float s2_dot(const float* a, const float* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+
+struct S2Tri { float v0[3], e1[3], e2[3], n0[3], n1[3], n2[3]; };
+static __device__ inline S2Tri s2_load_tri(const float* __restrict__ verts, const float* __restrict__ vnrm, const long long* __restrict__ faces,
+                                           long long f) {
+    S2Tri t;
+    const long long i0 = faces[f * 3], i1 = faces[f * 3 + 1], i2 = faces[f * 3 + 2];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        t.v0[c] = verts[i0 * 3 + c];
+        t.e1[c] = verts[i1 * 3 + c] - t.v0[c];
+        t.e2[c] = verts[i2 * 3 + c] - t.v0[c];
+        t.n0[c] = vnrm[i0 * 3 + c]; t.n1[c] = vnrm[i1 * 3 + c]; t.n2[c] = vnrm[i2 * 3 + c];
+    }
+    return t;
+}
+
+__global__ __launch_bounds__(256) void s2_hit_fwd_kernel(const float* __restrict__ o, const float* __restrict__ d,
+                                                         const long long* __restrict__ face, const float* __restrict__ verts,
+                                                         const float* __restrict__ vnrm, const long long* __restrict__ faces, int M,
+                                                         float* __restrict__ point, float* __restrict__ nrm, float* __restrict__ tout) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    const S2Tri T = s2_load_tri(verts, vnrm, faces, face[m]);
+    const float oo[3] = {o[m * 3LL], o[m * 3LL + 1], o[m * 3LL + 2]}, dd[3] = {d[m * 3LL], d[m * 3LL + 1], d[m * 3LL + 2]};
+    float pvec[3], qvec[3], tvec[3];
+    s2_cross(dd, T.e2, pvec);
+    const float inv = 1.0f / s2_dot(T.e1, pvec);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) tvec[c] = oo[c] - T.v0[c];
+    const float u = s2_dot(tvec, pvec) * inv;
+    s2_cross(tvec, T.e1, qvec);
+    const float v = s2_dot(dd, qvec) * inv;
+    const float t = s2_dot(T.e2, qvec) * inv;
+    float nr[3], len2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        nr[c] = (1.0f - u - v) * T.n0[c] + u * T.n1[c] + v * T.n2[c];
+        len2 += nr[c] * nr[c];
+    }
+    const float il = 1.0f / sqrtf(len2);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        nrm[m * 3LL + c] = nr[c] * il;
+        point[m * 3LL + c] = oo[c] + t * dd[c];
+    }
+    tout[m] = t;
+}
+
+__global__ __launch_bounds__(256) void s2_hit_bwd_kernel(const float* __restrict__ o, const float* __restrict__ d,
+                                                         const long long* __restrict__ face, const float* __restrict__ verts,
+                                                         const float* __restrict__ vnrm, const long long* __restrict__ faces, int M,
+                                                         const float* __restrict__ g_point, const float* __restrict__ g_nrm,
+                                                         const float* __restrict__ g_t, float* __restrict__ g_o, float* __restrict__ g_d) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    const S2Tri T = s2_load_tri(verts, vnrm, faces, face[m]);
+    const float oo[3] = {o[m * 3LL], o[m * 3LL + 1], o[m * 3LL + 2]}, dd[3] = {d[m * 3LL], d[m * 3LL + 1], d[m * 3LL + 2]};
+    float pvec[3], qvec[3], tvec[3];
+    s2_cross(dd, T.e2, pvec);
+    const float inv = 1.0f / s2_dot(T.e1, pvec);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) tvec[c] = oo[c] - T.v0[c];
+    const float tp = s2_dot(tvec, pvec), u = tp * inv;
+    s2_cross(tvec, T.e1, qvec);
+    const float dq = s2_dot(dd, qvec), v = dq * inv;
+    const float eq = s2_dot(T.e2, qvec), t = eq * inv;
+    float nr[3], len2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        nr[c] = (1.0f - u - v) * T.n0[c] + u * T.n1[c] + v * T.n2[c];
+        len2 += nr[c] * nr[c];
+    }
+    const float il = 1.0f / sqrtf(len2);
+    float gp[3], gn[3], n[3], ndg = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        gp[c] = g_point ? g_point[m * 3LL + c] : 0.f;
+        gn[c] = g_nrm ? g_nrm[m * 3LL + c] : 0.f;
+        n[c] = nr[c] * il;
+        ndg += n[c] * gn[c];
+    }
+    float go[3], gd[3];
+    float gt = (g_t ? g_t[m] : 0.f), gu = 0.f, gv = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        go[c] = gp[c];
+        gd[c] = t * gp[c];
+        gt += gp[c] * dd[c];
+        const float gnr = (gn[c] - n[c] * ndg) * il;
+        gu += gnr * (T.n1[c] - T.n0[c]);
+        gv += gnr * (T.n2[c] - T.n0[c]);
+    }
+    float gq[3], gtv[3], gpv[3];
+    float ginv = gt * eq + gv * dq + gu * tp;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        gq[c] = gt * inv * T.e2[c] + gv * inv * dd[c];
+        gd[c] += gv * inv * qvec[c];
+        gtv[c] = gu * inv * pvec[c];
+        gpv[c] = gu * inv * tvec[c];
+    }
+    float x[3];
+    s2_cross(T.e1, gq, x);                       // qvec = tvec x e1
+#pragma unroll
+    for (int c = 0; c < 3; ++c) gtv[c] += x[c];
+    const float gdet = -ginv * inv * inv;        // inv = 1 / (e1 . pvec)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) gpv[c] += gdet * T.e1[c];
+    s2_cross(T.e2, gpv, x);                      // pvec = d x e2
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        g_d[m * 3LL + c] = gd[c] + x[c];
+        g_o[m * 3LL + c] = go[c] + gtv[c];
+    }
+}
+
+extern "C" int nu_s2_hit_fwd(const float* o, const float* d, const long long* face, const float* verts, const float* vnrm,
+                             const long long* faces, int M, float* point, float* nrm, float* t, hipStream_t stream) {
+    if (M <= 0) return NU_OK;
+    hipLaunchKernelGGL(s2_hit_fwd_kernel, dim3(nu_cdiv(M, 256)), dim3(256), 0, stream, o, d, face, verts, vnrm, faces, M, point, nrm, t);
+    return nu_launch_status();
+}
+extern "C" int nu_s2_hit_bwd(const float* o, const float* d, const long long* face, const float* verts, const float* vnrm,
+                             const long long* faces, int M, const float* g_point, const float* g_nrm, const float* g_t, float* g_o,
+                             float* g_d, hipStream_t stream) {
+    if (M <= 0) return NU_OK;
+    hipLaunchKernelGGL(s2_hit_bwd_kernel, dim3(nu_cdiv(M, 256)), dim3(256), 0, stream, o, d, face, verts, vnrm, faces, M, g_point, g_nrm,
+                       g_t, g_o, g_d);
+    return nu_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Importance pass of the rays that miss the mesh (renderer_zerothick.py:1786-1812, no gradient): 192 samples z in [0.1, 64],
+// NeRF++ density, 64 inverse-CDF samples (sample_pdf, det), merged with the coarse ones into 256 sorted nodes.
+//   s2_far_points    point records of all M x 192 samples (dist_j = z_{j+1} - z_j, the last one repeated), idx = identity
+//   s2_far_resample  one wave per ray: weights, cdf, 64 samples at u = (i + 0.5) / 64, merge
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void s2_far_points_kernel(const float* __restrict__ start, const float* __restrict__ dirs,
+                                                            const float* __restrict__ zo, int M, int S, float* __restrict__ pt,
+                                                            int* __restrict__ idx) {
+#pragma clang fp contract(off)
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)M * S) return;
+    const int m = (int)(i / S), j = (int)(i - (long long)m * S);
+    const float z = zo[j];
+    const float dist = j + 1 < S ? zo[j + 1] - z : zo[S - 1] - zo[S - 2];
+    float x[3], dd[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        dd[c] = dirs[m * 3LL + c];
+        const float mm = dd[c] * z;
+        x[c] = start[m * 3LL + c] + mm;
+    }
+    float* rec = pt + i * NU_PT;
+    *reinterpret_cast<f32x4*>(rec) = f32x4{x[0], x[1], x[2], dist};
+    *reinterpret_cast<f32x4*>(rec + 4) = f32x4{dd[0], dd[1], dd[2], 0.f};
+    idx[i] = (int)i;
+}
+
+#define S2_FAR_S 192
+#define S2_FAR_NEW 64
+__global__ __launch_bounds__(256) void s2_far_resample_kernel(const float* __restrict__ alpha, const float* __restrict__ zo, int M,
+                                                              float* __restrict__ zout) {
+    __shared__ float s_cdf[4][S2_FAR_S], s_new[4][S2_FAR_NEW];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int mi = blockIdx.x * 4 + w;
+    const bool live = mi < M;
+    const int m = live ? mi : M - 1;               // idle waves recompute the last ray and store nothing (barriers below)
+    constexpr int S = S2_FAR_S, CH = 3;
+    // weights w_j = alpha_j prod_{k<j} (1 - alpha_k + 1e-7); the pdf uses the first S - 1 of them
+    float a[CH], pl = 1.f;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+        a[i] = alpha[(long long)m * S + lane * CH + i];
+        pl *= (1.0f - a[i] + 1e-7f);
+    }
+    float T = nu_wave_incl_prod(pl, lane);
+    T = __shfl_up(T, 1, 64);
+    if (lane == 0) T = 1.0f;
+    float wj[CH], ls = 0.f;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+        const int j = lane * CH + i;
+        wj[i] = j < S - 1 ? a[i] * T + 1e-5f : 0.f;
+        ls += wj[i];
+        T *= (1.0f - a[i] + 1e-7f);
+    }
+    const float tot = nu_wave_sum(ls);
+    ls = 0.f;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {                 // pdf = w / sum(w), then its running sum (sample_pdf, field.py:468-498)
+        wj[i] = wj[i] / tot;
+        ls += wj[i];
+    }
+    // inclusive prefix of the lane sums
+    float inc = ls;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+    }
+    float run = inc - ls;                          // sum of the weights before this lane's first sample
+    // cdf[0] = 0, cdf[j + 1] = sum_{k <= j} pdf_k  (S entries for S - 1 weights)
+    if (lane == 0) s_cdf[w][0] = 0.f;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+        const int j = lane * CH + i;
+        run += wj[i];
+        if (j < S - 1) s_cdf[w][j + 1] = run;
+    }
+    __syncthreads();
+    {
+        const float u = (lane + 0.5f) / (float)S2_FAR_NEW;     // linspace(0.5 / n, 1 - 0.5 / n, n)
+        int lo = 0, hi = S;                        // searchsorted(cdf, u, right = True): number of entries <= u
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (s_cdf[w][mid] <= u) lo = mid + 1; else hi = mid;
+        }
+        const int il = lo - 1 > 0 ? lo - 1 : 0, ih = lo < S - 1 ? lo : S - 1;
+        const float c_lo = s_cdf[w][il], c_hi = s_cdf[w][ih], b_lo = zo[il], b_hi = zo[ih];
+        float den = c_hi - c_lo;
+        den = den < 1e-5f ? 1.0f : den;
+        s_new[w][lane] = b_lo + (u - c_lo) / den * (b_hi - b_lo);
+    }
+    __syncthreads();
+    if (!live) return;
+    // merge: every coarse node lands at its index + #(new < it), every new sample at its index + #(coarse <= it)
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+        const int j = lane * CH + i;
+        const float zc = zo[j];
+        int lo = 0, hi = S2_FAR_NEW;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (s_new[w][mid] < zc) lo = mid + 1; else hi = mid;
+        }
+        zout[(long long)m * (S + S2_FAR_NEW) + j + lo] = zc;
+    }
+    {
+        const float zn = s_new[w][lane];
+        int lo = 0, hi = S;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (zo[mid] <= zn) lo = mid + 1; else hi = mid;
+        }
+        zout[(long long)m * (S + S2_FAR_NEW) + lane + lo] = zn;
+    }
+}
+
+extern "C" int nu_s2_far_points(const float* start, const float* dirs, const float* zo, int M, int S, float* pt, int* idx,
+                                hipStream_t stream) {
+    if (M <= 0) return NU_OK;
+    if (S < 2) return NU_ERR_ARG;
+    const long long n = (long long)M * S;
+    hipLaunchKernelGGL(s2_far_points_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, start, dirs, zo, M, S, pt, idx);
+    return nu_launch_status();
+}
+extern "C" int nu_s2_far_resample(const float* alpha, const float* zo, int M, int S, int n_new, float* zout, hipStream_t stream) {
+    if (M <= 0) return NU_OK;
+    if (S != S2_FAR_S || n_new != S2_FAR_NEW) return NU_ERR_ARG;
+    hipLaunchKernelGGL(s2_far_resample_kernel, dim3(nu_cdiv(M, 4)), dim3(256), 0, stream, alpha, zo, M, zout);
+    return nu_launch_status();
+}

@@ -103,6 +103,15 @@ class Scene:
         return dict(u=u, v=v, t=t, n=n, point=o + t[:, None] * d, origin=o, direction=d, faces_ind=faces_ind[hitted]), hitted
 
 
+def dintersect_hip(scene, eng, origin, direction):
+    """Scene.Dintersect on the HIP kernels (nu_lbvh_trace + nu_s2_hit_fwd/_bwd): -> dict(n, point, t, faces_ind), hitted mask."""
+    from . import stage2_ops as O
+    faces_ind, hitted = scene.intersect(origin, direction)
+    fi = faces_ind[hitted]
+    point, n, t = O.hit(eng, scene, origin[hitted], direction[hitted], fi)
+    return dict(n=n, point=point, t=t, faces_ind=fi), hitted
+
+
 def icosphere(subdiv=2, radius=0.5):
     """Unit icosahedron subdivided `subdiv` times (20 * 4^subdiv faces): build-generated stand-in for the stage-1 mesh."""
     p = (1.0 + 5 ** 0.5) / 2.0

@@ -22,7 +22,7 @@ from . import _lib as L
 from . import stage2_ops as O
 from . import torch_glue as G
 from .engine import Stage1Engine, addr
-from .lbvh import Scene
+from .lbvh import Scene, dintersect_hip
 from .nets import Stage1Nets
 from .shading_glue import shade
 from .renderer import (AppShadingNetwork, NeRFNetwork, NeROShapeRenderer, SDFNetwork, SingleVarianceNetwork, WNLinear)
@@ -240,7 +240,7 @@ class Stage2Renderer(nn.Module):
         for i in range(3):
             N = next_start.shape[0]
             tir = torch.ones(N, 1, dtype=torch.bool, device=dev)
-            inter, hit = scene.Dintersect(next_start, next_dir)
+            inter, hit = dintersect_hip(scene, n1.eng, next_start, next_dir)      # LBVH trace + differentiable hit (HIP)
             point = inter['point']
             converged = hit.reshape(-1, 1)
             normal = F.normalize(inter['n'], dim=-1) if outside else -F.normalize(inter['n'], dim=-1)
@@ -285,18 +285,7 @@ class Stage2Renderer(nn.Module):
                 miss = ~hitk
                 sm, dm = start[miss], dk[miss]
                 with torch.no_grad():
-                    zo = torch.linspace(0.1, 64.0, 192, device=dev)
-                    M = sm.shape[0]
-                    pts = (sm[:, None, :] + dm[:, None, :] * zo[None, :, None]).detach()
-                    zo2 = zo[None, :].expand(M, 192)
-                    dists = zo2[..., 1:] - zo2[..., :-1]
-                    dists = torch.cat([dists, dists[..., -1:]], -1)
-                    alpha, _ = self._density_alpha(n1, pts.reshape(-1, 3), dists.reshape(-1),
-                                                   dm.detach()[:, None, :].expand(-1, 192, 3).reshape(-1, 3))
-                    alpha = alpha.reshape(M, 192)
-                    w = alpha * G.cumprod_excl(alpha)[:, :-1]
-                    newz = G.sample_pdf_det(zo2.contiguous(), w[:, :-1], 64)
-                    z[miss] = torch.sort(torch.cat([zo2, newz], -1), dim=-1)[0]
+                    z[miss] = O.far_importance_nodes(n1.eng, sm, dm)
                 v = v.index_put((miss,), dm)
             paths.append((start, v, z))
         return paths, converges, directions, ior_ratios, infinity_bkgr, gradient_mesh, tirs[0]

@@ -168,3 +168,55 @@ def refract(eng, d, nrm, ior, point, outside):
     point [M,3].  -> (refracts [M] bool, eta [M], next direction [M,3], next origin [M,3]); rows of totally reflected rays are 0."""
     flag, eta, nd, ns = _RefractFn.apply(eng, d, nrm, ior, point, outside)
     return flag.bool(), eta, nd, ns
+
+
+class _HitFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, eng, o, d, face, verts, vnrm, faces):
+        o, d = o.detach().contiguous(), d.detach().contiguous()
+        M = o.shape[0]
+        point, nrm, t = torch.empty_like(o), torch.empty_like(o), torch.empty(M, device=o.device)
+        L.check(eng.lib.nu_s2_hit_fwd(c_p(addr(o)), c_p(addr(d)), c_p(addr(face)), c_p(addr(verts)), c_p(addr(vnrm)), c_p(addr(faces)), M,
+                                      c_p(addr(point)), c_p(addr(nrm)), c_p(addr(t)), eng.stream()), "nu_s2_hit_fwd")
+        ctx.eng, ctx.consts = eng, (face, verts, vnrm, faces)
+        ctx.save_for_backward(o, d)
+        ctx.set_materialize_grads(False)
+        return point, nrm, t
+
+    @staticmethod
+    def backward(ctx, g_point, g_nrm, g_t):
+        o, d = ctx.saved_tensors
+        face, verts, vnrm, faces = ctx.consts
+        M = o.shape[0]
+        g_o, g_d = torch.zeros_like(o), torch.zeros_like(d)
+        cg = lambda t: t.contiguous() if t is not None else None
+        g_point, g_nrm, g_t = cg(g_point), cg(g_nrm), cg(g_t)
+        L.check(ctx.eng.lib.nu_s2_hit_bwd(c_p(addr(o)), c_p(addr(d)), c_p(addr(face)), c_p(addr(verts)), c_p(addr(vnrm)), c_p(addr(faces)), M,
+                                          c_p(addr(g_point)), c_p(addr(g_nrm)), c_p(addr(g_t)), c_p(addr(g_o)), c_p(addr(g_d)),
+                                          ctx.eng.stream()), "nu_s2_hit_bwd")
+        return None, g_o, g_d, None, None, None, None
+
+
+def hit(eng, scene, o, d, face):
+    """Differentiable intersection of the rays (o, d) [M,3] with the faces `face` [M] the LBVH found: (point, unit normal, t)."""
+    return _HitFn.apply(eng, o, d, face.contiguous(), scene.vertices, scene.normals, scene.faces)
+
+
+def far_importance_nodes(eng, start, dirs):
+    """Rays that miss the mesh (no gradient): 192 coarse nodes z in [0.1, 64] -> NeRF++ density -> 64 inverse-CDF samples merged
+    in.  Returns z [M, 256], sorted (renderer_zerothick.py:1786-1812)."""
+    M, dev = start.shape[0], start.device
+    zo = torch.linspace(0.1, 64.0, 192, device=dev)
+    zout = torch.empty(M, 256, device=dev)
+    if M == 0:
+        return zout
+    lib, S_ = eng.lib, eng.stream()
+    start, dirs = start.detach().contiguous(), dirs.detach().contiguous()
+    P = M * 192
+    pt, idx = eng.empty(P, 8), torch.empty(P, dtype=torch.int32, device=dev)
+    L.check(lib.nu_s2_far_points(c_p(addr(start)), c_p(addr(dirs)), c_p(addr(zo)), M, 192, c_p(addr(pt)), c_p(addr(idx)), S_),
+            "nu_s2_far_points")
+    alpha, color = eng.empty(P), eng.empty(P, 4)
+    eng.nerf_forward(pt, idx, P, alpha, color)
+    L.check(lib.nu_s2_far_resample(c_p(addr(alpha)), c_p(addr(zo)), M, 192, 64, c_p(addr(zout)), S_), "nu_s2_far_resample")
+    return zout

@@ -129,3 +129,56 @@ def test_outer_segments_match_the_eager_formulation(gpu):
             continue
         scale = float(b.abs().max()) + 1e-12
         assert float((a - b).abs().max()) <= 2e-4 * scale + 1e-7, (k, float((a - b).abs().max()), scale)
+
+
+def test_hit_matches_the_torch_dintersect(gpu):
+    """nu_s2_hit_fwd/_bwd against the eager Moeller-Trumbore + normal interpolation (lbvh.dintersect), values and d o, d d."""
+    from nu_nerf_amd import stage2_ops as O
+    from nu_nerf_amd.lbvh import dintersect
+    net, n1 = _eng(gpu)
+    scene = net.scene
+    torch.manual_seed(21)
+    R = 500
+    o = (F.normalize(torch.randn(R, 3, device=gpu), dim=-1) * 3.0)
+    d = F.normalize(-o + 0.15 * torch.randn(R, 3, device=gpu), dim=-1)
+    fi, hitted = scene.intersect(o, d)
+    assert int(hitted.sum()) > 100
+    oh, dh = o[hitted].clone().requires_grad_(True), d[hitted].clone().requires_grad_(True)
+    f = fi[hitted]
+    point, nrm, t = O.hit(n1.eng, scene, oh, dh, f)
+    tri = scene.faces[f]
+    u, v, t_ref, n_ref = dintersect(oh, dh, scene.vertices[tri], scene.normals[tri])
+    p_ref = oh + t_ref[:, None] * dh
+    torch.testing.assert_close(point, p_ref, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(nrm, n_ref, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(t, t_ref, rtol=1e-5, atol=1e-6)
+    g1, g2, g3 = torch.randn_like(point), torch.randn_like(nrm), torch.randn_like(t)
+    got = torch.autograd.grad((point * g1).sum() + (nrm * g2).sum() + (t * g3).sum(), (oh, dh))
+    want = torch.autograd.grad((p_ref * g1).sum() + (n_ref * g2).sum() + (t_ref * g3).sum(), (oh, dh))
+    for a, b in zip(got, want):
+        torch.testing.assert_close(a, b, rtol=5e-4, atol=5e-5)
+
+
+def test_far_importance_nodes_match_the_eager_formulation(gpu):
+    from nu_nerf_amd import stage2_ops as O
+    from nu_nerf_amd import torch_glue as G
+    net, n1 = _eng(gpu)
+    torch.manual_seed(31)
+    M = 41
+    sm = F.normalize(torch.randn(M, 3, device=gpu), dim=-1) * 4.0
+    dm = F.normalize(torch.randn(M, 3, device=gpu), dim=-1)
+    z = O.far_importance_nodes(n1.eng, sm, dm)
+    with torch.no_grad():
+        zo = torch.linspace(0.1, 64.0, 192, device=gpu)
+        pts = sm[:, None, :] + dm[:, None, :] * zo[None, :, None]
+        zo2 = zo[None, :].expand(M, 192)
+        dists = zo2[..., 1:] - zo2[..., :-1]
+        dists = torch.cat([dists, dists[..., -1:]], -1)
+        alpha, _ = net._density_alpha(n1, pts.reshape(-1, 3), dists.reshape(-1), dm[:, None, :].expand(-1, 192, 3).reshape(-1, 3))
+        alpha = alpha.reshape(M, 192)
+        w = alpha * G.cumprod_excl(alpha)[:, :-1]
+        newz = G.sample_pdf_det(zo2.contiguous(), w[:, :-1], 64)
+        ref = torch.sort(torch.cat([zo2, newz], -1), dim=-1)[0]
+    assert z.shape == ref.shape and bool((z[:, 1:] >= z[:, :-1]).all())
+    # the 192 coarse nodes are reproduced exactly; the 64 inverse-CDF samples to the rounding of the running sums
+    torch.testing.assert_close(z, ref, rtol=2e-5, atol=2e-5)
