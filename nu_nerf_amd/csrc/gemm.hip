@@ -1797,7 +1797,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn16x256_kernel(NuGemmTN g) {
 // ------------------------------------------------------------------------------------------------
 template <bool BIG>
 __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(NuGemmTN g) {
-    __shared__ __attribute__((aligned(16))) float smem[2][256 * NT_LDS];      // [A | B][column][k (+4 pad)] = 73,728 B
+    __shared__ __attribute__((aligned(16))) float smem[2][2][256 * NT_LDS];   // [stage][A | B][column][k (+4 pad)] = 2 x 73,728 B
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wid = tid >> 6;
@@ -1834,86 +1834,107 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(NuGemmTN g) {
     int nvalid = 16;
     bool pend_pair0 = true;
     float bs = 0.f;
-    auto load_tile = [&](int t) {
+    // The loader is cut into pieces that sit BETWEEN groups of 8 MFMAs (pinned with sched_barrier): the two waves of a SIMD leave
+    // every barrier in the same phase, so whatever a wave issues in a block at the top of the chunk -- 32 scalar loads, their
+    // address arithmetic, 8 ds_write_b128 -- is time in which NEITHER issues MFMAs (measured: matrix pipe 74 % busy).
+    const char* __restrict__ ldA = nullptr;
+    const char* __restrict__ ldB = nullptr;
+    int ld_lda = 0, ld_ldb = 0, ld_ca = 0, ld_cb = 0, ld_pbase = 0;
+    int nvalid_ld = 16;
+    bool pair0_ld = true;
+    auto load_begin = [&](int t) {
         const int pair = t >= ntile ? 1 : 0;
         const int kt = t - pair * ntile;
-        const char* __restrict__ A = (const char*)(pair ? g.A1 + (long long)grp * g.sA1 : g.A0 + (long long)grp * g.sA0);
-        const char* __restrict__ B = (const char*)(pair ? g.B1 + (long long)grp * g.sB1 : g.B0 + (long long)grp * g.sB0);
-        const int lda = pair ? g.lda1 : g.lda0;
-        const int ldb = pair ? g.ldb1 : g.ldb0;
-        int ca = n1_0 + c, cb = n2_0 + c;
-        ca = ca < lda ? ca : lda - 1;
-        cb = cb < ldb ? cb : ldb - 1;
-        const int pbase = p_begin + kt * TBK + kg * 16;
-        nvalid = p_end - pbase;
-        pend_pair0 = pair == 0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                int pr = pbase + 4 * i + e;
-                pr = pr < p_end ? pr : p_end - 1;
-                if (BIG) {
-                    ra4[i][e] = reinterpret_cast<const float*>(A)[(long long)pr * lda + ca];
-                    rb4[i][e] = reinterpret_cast<const float*>(B)[(long long)pr * ldb + cb];
-                } else {
-                    const unsigned oa = ((unsigned)pr * (unsigned)lda + (unsigned)ca) * 4u;
-                    const unsigned ob = ((unsigned)pr * (unsigned)ldb + (unsigned)cb) * 4u;
-                    ra4[i][e] = *reinterpret_cast<const float*>(A + oa);
-                    rb4[i][e] = *reinterpret_cast<const float*>(B + ob);
-                }
-            }
+        ldA = (const char*)(pair ? g.A1 + (long long)grp * g.sA1 : g.A0 + (long long)grp * g.sA0);
+        ldB = (const char*)(pair ? g.B1 + (long long)grp * g.sB1 : g.B0 + (long long)grp * g.sB0);
+        ld_lda = pair ? g.lda1 : g.lda0;
+        ld_ldb = pair ? g.ldb1 : g.ldb0;
+        ld_ca = n1_0 + c; ld_cb = n2_0 + c;
+        ld_ca = ld_ca < ld_lda ? ld_ca : ld_lda - 1;
+        ld_cb = ld_cb < ld_ldb ? ld_cb : ld_ldb - 1;
+        ld_pbase = p_begin + kt * TBK + kg * 16;
+        nvalid_ld = p_end - ld_pbase;
+        pair0_ld = pair == 0;
     };
-    auto store_tile = [&]() {
+    auto load_piece = [&](int i, int e0, int e1) {          // rows 4 i + e0 .. 4 i + e1 - 1 of this thread's 16
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const bool ok = 4 * i + e < nvalid;
-                ra4[i][e] = ok ? ra4[i][e] : 0.f;
-                rb4[i][e] = ok ? rb4[i][e] : 0.f;
+        for (int e = e0; e < e1; ++e) {
+            int pr = ld_pbase + 4 * i + e;
+            pr = pr < p_end ? pr : p_end - 1;
+            if (BIG) {
+                ra4[i][e] = reinterpret_cast<const float*>(ldA)[(long long)pr * ld_lda + ld_ca];
+                rb4[i][e] = reinterpret_cast<const float*>(ldB)[(long long)pr * ld_ldb + ld_cb];
+            } else {
+                const unsigned oa = ((unsigned)pr * (unsigned)ld_lda + (unsigned)ld_ca) * 4u;
+                const unsigned ob = ((unsigned)pr * (unsigned)ld_ldb + (unsigned)ld_cb) * 4u;
+                ra4[i][e] = *reinterpret_cast<const float*>(ldA + oa);
+                rb4[i][e] = *reinterpret_cast<const float*>(ldB + ob);
             }
-        if (do_bias && pend_pair0) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) bs += (ra4[i][0] + ra4[i][1]) + (ra4[i][2] + ra4[i][3]);
         }
+    };
+    auto store_piece = [&](int st, int i) {                 // the chunk in registers: nvalid / pend_pair0 describe it
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<f32x4*>(&smem[0][c * NT_LDS + kg * 16 + 4 * i]) = ra4[i];
-            *reinterpret_cast<f32x4*>(&smem[1][c * NT_LDS + kg * 16 + 4 * i]) = rb4[i];
+        for (int e = 0; e < 4; ++e) {
+            const bool ok = 4 * i + e < nvalid;
+            ra4[i][e] = ok ? ra4[i][e] : 0.f;
+            rb4[i][e] = ok ? rb4[i][e] : 0.f;
         }
+        if (do_bias && pend_pair0) bs += (ra4[i][0] + ra4[i][1]) + (ra4[i][2] + ra4[i][3]);
+        *reinterpret_cast<f32x4*>(&smem[st][0][c * NT_LDS + kg * 16 + 4 * i]) = ra4[i];
+        *reinterpret_cast<f32x4*>(&smem[st][1][c * NT_LDS + kg * 16 + 4 * i]) = rb4[i];
+    };
+    auto load_tile = [&](int t) {
+        load_begin(t);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) load_piece(i, 0, 4);
+        nvalid = nvalid_ld; pend_pair0 = pair0_ld;
+    };
+    auto store_tile = [&](int st) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) store_piece(st, i);
     };
 
+    // two LDS stages: chunk t+1 waits in registers (fetched during chunk t-1), goes to the other stage in the MIDDLE of chunk t's
+    // MFMAs, and the registers are re-issued for chunk t+2 at once: one barrier per chunk, no store between barriers
     if (total > 0) {
         load_tile(0);
-        store_tile();
+        store_tile(0);
+        if (total > 1) load_tile(1);
     }
     __syncthreads();
 
     const int li = lane & 31, lh = lane >> 5;
     const int a_off = (wr * 64 + li) * NT_LDS + 4 * lh;
     const int b_off = (wc * 128 + li) * NT_LDS + 4 * lh;
+    int cur = 0;
     for (int t = 0; t < total; ++t) {
-        if (t + 1 < total) load_tile(t + 1);
+        const bool st_on = t + 1 < total, ld_on = t + 2 < total;
+        if (ld_on) load_begin(t + 2);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             f32x4 a[2], b[4];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const f32x4*>(&smem[0][a_off + 32 * i * NT_LDS + kk * 8]);
+            for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const f32x4*>(&smem[cur][0][a_off + 32 * i * NT_LDS + kk * 8]);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const f32x4*>(&smem[1][b_off + 32 * j * NT_LDS + kk * 8]);
+            for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const f32x4*>(&smem[cur][1][b_off + 32 * j * NT_LDS + kk * 8]);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+            for (int e = 0; e < 4; ++e) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                // register piece kk: handed to the other stage behind the first group of 8 MFMAs, re-issued behind the next two
+                if (e == 0 && st_on) store_piece(cur ^ 1, kk);
+                if (e == 1 && ld_on) load_piece(kk, 0, 2);
+                if (e == 2 && ld_on) load_piece(kk, 2, 4);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
+        nvalid = nvalid_ld; pend_pair0 = pair0_ld;
         __syncthreads();
-        if (t + 1 < total) {
-            store_tile();
-            __syncthreads();
-        }
+        cur ^= 1;
     }
 
     float* __restrict__ slab = g.slab + (long long)grp * g.sSlab + (long long)split * N1p * N2p;
@@ -1929,7 +1950,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(NuGemmTN g) {
             }
         }
     if (do_bias) {
-        float* red = &smem[0][0];
+        float* red = &smem[0][0][0];
         red[kg * 256 + c] = bs;
         __syncthreads();
         if (tid < 256) g.bias_slab[(long long)grp * g.sBiasSlab + (long long)split * N1p + n1_0 + tid] = red[tid] + red[256 + tid];
