@@ -405,6 +405,24 @@ class Stage1Engine:
         self.inner_weight = predictor('inner_weight', 96)
         self.refrac_light = predictor('refrac_light', self.ld_rl)
         layers += self.outer_light + self.inner_light + self.inner_weight + self.refrac_light
+        # ---- stage 2: the IoR network (field.py:1046-1066: 39 -> 256 ReLU -> 256 ReLU -> 256 -> 1), when the owner has one ----
+        self.ior = None
+        if 'ior_network.0.weight_v' in p:
+            self.ior = []
+            for j, idx in enumerate((0, 2, 4, 5)):
+                q = f'ior_network.{idx}'
+                v = p[q + '.weight_v']
+                N, K = v.shape
+                Kp = 64 if j == 0 else 256
+                lay = _Layer(q, v, p[q + '.weight_g'], p[q + '.bias'], N, K, Kp)
+                lay.Wp = (z(rup(N, 128) if j < 3 else N, Kp), 0)
+                if j < 3:
+                    lay.WpT, lay.ldT = (z(rup(Kp, 128), 256), 0), 256
+                lay.dWp, lay.ldd = (z(N, Kp), 0), Kp
+                lay.dv_off, lay.dg_off, lay.db_off = galloc(N * K), galloc(N), galloc(N)
+                reg(q + '.weight_v', lay.dv_off); reg(q + '.weight_g', lay.dg_off); reg(q + '.bias', lay.db_off)
+                self.ior.append(lay)
+            layers += self.ior
         self.layers = layers
         self.n_grad = self._goff
         # bf16 copies of every NT-side weight table (written by the same pack launch): same shapes, same element offsets

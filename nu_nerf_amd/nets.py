@@ -214,6 +214,52 @@ class MaterialsFn(torch.autograd.Function):
         return None, dYX[:, 1:257], dYX[:, 257:260], None, _token_grad(eng, flat, ctx.names)
 
 
+class IorFn(torch.autograd.Function):
+    """The stage-2 IoR network on the HIP GEMMs (field.py:1046-1066): X [rows, 39] (the 6-frequency embedding of the hit point)
+    -> 256 ReLU -> 256 ReLU -> 256 (no activation) -> 1 raw output (the caller applies the sigmoid); gradients w.r.t. X and the
+    weight-normed parameters."""
+
+    @staticmethod
+    def forward(ctx, eng, X, names, token):
+        from .engine import EPI_BIAS_NONE, EPI_BIAS_RELU
+        ls = eng.ior
+        rows, K = X.shape
+        Xp = eng.zeros(rows, 64)
+        Xp[:, :K] = X.detach()
+        H = [eng.empty(rows, 256) for _ in range(3)]
+        eng.nt(addr(Xp), 64, addr(*ls[0].Wp), 64, rows, 256, 64, addr(H[0]), 256, EPI_BIAS_RELU, bias=addr(ls[0].b))
+        eng.nt(addr(H[0]), 256, addr(*ls[1].Wp), 256, rows, 256, 256, addr(H[1]), 256, EPI_BIAS_RELU, bias=addr(ls[1].b))
+        eng.nt(addr(H[1]), 256, addr(*ls[2].Wp), 256, rows, 256, 256, addr(H[2]), 256, EPI_BIAS_NONE, bias=addr(ls[2].b))
+        out = eng.empty(rows, 1)
+        eng.skinny_fwd(addr(H[2]), 256, rows, 256, addr(*ls[3].Wp), 256, addr(ls[3].b), 1, addr(out), 1)
+        ctx.eng, ctx.names, ctx.Xp, ctx.H, ctx.K = eng, names, Xp, H, K
+        ctx.set_materialize_grads(False)
+        return out[:, 0].clone()
+
+    @staticmethod
+    def backward(ctx, dout):
+        from .engine import EPI_MUL_DRELU, EPI_PLAIN
+        eng, ls, Xp, H = ctx.eng, ctx.eng.ior, ctx.Xp, ctx.H
+        rows = Xp.shape[0]
+        flat = eng.zeros(eng.n_grad)
+        dy = (dout.contiguous() if dout is not None else eng.zeros(rows)).reshape(rows, 1).contiguous()
+        d2 = eng.empty(rows, 256)
+        eng.skinny_bwd(addr(dy), 1, addr(H[2]), 256, rows, 256, addr(*ls[3].Wp), 256, 1, addr(d2), 256, 0, 0,
+                       addr(*ls[3].dWp), ls[3].ldd, addr(flat, ls[3].db_off))
+        eng.wgrad(addr(d2), 256, addr(H[1]), 256, rows, 256, 256, addr(*ls[2].dWp), ls[2].ldd, addr(flat, ls[2].db_off))
+        d1 = eng.empty(rows, 256)
+        eng.nt(addr(d2), 256, addr(*ls[2].WpT), ls[2].ldT, rows, 256, 256, addr(d1), 256, EPI_MUL_DRELU, H=addr(H[1]), ldh=256)
+        eng.wgrad(addr(d1), 256, addr(H[0]), 256, rows, 256, 256, addr(*ls[1].dWp), ls[1].ldd, addr(flat, ls[1].db_off))
+        d0 = eng.empty(rows, 256)
+        eng.nt(addr(d1), 256, addr(*ls[1].WpT), ls[1].ldT, rows, 256, 256, addr(d0), 256, EPI_MUL_DRELU, H=addr(H[0]), ldh=256)
+        eng.wgrad(addr(d0), 256, addr(Xp), 64, rows, 256, 64, addr(*ls[0].dWp), ls[0].ldd, addr(flat, ls[0].db_off))
+        dX = eng.empty(rows, 64)
+        eng.nt(addr(d0), 256, addr(*ls[0].WpT), ls[0].ldT, rows, 64, 256, addr(dX), 64, EPI_PLAIN)
+        eng.unpack_grads(flat)
+        ctx.H = ctx.Xp = None
+        return None, dX[:, :ctx.K], None, _token_grad(eng, flat, ctx.names)
+
+
 class Stage1Nets:
     """Differentiable callables over one Stage1Engine (SDF, variance, NeRF++, the shading predictors)."""
 
@@ -236,6 +282,7 @@ class Stage1Nets:
                            ('inner_weight', eng.inner_weight), ('refrac_light', eng.refrac_light)):
             names, params = sel(lambda n, nm=nm: n.startswith('color_network.' + nm + '.'))
             self.stack[nm] = (layers, names, params)
+        self.ior_names, _ = sel(lambda n: n.startswith('ior_network.'))
         self.all_names = [n for n in g if n in named and isinstance(named[n], torch.nn.Parameter)]
         self._token = None
 
@@ -260,6 +307,10 @@ class Stage1Nets:
 
     def materials(self, feat, x):
         return MaterialsFn.apply(self.eng, feat, x, self.mat_names, self.token())
+
+    def ior(self, X):
+        """Raw (pre-sigmoid) output of the IoR network on encoded points X [rows, 39]."""
+        return IorFn.apply(self.eng, X, self.ior_names, self.token())
 
     def predictor(self, name, X):
         layers, names, params = self.stack[name]

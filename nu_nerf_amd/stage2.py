@@ -7,7 +7,8 @@ What runs where in this first version:
     the INPUT gradients that carry d L / d IoR: HIP GEMMs through nu_nerf_amd/nets.py;
   * the no-grad segment samplers: HIP sampler kernels for the inner-SDF up-sampling, torch for the NeRF++ importance pass;
   * the ragged per-bounce bookkeeping, encodings, BRDF mix and segment composites: torch ops (nu_nerf_amd/torch_glue.py);
-  * the IoR network (<= train_ray_num rows per bounce, 0.01 % of the FLOPs): torch.
+  * the IoR network: HIP GEMMs through the inner engine (nets.IorFn); `IoRNetwork.forward` below is kept for the two
+    networks the zero-thickness variant never evaluates (IoRint_pred, thickness_pred).
 state_dict() names/order equal the reference's (574 entries incl. the `color_network.stage1_network.*` aliases).
 """
 import ctypes
@@ -173,6 +174,8 @@ class Stage2Renderer(nn.Module):
             named['color_network.FG_LUT'] = self.color_network_inner.FG_LUT
             for k, p in s1.outer_nerf.named_parameters():      # placeholder: the inner engine never evaluates a NeRF++
                 named['outer_nerf.' + k] = p
+            for k, p in self.IORs_pred.module0.named_parameters():   # the IoR network rides on the inner engine's GEMMs
+                named['ior_network.' + k] = p
             ecfg = dict(self.cfg)
             ecfg.update(self.color_network_inner.cfg)
             n2 = Stage1Nets(Stage1Engine(named, dev, ecfg), named)
@@ -246,7 +249,7 @@ class Stage2Renderer(nn.Module):
             normal = F.normalize(inter['n'], dim=-1) if outside else -F.normalize(inter['n'], dim=-1)
             infinity_bkgr.append(~converged)
             mask = converged.flatten()
-            ior = self.IORs_pred(point.reshape(-1, 3)).reshape(-1)
+            ior = torch.sigmoid(n2.ior(G.embed(point.reshape(-1, 3), 6)))       # IoRNetwork (field.py:1046-1066) on the HIP GEMMs
             refr, eta, nd_all, ns_all = O.refract(n1.eng, next_dir[mask], normal, ior, point, outside)   # HIP, fwd + bwd
             converged_out = converged.clone()
             converged_out[mask] = refr[:, None]
