@@ -423,6 +423,15 @@ int nu_s2_hit_bwd(const float* o, const float* d, const long long* face, const f
                   int M, const float* g_point, const float* g_nrm, const float* g_t, float* g_o, float* g_d, hipStream_t stream);
 int nu_s2_far_points(const float* start, const float* dirs, const float* zo, int M, int S, float* pt, int* idx, hipStream_t stream);
 int nu_s2_far_resample(const float* alpha, const float* zo, int M, int S, int n_new, float* zout, hipStream_t stream);
+/*   nu_s2_shade_combine_fwd / _bwd      AppShadingNetwork_S2.forward's BRDF mix (field.py:909-1010) on raw head outputs, layouts as
+ *                                       nu_shade_combine_*: colour = (diffuse + specular)(1 - T) + F light0 T (x 0 when `internal`),
+ *                                       rc [P] = (1 - F) T */
+int nu_s2_shade_combine_fwd(const float* Mraw, int ldm, const float* OLo, const float* ILo, const float* IWo, const float* SD,
+                            const float* lut, const int* idx, int P, float exp_max, int internal, float* color_rm, float* rc,
+                            hipStream_t stream);
+int nu_s2_shade_combine_bwd(const float* Mraw, int ldm, const float* OLo, const float* ILo, const float* IWo, const float* SD,
+                            const float* lut, const int* idx, int P, float exp_max, int internal, const float* dcolor_rm, const float* d_rc,
+                            float* dMraw, float* dOLo, float* dILo, float* dIWo, float* dNoV, hipStream_t stream);
 
 
 /* ---------------------------------------------------------------------------------------------------------

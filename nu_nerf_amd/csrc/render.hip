@@ -383,7 +383,10 @@ static __device__ inline NuLut nu_lut(const float* __restrict__ lut, float u, fl
     return o;
 }
 
-template <bool BWD>
+// S2 = AppShadingNetwork_S2.forward (field.py:909-1010, the stage-2 surface shading): no refraction light -- the transmitted part
+// continues along the refracted ray -- colour = (diffuse + specular) (1 - T) + F light0 T, second output (1 - F) T (the factor the
+// running transmittance is multiplied with); `internal` (hit from inside the object): the colour is multiplied by zero.
+template <bool BWD, bool S2>
 __global__ __launch_bounds__(256) void shade_combine_kernel(
     const float* __restrict__ Mraw, int ldm, const float* __restrict__ OLo, const float* __restrict__ ILo,
     const float* __restrict__ IWo, const float* __restrict__ RLo, const float* __restrict__ SD,
@@ -392,7 +395,9 @@ __global__ __launch_bounds__(256) void shade_combine_kernel(
     float* __restrict__ color_rm, float* __restrict__ aux,  // aux [P,4]: occ_prob, transmission, metallic, roughness
     // backward
     const float* __restrict__ dcolor_rm, float* __restrict__ dMraw, float* __restrict__ dOLo, float* __restrict__ dILo,
-    float* __restrict__ dIWo, float* __restrict__ dRLo, float* __restrict__ dNoV) {
+    float* __restrict__ dIWo, float* __restrict__ dRLo, float* __restrict__ dNoV,
+    // S2 only
+    float* __restrict__ rc_out = nullptr, const float* __restrict__ d_rc = nullptr, int internal = 0) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P) return;
     const float* mr = Mraw + (long long)p * ldm;
@@ -408,7 +413,7 @@ __global__ __launch_bounds__(256) void shade_combine_kernel(
         rdir0[c] = OLo[(long long)(2LL * P + p) * 4 + c];
         rind[c] = ILo[(long long)p * 4 + c];
         rind0[c] = ILo[(long long)(P + p) * 4 + c];
-        rrefr[c] = RLo[(long long)p * 4 + c];
+        rrefr[c] = S2 ? 0.f : RLo[(long long)p * 4 + c];
         Ld[c] = expf(fminf(rLd[c], exp_max));
         dir[c] = expf(fminf(rdir[c], exp_max));
         dir0[c] = expf(fminf(rdir0[c], exp_max));
@@ -432,12 +437,14 @@ __global__ __launch_bounds__(256) void shade_combine_kernel(
         light[c] = ind[c] * oc + dir[c] * (1.0f - oc);
         light0[c] = ind0[c] * oc + dir0[c] * (1.0f - oc);
         const float spec = (sa[c] * L.A + L.B) * light[c];
-        lin[c] = (diffuse + spec) * (1.0f - T) + (F * light0[c] + (1.0f - F) * refr[c]) * T;
+        lin[c] = (diffuse + spec) * (1.0f - T) + (S2 ? F * light0[c] : F * light0[c] + (1.0f - F) * refr[c]) * T;
+        if (S2 && internal) lin[c] = lin[c] * 0.f;
     }
     const int k = idx[p];
     if (!BWD) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) color_rm[k * 4LL + c] = nu_linear_to_srgb(lin[c]);
+        if (S2) rc_out[p] = (1.0f - F) * T;
         if (aux) {
             f32x4 a = {occ, T, met, rho};
             *reinterpret_cast<f32x4*>(aux + (long long)p * 4) = a;
@@ -445,19 +452,23 @@ __global__ __launch_bounds__(256) void shade_combine_kernel(
         return;
     }
     float dmet = 0.f, drho = 0.f, dT = 0.f, dalb[3], docc_c = 0.f, dF = 0.f, dA = 0.f, dB = 0.f;
+    if (S2 && d_rc) {                    // second output (1 - F) T
+        dF -= d_rc[p] * T;
+        dT += d_rc[p] * (1.0f - F);
+    }
     float* gOL0 = dOLo + (long long)p * 4;
     float* gOL1 = dOLo + (long long)(P + p) * 4;
     float* gOL2 = dOLo + (long long)(2LL * P + p) * 4;
     float* gIL0 = dILo + (long long)p * 4;
     float* gIL1 = dILo + (long long)(P + p) * 4;
-    float* gRL = dRLo + (long long)p * 4;
+    float* gRL = S2 ? nullptr : dRLo + (long long)p * 4;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        const float g = dcolor_rm[k * 4LL + c] * nu_linear_to_srgb_grad(lin[c]);
+        const float g = (S2 && internal) ? 0.f : dcolor_rm[k * 4LL + c] * nu_linear_to_srgb_grad(lin[c]);
         const float diffuse = (1.0f - met) * alb[c] * Ld[c];
         const float specw = sa[c] * L.A + L.B;
         const float spec = specw * light[c];
-        const float mixT = F * light0[c] + (1.0f - F) * refr[c];
+        const float mixT = S2 ? F * light0[c] : F * light0[c] + (1.0f - F) * refr[c];
         dT += g * (mixT - (diffuse + spec));
         const float gd = g * (1.0f - T);   // d diffuse, d spec
         const float gm = g * T;            // d mixT
@@ -474,7 +485,7 @@ __global__ __launch_bounds__(256) void shade_combine_kernel(
         dmet += dsa * (alb[c] - 0.04f);
         dalb[c] += dsa * met;
         // mixT
-        dF += gm * (light0[c] - refr[c]);
+        dF += gm * (S2 ? light0[c] : light0[c] - refr[c]);
         const float dlight0 = gm * F;
         const float drefr = gm * (1.0f - F);
         // light mixes
@@ -487,9 +498,10 @@ __global__ __launch_bounds__(256) void shade_combine_kernel(
         gOL2[c] = rdir0[c] <= exp_max ? ddir0 * dir0[c] : 0.f;
         gIL0[c] = rind[c] <= exp_max ? dind * ind[c] : 0.f;
         gIL1[c] = rind0[c] <= exp_max ? dind0 * ind0[c] : 0.f;
-        gRL[c] = rrefr[c] <= exp_max ? drefr * refr[c] : 0.f;
+        if (!S2) gRL[c] = rrefr[c] <= exp_max ? drefr * refr[c] : 0.f;
     }
-    gOL0[3] = 0.f; gOL1[3] = 0.f; gOL2[3] = 0.f; gIL0[3] = 0.f; gIL1[3] = 0.f; gRL[3] = 0.f;
+    gOL0[3] = 0.f; gOL1[3] = 0.f; gOL2[3] = 0.f; gIL0[3] = 0.f; gIL1[3] = 0.f;
+    if (!S2) gRL[3] = 0.f;
     // occlusion: occ = 0.5 raw + 0.5, clamp passes gradient on [0,1]
     dIWo[p] = (occ >= 0.f && occ <= 1.f) ? docc_c * 0.5f : 0.f;
     // Fresnel: F = clamp(0.04 + 0.96 t^5), t = clamp(1 - NoV)
@@ -517,9 +529,10 @@ extern "C" int nu_shade_combine_fwd(const float* Mraw, int ldm, const float* OLo
                                     const float* RLo, const float* SD, const float* lut, const int* idx, int P,
                                     float exp_max, float* color_rm, float* aux, hipStream_t stream) {
     if (P <= 0) return NU_OK;
-    hipLaunchKernelGGL(shade_combine_kernel<false>, dim3(nu_cdiv(P, 256)), dim3(256), 0, stream, Mraw, ldm, OLo, ILo, IWo,
+    hipLaunchKernelGGL((shade_combine_kernel<false, false>), dim3(nu_cdiv(P, 256)), dim3(256), 0, stream, Mraw, ldm, OLo, ILo, IWo,
                        RLo, SD, lut, idx, P, exp_max, color_rm, aux, (const float*)nullptr, (float*)nullptr,
-                       (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr);
+                       (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr,
+                       (const float*)nullptr, 0);
     return nu_launch_status();
 }
 extern "C" int nu_shade_combine_bwd(const float* Mraw, int ldm, const float* OLo, const float* ILo, const float* IWo,
@@ -527,9 +540,31 @@ extern "C" int nu_shade_combine_bwd(const float* Mraw, int ldm, const float* OLo
                                     float exp_max, const float* dcolor_rm, float* dMraw, float* dOLo, float* dILo,
                                     float* dIWo, float* dRLo, float* dNoV, hipStream_t stream) {
     if (P <= 0) return NU_OK;
-    hipLaunchKernelGGL(shade_combine_kernel<true>, dim3(nu_cdiv(P, 256)), dim3(256), 0, stream, Mraw, ldm, OLo, ILo, IWo,
+    hipLaunchKernelGGL((shade_combine_kernel<true, false>), dim3(nu_cdiv(P, 256)), dim3(256), 0, stream, Mraw, ldm, OLo, ILo, IWo,
                        RLo, SD, lut, idx, P, exp_max, (float*)nullptr, (float*)nullptr, dcolor_rm, dMraw, dOLo, dILo, dIWo,
-                       dRLo, dNoV);
+                       dRLo, dNoV, (float*)nullptr, (const float*)nullptr, 0);
+    return nu_launch_status();
+}
+
+// stage-2 surface shading (AppShadingNetwork_S2): colour [P,4] sRGB (scattered through idx), rc [P] = (1 - F) T
+extern "C" int nu_s2_shade_combine_fwd(const float* Mraw, int ldm, const float* OLo, const float* ILo, const float* IWo, const float* SD,
+                                       const float* lut, const int* idx, int P, float exp_max, int internal, float* color_rm, float* rc,
+                                       hipStream_t stream) {
+    if (P <= 0) return NU_OK;
+    hipLaunchKernelGGL((shade_combine_kernel<false, true>), dim3(nu_cdiv(P, 256)), dim3(256), 0, stream, Mraw, ldm, OLo, ILo, IWo,
+                       (const float*)nullptr, SD, lut, idx, P, exp_max, color_rm, (float*)nullptr, (const float*)nullptr, (float*)nullptr,
+                       (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, rc, (const float*)nullptr,
+                       internal);
+    return nu_launch_status();
+}
+extern "C" int nu_s2_shade_combine_bwd(const float* Mraw, int ldm, const float* OLo, const float* ILo, const float* IWo, const float* SD,
+                                       const float* lut, const int* idx, int P, float exp_max, int internal, const float* dcolor_rm,
+                                       const float* d_rc, float* dMraw, float* dOLo, float* dILo, float* dIWo, float* dNoV,
+                                       hipStream_t stream) {
+    if (P <= 0) return NU_OK;
+    hipLaunchKernelGGL((shade_combine_kernel<true, true>), dim3(nu_cdiv(P, 256)), dim3(256), 0, stream, Mraw, ldm, OLo, ILo, IWo,
+                       (const float*)nullptr, SD, lut, idx, P, exp_max, (float*)nullptr, (float*)nullptr, dcolor_rm, dMraw, dOLo, dILo,
+                       dIWo, (float*)nullptr, dNoV, (float*)nullptr, d_rc, internal);
     return nu_launch_status();
 }
 

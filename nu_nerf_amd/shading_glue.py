@@ -10,6 +10,9 @@ import torch.nn.functional as F
 from . import torch_glue as G
 
 
+FUSED_COMBINE = True     # False: the eager formulation everywhere (the parity tests' checker)
+
+
 def offset_points_to_sphere(points):
     """field.py:447-455"""
     nrm = torch.norm(points, dim=-1, keepdim=True)
@@ -54,13 +57,44 @@ def lights(nets, exp_max, points, n, refl, rough, sphere=False, detail=False):
     return lo[:P], light, light0
 
 
+def raw_lights(nets, points, n, refl, rough, sphere=False):
+    """Raw (pre-activation) heads of the light predictors, row-batched as `lights` does: outer_light [3P,3], inner_light [2P,3],
+    inner_weight [P,1]."""
+    P = points.shape[0]
+    one, zero = torch.ones_like(rough), torch.zeros_like(rough)
+    enc = torch.cat([G.ide(n, one), G.ide(refl, rough), G.ide(refl, zero)], 0)
+    if sphere:
+        sn, sr = sphere_point(points, n), sphere_point(points, refl)
+        enc_ol = torch.cat([enc, torch.cat([G.ide(sn, one), G.ide(sr, rough), G.ide(sr, rough)], 0)], -1)
+    else:
+        enc_ol = enc
+    ol = nets.predictor('outer_light', enc_ol)
+    pe = G.embed(points, 6)
+    il = nets.predictor('inner_light', torch.cat([torch.cat([pe, enc[P:2 * P]], -1), torch.cat([pe, enc[2 * P:]], -1)], 0))
+    iw = nets.predictor('inner_weight', torch.cat([pe.detach(), G.embed(refl, 6).detach()], -1))
+    return ol, il, iw
+
+
 def shade(nets, scfg, lut, points, normals, view_dirs, feats, s2=False, is_internal=False, inter_results=False):
-    """AppShadingNetwork.forward (field.py:684-777) or, with s2=True, AppShadingNetwork_S2.forward (field.py:909-1010)."""
+    """AppShadingNetwork.forward (field.py:684-777) or, with s2=True, AppShadingNetwork_S2.forward (field.py:909-1010).
+    Without inter_results the BRDF mix runs as one HIP kernel pair on the raw head outputs (stage2_ops.shade_combine); the
+    eager formulation below it serves the validation images (inter_results=True)."""
     exp_max = scfg['light_exp_max']
     sphere = bool(scfg.get('sphere_direction', False))
     n, v = F.normalize(normals, dim=-1), F.normalize(view_dirs, dim=-1)
     nov = torch.sum(n * v, -1, keepdim=True)
     refl = nov * n * 2 - v
+    if FUSED_COMBINE and not inter_results and points.is_cuda and points.shape[0] > 0:
+        from . import stage2_ops as O
+        m_raw = nets.materials(feats, points)
+        rough = torch.sigmoid(m_raw[:, 1:2])
+        ol, il, iw = raw_lights(nets, points, n, refl, rough, sphere)
+        rl = None
+        if not s2:
+            rf = scfg.get('refrac_freq', 6)
+            rl = nets.predictor('refrac_light', torch.cat([G.embed(points, rf), G.embed(v, rf)], -1))
+        color, rc = O.shade_combine(nets.eng, m_raw, ol, il, iw, rl, nov, lut, exp_max, s2=s2, internal=is_internal)
+        return color, (rc if s2 else None)
     m = torch.sigmoid(nets.materials(feats, points))
     metallic, rough, albedo, trans = m[:, 0:1], m[:, 1:2], m[:, 2:5], m[:, 5:6]
     diffuse_light, light, light0, occ, indirect = lights(nets, exp_max, points, n, refl, rough, sphere, detail=True)

@@ -220,3 +220,67 @@ def far_importance_nodes(eng, start, dirs):
     eng.nerf_forward(pt, idx, P, alpha, color)
     L.check(lib.nu_s2_far_resample(c_p(addr(alpha)), c_p(addr(zo)), M, 192, 64, c_p(addr(zout)), S_), "nu_s2_far_resample")
     return zout
+
+
+class _ShadeCombineFn(torch.autograd.Function):
+    """The BRDF mix on raw head outputs (nu_shade_combine_* for AppShadingNetwork.forward, nu_s2_shade_combine_* for
+    AppShadingNetwork_S2.forward): sigmoids of the material heads, exp(min(., exp_max)) of the light heads, occlusion mix, Schlick
+    Fresnel, split-sum LUT (bilinear, clamp), sRGB."""
+
+    @staticmethod
+    def forward(ctx, eng, m_raw, ol_raw, il_raw, iw_raw, rl_raw, nov, lut, exp_max, s2, internal):
+        P, dev = m_raw.shape[0], m_raw.device
+        pad = lambda t, rows, w: torch.cat([t.detach(), torch.zeros(rows, w - t.shape[1], device=dev)], 1).contiguous()
+        Mraw, OLo, ILo = pad(m_raw, P, 8), pad(ol_raw, 3 * P, 4), pad(il_raw, 2 * P, 4)
+        IWo = iw_raw.detach().reshape(P).contiguous()
+        RLo = None if s2 else pad(rl_raw, P, 4)
+        SD = torch.zeros(P, 8, device=dev)
+        SD[:, 3] = nov.detach().reshape(P)
+        idx = torch.arange(P, dtype=torch.int32, device=dev)
+        color = torch.empty(P, 4, device=dev)
+        rc = torch.empty(P, device=dev)
+        lib, S_ = eng.lib, eng.stream()
+        if s2:
+            L.check(lib.nu_s2_shade_combine_fwd(c_p(addr(Mraw)), 8, c_p(addr(OLo)), c_p(addr(ILo)), c_p(addr(IWo)), c_p(addr(SD)),
+                                                c_p(addr(lut)), c_p(addr(idx)), P, ctypes.c_float(exp_max), 1 if internal else 0,
+                                                c_p(addr(color)), c_p(addr(rc)), S_), "nu_s2_shade_combine_fwd")
+        else:
+            L.check(lib.nu_shade_combine_fwd(c_p(addr(Mraw)), 8, c_p(addr(OLo)), c_p(addr(ILo)), c_p(addr(IWo)), c_p(addr(RLo)),
+                                             c_p(addr(SD)), c_p(addr(lut)), c_p(addr(idx)), P, ctypes.c_float(exp_max), c_p(addr(color)),
+                                             c_p(0), S_), "nu_shade_combine_fwd")
+        ctx.eng, ctx.cfg, ctx.bufs = eng, (exp_max, s2, internal), (Mraw, OLo, ILo, IWo, RLo, SD, idx, lut)
+        ctx.set_materialize_grads(False)
+        return color[:, :3].contiguous(), rc[:, None]
+
+    @staticmethod
+    def backward(ctx, dcolor, d_rc):
+        eng = ctx.eng
+        exp_max, s2, internal = ctx.cfg
+        Mraw, OLo, ILo, IWo, RLo, SD, idx, lut = ctx.bufs
+        P, dev = Mraw.shape[0], Mraw.device
+        dc4 = torch.zeros(P, 4, device=dev)
+        if dcolor is not None:
+            dc4[:, :3] = dcolor
+        dMraw, dOLo, dILo, dIWo, dNoV = torch.zeros_like(Mraw), torch.zeros_like(OLo), torch.zeros_like(ILo), torch.zeros_like(IWo), torch.zeros(P, device=dev)
+        lib, S_ = eng.lib, eng.stream()
+        if s2:
+            g_rc = d_rc.reshape(P).contiguous() if d_rc is not None else None
+            L.check(lib.nu_s2_shade_combine_bwd(c_p(addr(Mraw)), 8, c_p(addr(OLo)), c_p(addr(ILo)), c_p(addr(IWo)), c_p(addr(SD)),
+                                                c_p(addr(lut)), c_p(addr(idx)), P, ctypes.c_float(exp_max), 1 if internal else 0,
+                                                c_p(addr(dc4)), c_p(addr(g_rc)), c_p(addr(dMraw)), c_p(addr(dOLo)), c_p(addr(dILo)),
+                                                c_p(addr(dIWo)), c_p(addr(dNoV)), S_), "nu_s2_shade_combine_bwd")
+            dRL = None
+        else:
+            dRLo = torch.zeros_like(RLo)
+            L.check(lib.nu_shade_combine_bwd(c_p(addr(Mraw)), 8, c_p(addr(OLo)), c_p(addr(ILo)), c_p(addr(IWo)), c_p(addr(RLo)),
+                                             c_p(addr(SD)), c_p(addr(lut)), c_p(addr(idx)), P, ctypes.c_float(exp_max), c_p(addr(dc4)),
+                                             c_p(addr(dMraw)), c_p(addr(dOLo)), c_p(addr(dILo)), c_p(addr(dIWo)), c_p(addr(dRLo)),
+                                             c_p(addr(dNoV)), S_), "nu_shade_combine_bwd")
+            dRL = dRLo[:, :3]
+        return None, dMraw[:, :6], dOLo[:, :3], dILo[:, :3], dIWo[:, None], dRL, dNoV[:, None], None, None, None, None
+
+
+def shade_combine(eng, m_raw, ol_raw, il_raw, iw_raw, rl_raw, nov, lut, exp_max, s2=False, internal=False):
+    """-> (sRGB colour [P,3], (1 - F) T [P,1] (meaningful for s2)).  Raw heads: materials [P,6], outer_light [3P,3] (diffuse |
+    specular at the point's roughness | mirror), inner_light [2P,3], inner_weight [P,1], refrac_light [P,3] (stage-1 form only)."""
+    return _ShadeCombineFn.apply(eng, m_raw, ol_raw, il_raw, iw_raw, rl_raw, nov, lut.contiguous(), float(exp_max), bool(s2), bool(internal))

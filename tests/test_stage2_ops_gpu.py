@@ -182,3 +182,44 @@ def test_far_importance_nodes_match_the_eager_formulation(gpu):
     assert z.shape == ref.shape and bool((z[:, 1:] >= z[:, :-1]).all())
     # the 192 coarse nodes are reproduced exactly; the 64 inverse-CDF samples to the rounding of the running sums
     torch.testing.assert_close(z, ref, rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("s2,internal", [(True, False), (True, True), (False, False)])
+def test_fused_brdf_mix_matches_the_eager_shading(gpu, s2, internal):
+    """shade() with the BRDF mix on nu_(s2_)shade_combine_* against the eager torch formulation of AppShadingNetwork(_S2).forward:
+    colour, (1 - F) T, and the gradients w.r.t. points, normals, view directions, features and every parameter."""
+    from nu_nerf_amd import shading_glue as SG
+    net, n1 = _eng(gpu)
+    s1c = net.stage1_network.color_network
+    torch.manual_seed(41)
+    P = 257
+    base = [F.normalize(torch.randn(P, 3, device=gpu), dim=-1) * 0.5, F.normalize(torch.randn(P, 3, device=gpu), dim=-1),
+            F.normalize(torch.randn(P, 3, device=gpu), dim=-1), 0.3 * torch.randn(P, 256, device=gpu)]
+    gcol, grc = torch.randn(P, 3, device=gpu), torch.randn(P, 1, device=gpu)
+    params = [p for p in net.stage1_network.color_network.parameters() if p.requires_grad]
+    res = {}
+    for fused in (True, False):
+        SG.FUSED_COMBINE = fused
+        try:
+            n1.begin_pass()
+            ins = [t.clone().requires_grad_(True) for t in base]
+            color, rc = SG.shade(n1, s1c.cfg, s1c.FG_LUT, ins[0], ins[1], ins[2], ins[3], s2=s2, is_internal=internal)
+            loss = (color * gcol).sum() + ((rc * grc).sum() if s2 else 0.0)
+            grads = torch.autograd.grad(loss, ins + params, allow_unused=True)
+            res[fused] = (color.detach(), rc.detach() if s2 else None, grads)
+        finally:
+            SG.FUSED_COMBINE = True
+    torch.testing.assert_close(res[True][0], res[False][0], rtol=1e-5, atol=1e-6)
+    if s2:
+        torch.testing.assert_close(res[True][1], res[False][1], rtol=1e-5, atol=1e-6)
+        if internal:
+            assert float(res[True][0].abs().max()) == 0.0
+    n_checked = 0
+    for a, b in zip(res[True][2], res[False][2]):
+        if b is None or float(b.abs().max()) == 0.0:
+            assert a is None or float(a.abs().max()) <= 1e-12
+            continue
+        scale = float(b.abs().max())
+        assert float((a - b).abs().max()) <= 3e-4 * scale + 1e-7, (float((a - b).abs().max()), scale)
+        n_checked += 1
+    assert n_checked >= (4 if not internal else 3)
