@@ -45,7 +45,7 @@ def test_stage2_train_step_vs_reference_golden(gpu):
     assert (d1 < 1e-5).mean() > 0.95 and d1.max() < 5e-3            # inverse-CDF placement, see test_oracle_golden
     np.testing.assert_allclose(out['_ior_ratios'][0].detach().cpu().numpy(), g['ior0'], rtol=1e-5)
     np.testing.assert_allclose(out['_directions'][1].detach().cpu().numpy(), g['dir1'], rtol=1e-5, atol=1e-6)
-    np.testing.assert_allclose(out['ray_rgb'].detach().cpu().numpy(), g['out_ray_rgb'], rtol=2e-4, atol=3e-5)
+    np.testing.assert_allclose(out['ray_rgb'].detach().cpu().numpy(), g['out_ray_rgb'], rtol=1e-4, atol=1e-5)
     for k in g:
         if k.startswith('term_'):
             np.testing.assert_allclose(float(torch.mean(log[k[5:]]).detach()), float(g[k]), rtol=5e-4, err_msg=k)
