@@ -426,6 +426,14 @@ int nu_s2_far_resample(const float* alpha, const float* zo, int M, int S, int n_
 /*   nu_s2_shade_combine_fwd / _bwd      AppShadingNetwork_S2.forward's BRDF mix (field.py:909-1010) on raw head outputs, layouts as
  *                                       nu_shade_combine_*: colour = (diffuse + specular)(1 - T) + F light0 T (x 0 when `internal`),
  *                                       rc [P] = (1 - F) T */
+/*   nu_s2_neus_alpha_fwd / _bwd          NeuS alpha of the inner segment on explicit points (renderer_zerothick.py:1897-1915): sdf, unit
+ *                                       normal, direction, section length, inv_s [1] on device; backward -> d sdf, d n, d d, d dist and
+ *                                       the per-point share of d inv_s */
+int nu_s2_neus_alpha_fwd(const float* sdf, const float* nrm, const float* dir, const float* dist, const float* inv_s, float cos_anneal,
+                         int P, float* alpha, hipStream_t stream);
+int nu_s2_neus_alpha_bwd(const float* sdf, const float* nrm, const float* dir, const float* dist, const float* inv_s, float cos_anneal,
+                         int P, const float* g_alpha, float* g_sdf, float* g_nrm, float* g_dir, float* g_dist, float* g_s,
+                         hipStream_t stream);
 int nu_s2_shade_combine_fwd(const float* Mraw, int ldm, const float* OLo, const float* ILo, const float* IWo, const float* SD,
                             const float* lut, const int* idx, int P, float exp_max, int internal, float* color_rm, float* rc,
                             hipStream_t stream);

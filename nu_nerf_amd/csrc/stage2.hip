@@ -779,3 +779,67 @@ extern "C" int nu_s2_far_resample(const float* alpha, const float* zo, int M, in
     hipLaunchKernelGGL(s2_far_resample_kernel, dim3(nu_cdiv(M, 4)), dim3(256), 0, stream, alpha, zo, M, zout);
     return nu_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------
+// NeuS alpha of the inner segment (renderer_zerothick.py:1897-1915; compute_sdf_alpha with explicit points), one thread per point:
+//   c = d . n;  it = -(relu(0.5 - 0.5 c)(1 - ca) + relu(-c) ca);  p = sigmoid((sdf - 0.5 it dist) s);  q = sigmoid((sdf + 0.5 it dist) s)
+//   alpha = clip((p - q + 1e-5) / (p + 1e-5), 0, 1)
+// Backward -> d sdf, d n, d d, d dist and the per-point share of d s (the caller sums it).
+// ------------------------------------------------------------------------------------------------
+static __device__ inline float s2_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__global__ __launch_bounds__(256) void s2_neus_alpha_kernel(const float* __restrict__ sdf, const float* __restrict__ nrm,
+                                                            const float* __restrict__ dir, const float* __restrict__ dist,
+                                                            const float* __restrict__ inv_s, float ca, int P, float* __restrict__ alpha,
+                                                            const float* __restrict__ g_alpha, float* __restrict__ g_sdf,
+                                                            float* __restrict__ g_nrm, float* __restrict__ g_dir, float* __restrict__ g_dist,
+                                                            float* __restrict__ g_s) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const float s = inv_s[0];
+    const float n[3] = {nrm[p * 3LL], nrm[p * 3LL + 1], nrm[p * 3LL + 2]}, d[3] = {dir[p * 3LL], dir[p * 3LL + 1], dir[p * 3LL + 2]};
+    const float c = d[0] * n[0] + d[1] * n[1] + d[2] * n[2];
+    const float a1 = -c * 0.5f + 0.5f, a2 = -c;
+    const float r1 = fmaxf(a1, 0.f), r2 = fmaxf(a2, 0.f);
+    const float it = -(r1 * (1.0f - ca) + r2 * ca);
+    const float f = sdf[p], ds = dist[p];
+    const float h = it * ds * 0.5f;
+    const float pc = s2_sigmoid((f - h) * s), nc = s2_sigmoid((f + h) * s);
+    const float num = pc - nc + 1e-5f, den = pc + 1e-5f;
+    const float raw = num / den;
+    if (!g_alpha) {
+        alpha[p] = fminf(fmaxf(raw, 0.0f), 1.0f);
+        return;
+    }
+    const float g = (raw >= 0.0f && raw <= 1.0f) ? g_alpha[p] : 0.f;
+    const float dnum = g / den, dden = -g * num / (den * den);
+    const float dpc = dnum + dden, dnc = -dnum;
+    const float du1 = dpc * pc * (1.0f - pc), du2 = dnc * nc * (1.0f - nc);
+    g_sdf[p] = (du1 + du2) * s;
+    g_s[p] = du1 * (f - h) + du2 * (f + h);
+    const float dh = (du2 - du1) * s;                 // h = 0.5 it dist
+    const float dit = dh * 0.5f * ds;
+    g_dist[p] = dh * 0.5f * it;
+    const float dr1 = -dit * (1.0f - ca), dr2 = -dit * ca;
+    const float dc = (a1 > 0.f ? -0.5f * dr1 : 0.f) + (a2 > 0.f ? -dr2 : 0.f);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        g_dir[p * 3LL + k] = dc * n[k];
+        g_nrm[p * 3LL + k] = dc * d[k];
+    }
+}
+extern "C" int nu_s2_neus_alpha_fwd(const float* sdf, const float* nrm, const float* dir, const float* dist, const float* inv_s, float ca,
+                                    int P, float* alpha, hipStream_t stream) {
+    if (P <= 0) return NU_OK;
+    hipLaunchKernelGGL(s2_neus_alpha_kernel, dim3(nu_cdiv(P, 256)), dim3(256), 0, stream, sdf, nrm, dir, dist, inv_s, ca, P, alpha,
+                       (const float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr);
+    return nu_launch_status();
+}
+extern "C" int nu_s2_neus_alpha_bwd(const float* sdf, const float* nrm, const float* dir, const float* dist, const float* inv_s, float ca,
+                                    int P, const float* g_alpha, float* g_sdf, float* g_nrm, float* g_dir, float* g_dist, float* g_s,
+                                    hipStream_t stream) {
+    if (P <= 0) return NU_OK;
+    hipLaunchKernelGGL(s2_neus_alpha_kernel, dim3(nu_cdiv(P, 256)), dim3(256), 0, stream, sdf, nrm, dir, dist, inv_s, ca, P,
+                       (float*)nullptr, g_alpha, g_sdf, g_nrm, g_dir, g_dist, g_s);
+    return nu_launch_status();
+}

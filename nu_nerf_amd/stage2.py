@@ -332,11 +332,7 @@ class Stage2Renderer(nn.Module):
                     s = torch.exp(self.deviation_network_inner.variance * 10.0).clip(1e-6, 1e6)
                     if self.cfg['freeze_inv_s_step'] is not None and step < self.cfg['freeze_inv_s_step']:
                         s = s.detach()
-                    cosv = (din * grads).sum(-1)
-                    it = -(F.relu(-cosv * 0.5 + 0.5) * (1.0 - cos_anneal_ratio) + F.relu(-cosv) * cos_anneal_ratio)
-                    pc = torch.sigmoid((sdf - it * dsin * 0.5) * s)
-                    nc = torch.sigmoid((sdf + it * dsin * 0.5) * s)
-                    a = ((pc - nc + 1e-5) / (pc + 1e-5)).clip(0.0, 1.0)
+                    a = O.neus_alpha(n2.eng, sdf, grads, din, dsin, s, cos_anneal_ratio)        # HIP, fwd + bwd
                     c, _ = self._shading(n2, self.color_network_inner.cfg, self.color_network_inner.FG_LUT, pin, grads, -din, feats)
                     alpha = alpha.index_put((inner,), a)
                     col = col.index_put((inner,), torch.cat([c, torch.zeros_like(c[:, :1])], -1))

@@ -284,3 +284,35 @@ def shade_combine(eng, m_raw, ol_raw, il_raw, iw_raw, rl_raw, nov, lut, exp_max,
     """-> (sRGB colour [P,3], (1 - F) T [P,1] (meaningful for s2)).  Raw heads: materials [P,6], outer_light [3P,3] (diffuse |
     specular at the point's roughness | mirror), inner_light [2P,3], inner_weight [P,1], refrac_light [P,3] (stage-1 form only)."""
     return _ShadeCombineFn.apply(eng, m_raw, ol_raw, il_raw, iw_raw, rl_raw, nov, lut.contiguous(), float(exp_max), bool(s2), bool(internal))
+
+
+class _NeusAlphaFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, eng, sdf, nrm, dirs, dist, inv_s, ca):
+        sdf, nrm, dirs, dist = (t.detach().contiguous() for t in (sdf, nrm, dirs, dist))
+        s1 = inv_s.detach().reshape(1).contiguous()
+        P = sdf.shape[0]
+        alpha = torch.empty(P, device=sdf.device)
+        L.check(eng.lib.nu_s2_neus_alpha_fwd(c_p(addr(sdf)), c_p(addr(nrm)), c_p(addr(dirs)), c_p(addr(dist)), c_p(addr(s1)),
+                                             ctypes.c_float(ca), P, c_p(addr(alpha)), eng.stream()), "nu_s2_neus_alpha_fwd")
+        ctx.eng, ctx.ca, ctx.s_shape = eng, ca, inv_s.shape
+        ctx.save_for_backward(sdf, nrm, dirs, dist, s1)
+        return alpha
+
+    @staticmethod
+    def backward(ctx, g):
+        sdf, nrm, dirs, dist, s1 = ctx.saved_tensors
+        P = sdf.shape[0]
+        g_sdf, g_n, g_d, g_dist, g_s = torch.empty_like(sdf), torch.empty_like(nrm), torch.empty_like(dirs), torch.empty_like(dist), torch.empty_like(sdf)
+        L.check(ctx.eng.lib.nu_s2_neus_alpha_bwd(c_p(addr(sdf)), c_p(addr(nrm)), c_p(addr(dirs)), c_p(addr(dist)), c_p(addr(s1)),
+                                                 ctypes.c_float(ctx.ca), P, c_p(addr(g.contiguous())), c_p(addr(g_sdf)), c_p(addr(g_n)),
+                                                 c_p(addr(g_d)), c_p(addr(g_dist)), c_p(addr(g_s)), ctx.eng.stream()), "nu_s2_neus_alpha_bwd")
+        return None, g_sdf, g_n, g_d, g_dist, g_s.sum().reshape(ctx.s_shape), None
+
+
+def neus_alpha(eng, sdf, nrm, dirs, dist, inv_s, cos_anneal):
+    """NeuS alpha on explicit points [P]: sdf [P], normals [P,3] (the SDF gradient), directions [P,3], section lengths [P], inv_s
+    (scalar tensor)."""
+    if sdf.shape[0] == 0:
+        return sdf.new_zeros(0)
+    return _NeusAlphaFn.apply(eng, sdf, nrm, dirs, dist, inv_s, float(cos_anneal))

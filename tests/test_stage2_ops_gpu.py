@@ -223,3 +223,30 @@ def test_fused_brdf_mix_matches_the_eager_shading(gpu, s2, internal):
         assert float((a - b).abs().max()) <= 3e-4 * scale + 1e-7, (float((a - b).abs().max()), scale)
         n_checked += 1
     assert n_checked >= (4 if not internal else 3)
+
+
+def test_neus_alpha_matches_torch(gpu):
+    from nu_nerf_amd import stage2_ops as O
+    net, n1 = _eng(gpu)
+    torch.manual_seed(51)
+    P = 3000
+    sdf = (0.02 * torch.randn(P, device=gpu)).requires_grad_(True)
+    nrm = (F.normalize(torch.randn(P, 3, device=gpu), dim=-1) * (0.8 + 0.4 * torch.rand(P, 1, device=gpu))).requires_grad_(True)
+    dirs = F.normalize(torch.randn(P, 3, device=gpu), dim=-1).requires_grad_(True)
+    dist = (0.002 + 0.01 * torch.rand(P, device=gpu)).requires_grad_(True)
+    s = torch.tensor(64.0, device=gpu, requires_grad=True)
+    for ca in (0.0, 0.35, 1.0):
+        a = O.neus_alpha(n1.eng, sdf, nrm, dirs, dist, s, ca)
+        cosv = (dirs * nrm).sum(-1)
+        it = -(F.relu(-cosv * 0.5 + 0.5) * (1.0 - ca) + F.relu(-cosv) * ca)
+        pc = torch.sigmoid((sdf - it * dist * 0.5) * s)
+        nc = torch.sigmoid((sdf + it * dist * 0.5) * s)
+        ref = ((pc - nc + 1e-5) / (pc + 1e-5)).clip(0.0, 1.0)
+        torch.testing.assert_close(a, ref, rtol=1e-5, atol=2e-7)
+        assert 0.05 < float((ref > 1e-3).float().mean()) < 1.0
+        g = torch.randn(P, device=gpu)
+        got = torch.autograd.grad((a * g).sum(), (sdf, nrm, dirs, dist, s))
+        want = torch.autograd.grad((ref * g).sum(), (sdf, nrm, dirs, dist, s))
+        for x, y, name in zip(got, want, ('sdf', 'nrm', 'dirs', 'dist', 's')):
+            scale = float(y.abs().max()) + 1e-12
+            assert float((x - y).abs().max()) <= 3e-4 * scale + 1e-8, (name, ca, float((x - y).abs().max()), scale)
