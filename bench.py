@@ -393,6 +393,11 @@ def main():
                 tjd = json.load(open(tj))
                 traffic = tjd.get('gemm_nt_kernel', {}).get('hbm_bytes_per_launch')
                 traffic_tn = tjd.get('gemm_tn_kernel', {}).get('hbm_bytes_per_launch')
+            tj4 = os.path.join(ROOT, 'profiles', 'r02', 'traffic_pmc_config4.json')
+            if os.path.exists(tj4) and R == 8192 and world == 1 and args.real_capture and args.mlp_dtype == 'bf16' and eng.h16:
+                tjd = json.load(open(tj4))
+                traffic = tjd.get('gemm_nt_kernel', {}).get('hbm_bytes_per_launch')
+                traffic_tn = tjd.get('gemm_tn_kernel', {}).get('hbm_bytes_per_launch')
             common = {"algorithmic_bytes_per_launch": ktime['bytes'] / max(ktime['launches'], 1),
                       "algorithmic_flops_per_launch": ktime['flops'] / max(ktime['launches'], 1),
                       "launches": ktime['launches'], "avg_launch_us": 1e6 * ktime['seconds'] / max(ktime['launches'], 1),
@@ -415,7 +420,8 @@ def main():
                 gbs = ktime['bytes'] / max(ktime['seconds'], 1e-12) / 1e9
                 stored = eng.h16
                 res["roofline"] = {"bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0,
-                                   "traffic": None, "mfma_tflops": tf,
+                                   "traffic": traffic, "mfma_tflops": tf,
+                                   "traffic_unit": "HBM bytes per launch (rocprofv3 PMC of this workload and these kernels, profiles/r02/traffic_pmc_config4.json)",
                                    "kernel": ("gemm_nt16_kernel<*> (v_mfma_f32_32x32x16_bf16, bf16 weights and hidden activations in HBM)"
                                               if stored else "gemm_nt_kernel<*, bf16> (v_mfma_f32_32x32x16_bf16, fp32 operands in HBM)"),
                                    **common}

@@ -9,7 +9,7 @@ def agg(path, name):
         if r['Counter_Name'] != name:
             continue
         kn = r['Kernel_Name']
-        k = 'gemm_nt_kernel' if ('gemm_nt_kernel' in kn or 'gemm_nt2_kernel' in kn) else ('gemm_tn_kernel' if ('gemm_tn_kernel' in kn or 'gemm_tn256_kernel' in kn) else
+        k = 'gemm_nt_kernel' if ('gemm_nt_kernel' in kn or 'gemm_nt2_kernel' in kn or 'gemm_nt16' in kn) else ('gemm_tn_kernel' if ('gemm_tn_kernel' in kn or 'gemm_tn256_kernel' in kn or 'gemm_tn16' in kn) else
              ('calib_read4' if 'calib_read4' in kn else ('calib_read16' if 'calib_read16' in kn else None)))
         if k:
             out[k][0] += 1
