@@ -310,6 +310,8 @@ class Stage1Nets:
 
     def ior(self, X):
         """Raw (pre-sigmoid) output of the IoR network on encoded points X [rows, 39]."""
+        if X.shape[0] == 0:
+            return X.new_zeros(0)
         return IorFn.apply(self.eng, X, self.ior_names, self.token())
 
     def predictor(self, name, X):

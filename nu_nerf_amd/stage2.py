@@ -1,14 +1,18 @@
 """Stage-2 renderer (zero-thickness variant): drop-in for `Stage2Renderer` of network/renderer_zerothick.py:868-2055
 (`name2renderer['stage2']`, registry :2057-2060).
 
-What runs where in this first version:
-  * mesh closest-hit tracing: HIP LBVH (nu_nerf_amd/lbvh.py) instead of OptiX + its host round trips;
-  * every MLP contraction (stage-1 SDF / NeRF++ / shading predictors, inner SDF / shading) incl. second-order SDF terms and
-    the INPUT gradients that carry d L / d IoR: HIP GEMMs through nu_nerf_amd/nets.py;
-  * the no-grad segment samplers: HIP sampler kernels for the inner-SDF up-sampling, torch for the NeRF++ importance pass;
-  * the ragged per-bounce bookkeeping, encodings, BRDF mix and segment composites: torch ops (nu_nerf_amd/torch_glue.py);
-  * the IoR network: HIP GEMMs through the inner engine (nets.IorFn); `IoRNetwork.forward` below is kept for the two
-    networks the zero-thickness variant never evaluates (IoRint_pred, thickness_pred).
+The light paths are a chain of SEGMENTS (`trace_segments`), rendered front to back (`render_segments`).  Everything numeric runs
+on HIP kernels with hand-derived backward -- stage 2 needs d L / d position everywhere, because every sample position depends on
+the learned index of refraction:
+  * closest hit: HIP LBVH (nu_nerf_amd/lbvh.py) instead of OptiX; differentiable hit point / normal: nu_s2_hit_*;
+  * IoR network, SDF / NeRF++ / predictor / material networks incl. second-order SDF terms and input gradients: MFMA GEMMs
+    (nets.py: IorFn, SdfFn, NerfFn, StackFn, MaterialsFn; one parameter hub per engine and pass);
+  * refraction / total internal reflection: nu_s2_refract_*;
+  * sample placement: the stage-1 sampler kernels for the inner-SDF up-sampling, nu_s2_far_* for the NeRF++ importance pass;
+  * the outer samples of all segments: nu_s2_seg_* + ONE NeRF++ pass; inner segment: nu_s2_neus_alpha_*;
+  * shading: encodings (nu_ide, nu_embed) + predictor stacks + one BRDF-mix kernel pair (nu_s2_shade_combine_*, shading_glue.py);
+  * per-segment composite in linear RGB with the running transmittance: nu_s2_composite_*.
+torch is left with index bookkeeping (one nonzero per mask, index_select / index_add) and O(rays) glue.
 state_dict() names/order equal the reference's (574 entries incl. the `color_network.stage1_network.*` aliases).
 """
 import ctypes
@@ -230,134 +234,127 @@ class Stage2Renderer(nn.Module):
             z, sdf, sn = zo, so, sn + 32
         return z
 
-    # ---- ray_trace --------------------------------------------------------------------------------
-    def ray_trace(self, rays_o, rays_d):
-        """Up to 3 refraction bounces against the mesh + per-segment sample placement (renderer_zerothick.py:1571-1828).
-        Segments come back as (start, v, z): nodes x_j = start + v * z_j (z without gradient), never materialised here."""
+    # ---- light paths ------------------------------------------------------------------------------
+    def trace_segments(self, rays_o, rays_d):
+        """The light paths of a ray batch as a chain of SEGMENTS (renderer_zerothick.py:1571-1828: up to 3 refraction bounces
+        against the stage-1 mesh, then the sample placement of every straight piece).
+
+        Segment b holds the rays still alive after b refractions: where they start, where they go, which of them hit the mesh
+        (`hit_idx`), which of those refract and continue (`cont_idx`, indices into the segment) and their sample nodes
+        x_j = start + v z_j.  The geometry runs on HIP kernels with hand-derived backward -- closest hit (LBVH), differentiable
+        hit point / normal, IoR network, Snell refraction / total internal reflection -- and the placement on the no-grad HIP
+        samplers; what is left here is index bookkeeping (one `nonzero` per mask, reused)."""
         n1, n2 = self.nets()
         scene, dev = self.scene, rays_o.device
-        next_start, next_dir = rays_o, rays_d
-        starts, directions = [rays_o], [rays_d]
-        intersections, converges, infinity_bkgr, ior_ratios, gradient_mesh, tirs = [], [], [], [], [], []
-        outside = True
-        for i in range(3):
-            N = next_start.shape[0]
-            tir = torch.ones(N, 1, dtype=torch.bool, device=dev)
-            inter, hit = dintersect_hip(scene, n1.eng, next_start, next_dir)      # LBVH trace + differentiable hit (HIP)
-            point = inter['point']
-            converged = hit.reshape(-1, 1)
-            normal = F.normalize(inter['n'], dim=-1) if outside else -F.normalize(inter['n'], dim=-1)
-            infinity_bkgr.append(~converged)
-            mask = converged.flatten()
-            ior = torch.sigmoid(n2.ior(G.embed(point.reshape(-1, 3), 6)))       # IoRNetwork (field.py:1046-1066) on the HIP GEMMs
-            refr, eta, nd_all, ns_all = O.refract(n1.eng, next_dir[mask], normal, ior, point, outside)   # HIP, fwd + bwd
-            converged_out = converged.clone()
-            converged_out[mask] = refr[:, None]
-            tir[mask] = refr[:, None]
-            tirs.append(tir)
-            nd, ns, ratio, gm = nd_all[refr], ns_all[refr], eta[refr][:, None], normal[refr]
-            next_dir, next_start = nd, ns
-            directions.append(nd)
-            starts.append(ns)
-            converges.append(converged_out)
-            intersections.append(point)
-            if torch.all(~converged_out):
-                break
-            gradient_mesh.append(gm)
-            ior_ratios.append(ratio)
-            outside = not outside
-        for i in range(len(tirs) - 1, 0, -1):
-            m = converges[i - 1].flatten()
-            tirs[i - 1][m] = tirs[i - 1][m] & tirs[i]
-        paths = []
-        for k in range(len(converges)):
-            start = starts[k].reshape(-1, 3)
-            dk = directions[k]
+        N0 = rays_o.shape[0]
+        segs = []
+        start, dirs = rays_o, rays_d
+        root = torch.arange(N0, device=dev)                    # camera ray each segment ray descends from
+        valid = torch.ones(N0, dtype=torch.bool, device=dev)   # False: total internal reflection somewhere along the path
+        for b in range(3):
+            inside = b % 2 == 1
             N = start.shape[0]
-            S1 = 256 if k != 1 else 128
-            hitk = ~infinity_bkgr[k].flatten()
-            v = (start + dk * 4.5) - start                      # rounded like the reference's end - start
+            S1 = 128 if b == 1 else 256
+            inter, hit = dintersect_hip(scene, n1.eng, start, dirs)            # LBVH closest hit + differentiable hit
+            hit_idx = hit.nonzero().flatten()
+            miss_idx = (~hit).nonzero().flatten()
+            point = inter['point']
+            normal = F.normalize(inter['n'], dim=-1)
+            if inside:
+                normal = -normal
+            ior = torch.sigmoid(n2.ior(G.embed(point, 6)))                     # IoRNetwork on the HIP GEMMs
+            d_hit = dirs.index_select(0, hit_idx)
+            refracts, eta, next_dir, next_start = O.refract(n1.eng, d_hit, normal, ior, point, not inside)
+            keep = refracts.nonzero().flatten()
+            cont_idx = hit_idx.index_select(0, keep)
+            lost = hit_idx.index_select(0, (~refracts).nonzero().flatten())
+            valid[root.index_select(0, lost)] = False
+            # ---- sample nodes of this segment: x_j = start + v z_j ----
+            v = (start + dirs * 4.5) - start                   # rounded like the reference's `end - start`
             z = torch.linspace(0, 1, S1, device=dev)[None, :].repeat(N, 1)
-            if hitk.any():
-                sh, eh = start[hitk], intersections[k]
-                v = v.index_put((hitk,), eh - sh)
-                if k == 1:
+            if hit_idx.numel() > 0:
+                s_hit = start.index_select(0, hit_idx)
+                v = v.index_copy(0, hit_idx, point - s_hit)
+                if b == 1:                                     # inside the object: hierarchical sampling against the inner SDF
                     with torch.no_grad():
-                        z[hitk] = self._upsample_inner(n2, sh.detach(), dk[hitk].detach(), eh.detach())
-            if (~hitk).any() and k != 1:
-                miss = ~hitk
-                sm, dm = start[miss], dk[miss]
+                        z[hit_idx] = self._upsample_inner(n2, s_hit.detach(), d_hit.detach(), point.detach())
+            if miss_idx.numel() > 0 and b != 1:                # rays that leave the scene: NeRF++ importance pass, no gradient
+                d_miss = dirs.index_select(0, miss_idx)
                 with torch.no_grad():
-                    z[miss] = O.far_importance_nodes(n1.eng, sm, dm)
-                v = v.index_put((miss,), dm)
-            paths.append((start, v, z))
-        return paths, converges, directions, ior_ratios, infinity_bkgr, gradient_mesh, tirs[0]
+                    z[miss_idx] = O.far_importance_nodes(n1.eng, start.index_select(0, miss_idx), d_miss)
+                v = v.index_copy(0, miss_idx, d_miss)
+            segs.append(dict(start=start, dirs=dirs, v=v, z=z, cont_idx=cont_idx, n_cont=int(cont_idx.numel()),
+                             normal=normal.index_select(0, keep), eta=eta.index_select(0, keep)[:, None], inside=inside))
+            if cont_idx.numel() == 0:
+                break
+            start, dirs = next_start.index_select(0, keep), next_dir.index_select(0, keep)
+            root = root.index_select(0, cont_idx)
+        return segs, valid[:, None]
 
     @staticmethod
     def path_points(seg):
-        start, v, z = seg
-        return start[:, None, :] + v[:, None, :] * z[..., None]
+        return seg['start'][:, None, :] + seg['v'][:, None, :] * seg['z'][..., None]
 
     # ---- render_core ------------------------------------------------------------------------------
-    def render_core(self, rays_o, rays_d, paths, converges, directions, infinity_bkgr, gradient_mesh, ior_ratios,
-                    human_poses=None, cos_anneal_ratio=0.0, step=None, is_train=True, is_nerf=False):
-        """Per-segment composite in linear RGB with a running transmittance (renderer_zerothick.py:1835-2011, training).
+    def render_segments(self, segs, cos_anneal_ratio=0.0, step=None):
+        """Front-to-back over the segments in linear RGB with a running transmittance (renderer_zerothick.py:1835-2011, training).
         The outer (|x| > 1) samples of ALL segments go through the NeRF++ in one pass of HIP kernels (stage2_ops.outer_segments);
-        each segment's composite is one kernel pair (stage2_ops.segment_composite)."""
+        each segment's composite is one kernel pair; surface and inner-segment shading are the HIP network ops + one BRDF-mix
+        kernel pair (shading_glue.shade)."""
         n1, n2 = self.nets()
-        dev = rays_o.device
-        N0 = converges[0].shape[0]
+        dev = segs[0]['start'].device
+        N0 = segs[0]['start'].shape[0]
         T = torch.ones(N0, 3, device=dev)
         colors = []
         out = {'gradient_error': torch.zeros(1, device=dev), 'std': torch.zeros(1, device=dev)}
         s1c = self.stage1_network.color_network
-        outer = O.outer_segments(n1, [(st, v, z, directions[i]) for i, (st, v, z) in enumerate(paths)])
-        for i in range(len(paths)):
-            start, v, z = paths[i]
-            cd, cc = directions[i], converges[i].flatten()
-            N = start.shape[0]
-            alpha, col = outer[i]
-            if i == 1 and N > 0:
-                cp = self.path_points(paths[i])
-                pfn = cp[:, :-1, :]
-                inner = torch.norm(pfn, dim=-1) <= 1.0
-                if inner.any():
-                    dists = torch.linalg.norm(pfn[:, 1:] - pfn[:, :-1], dim=-1)
-                    dists = torch.cat([dists, dists[..., -1:]], -1)
-                    ns = pfn.shape[1]
-                    dirs = cd[:, None, :].expand(N, ns, 3)
-                    pin, din, dsin = pfn[inner], dirs[inner], dists[inner]
-                    y, grads = n2.sdf(pin)
-                    sdf, feats = y[:, 0], y[:, 1:]
+        outer = O.outer_segments(n1, [(sg['start'], sg['v'], sg['z'], sg['dirs']) for sg in segs])
+        for b, sg in enumerate(segs):
+            N, cont = sg['start'].shape[0], sg['cont_idx']
+            alpha, col = outer[b]
+            if b == 1 and N > 0:                               # inside the object: the inner SDF surface (NeuS alpha + shading)
+                nodes = self.path_points(sg)[:, :-1, :]
+                inner = torch.norm(nodes, dim=-1) <= 1.0
+                where = inner.nonzero()
+                if where.shape[0] > 0:
+                    r_i, s_i = where[:, 0], where[:, 1]
+                    seglen = torch.linalg.norm(nodes[:, 1:] - nodes[:, :-1], dim=-1)
+                    seglen = torch.cat([seglen, seglen[..., -1:]], -1)
+                    x_in, d_in, len_in = nodes[r_i, s_i], sg['dirs'].index_select(0, r_i), seglen[r_i, s_i]
+                    y, grads = n2.sdf(x_in)
                     s = torch.exp(self.deviation_network_inner.variance * 10.0).clip(1e-6, 1e6)
                     if self.cfg['freeze_inv_s_step'] is not None and step < self.cfg['freeze_inv_s_step']:
                         s = s.detach()
-                    a = O.neus_alpha(n2.eng, sdf, grads, din, dsin, s, cos_anneal_ratio)        # HIP, fwd + bwd
-                    c, _ = self._shading(n2, self.color_network_inner.cfg, self.color_network_inner.FG_LUT, pin, grads, -din, feats)
-                    alpha = alpha.index_put((inner,), a)
-                    col = col.index_put((inner,), torch.cat([c, torch.zeros_like(c[:, :1])], -1))
+                    a = O.neus_alpha(n2.eng, y[:, 0], grads, d_in, len_in, s, cos_anneal_ratio)
+                    c, _ = self._shading(n2, self.color_network_inner.cfg, self.color_network_inner.FG_LUT, x_in, grads, -d_in, y[:, 1:])
+                    alpha = alpha.index_put((r_i, s_i), a)
+                    col = col.index_put((r_i, s_i), torch.cat([c, torch.zeros_like(c[:, :1])], -1))
                     out['std'] = torch.mean(1 / s)
                     out['gradient_error'] = (torch.linalg.norm(grads, dim=-1) - 1.0) ** 2
-            color_now, T_end = O.segment_composite(n1.eng, alpha, col, T)
-            T = T_end
-            have_hit = bool(cc.any()) if N > 0 else False
-            if have_hit:
-                p_neus = start[cc] + v[cc] * z[cc][:, -1:]
-                y, _ = n1.sdf(p_neus)
-                col_sdf, refr_coeff = self._shading(n1, s1c.cfg, s1c.FG_LUT, p_neus, gradient_mesh[i], -cd[cc], y[:, 1:],
-                                                    s2=True, is_internal=(i % 2 != 0))
-                color_now = color_now + torch.zeros_like(color_now).index_put((cc,), G.srgb_to_linear(col_sdf) * T[cc])
-                T = T[cc] * refr_coeff
-                colors.append(color_now)
-            else:
-                colors.append(color_now)
+            light, T = O.segment_composite(n1.eng, alpha, col, T)
+            if sg['n_cont'] == 0:
+                colors.append(light)
                 break
-        for i in range(len(colors) - 1, 0, -1):
-            m = converges[i - 1].flatten()
-            colors[i - 1] = colors[i - 1] + torch.zeros_like(colors[i - 1]).index_put((m,), colors[i])
+            # the surface the continuing rays cross: stage-1 materials at the hit point, AppShadingNetwork_S2
+            hit_pt = sg['start'].index_select(0, cont) + sg['v'].index_select(0, cont) * sg['z'].index_select(0, cont)[:, -1:]
+            y, _ = n1.sdf(hit_pt)
+            surf, through = self._shading(n1, s1c.cfg, s1c.FG_LUT, hit_pt, sg['normal'], -sg['dirs'].index_select(0, cont), y[:, 1:],
+                                          s2=True, is_internal=sg['inside'])
+            T_c = T.index_select(0, cont)
+            colors.append(light.index_add(0, cont, G.srgb_to_linear(surf) * T_c))
+            T = T_c * through
+        for b in range(len(colors) - 1, 0, -1):                # what the deeper segments saw flows back along the paths
+            colors[b - 1] = colors[b - 1].index_add(0, segs[b - 1]['cont_idx'], colors[b])
         out['ray_rgb'] = torch.clamp(G.linear_to_srgb(colors[0]), min=0.0, max=1.0)
         out['acc'] = torch.ones(N0, device=dev)
         return out
+
+    # the reference's method names (renderer_zerothick.py:1571, :1835), kept for callers that use them
+    def ray_trace(self, rays_o, rays_d):
+        return self.trace_segments(rays_o, rays_d)
+
+    def render_core(self, segs, cos_anneal_ratio=0.0, step=None, **_):
+        return self.render_segments(segs, cos_anneal_ratio=cos_anneal_ratio, step=step)
 
     def render(self, rays_o, rays_d, near=None, far=None, human_poses=None, perturb_overwrite=-1, cos_anneal_ratio=0.0,
                is_train=True, step=None, is_nerf=False):
@@ -367,13 +364,13 @@ class Stage2Renderer(nn.Module):
         n2.eng.pack()
         n1.begin_pass()
         n2.begin_pass()
-        paths, conv, dirs, iors, inf_b, gmesh, tir = self.ray_trace(rays_o, rays_d)
-        ret = self.render_core(rays_o, rays_d, paths, conv, dirs, inf_b, gmesh, iors, human_poses,
-                               cos_anneal_ratio=cos_anneal_ratio, step=step, is_train=is_train, is_nerf=is_nerf)
-        ret['tir_mask'] = tir
+        segs, valid = self.trace_segments(rays_o, rays_d)
+        ret = self.render_segments(segs, cos_anneal_ratio=cos_anneal_ratio, step=step)
+        ret['tir_mask'] = valid
         with torch.no_grad():
-            ret['_paths'] = [self.path_points(p) for p in paths]       # materialised for inspection only
-        ret['_ior_ratios'], ret['_directions'] = iors, dirs
+            ret['_paths'] = [self.path_points(sg) for sg in segs]       # materialised for inspection only
+        ret['_ior_ratios'] = [sg['eta'] for sg in segs if sg['n_cont'] > 0]
+        ret['_directions'] = [sg['dirs'] for sg in segs]
         return ret
 
     def train_step_rays(self, batch, step):
