@@ -257,3 +257,43 @@ def test_forward_routes_eval_requests_to_test_step_cpu_side():
     full, _, _ = make_image_rays(5, hw=16, downsample=1.0)
     dn = full['rays_d'] / np.linalg.norm(full['rays_d'], axis=1, keepdims=True)
     assert np.all(dn @ (-full['rays_o'][0] / np.linalg.norm(full['rays_o'][0])) > 0.85)       # looking at the origin (corner pixels: cos 0.89)
+
+
+def test_stage2_parameter_hub_hands_each_parameter_its_slice_once_cpu_side():
+    """nets.ParamHubFn (stage 2): network ops differentiate ONE token of the flat gradient buffer's shape; the hub sums their
+    contributions, hands every touched parameter its slice once and leaves untouched parameters at grad None (optimizer state is
+    created lazily: train_glue.FusedAdam).  Host logic only: a stand-in engine with the flat-buffer bookkeeping, no library."""
+    from nu_nerf_amd import nets as N
+
+    class Eng:
+        dev = torch.device('cpu')
+        grad_views = {'a.w': (0, (2, 3)), 'a.b': (6, (2,)), 'b.w': (8, (4,)), 'c.w': (12, (3,))}
+        n_grad = 15
+
+    eng = Eng()
+    params = {n: torch.nn.Parameter(torch.zeros(s)) for n, (_, s) in eng.grad_views.items()}
+    names = list(params)
+    assert N._own_range(eng, ['a.w', 'a.b']) == (0, 8) and N._own_range(eng, ['b.w']) == (8, 12)
+    with pytest.raises(AssertionError):
+        N._own_range(eng, ['a.w', 'b.w'])                      # not contiguous: the op would leak another op's slots
+
+    class Op(torch.autograd.Function):
+        """A stand-in network op: its backward fills the WHOLE flat buffer (as unpack_grads does) and returns its own share."""
+        @staticmethod
+        def forward(ctx, x, own, fill, token):
+            ctx.own, ctx.fill = own, fill
+            return x * 2.0
+
+        @staticmethod
+        def backward(ctx, g):
+            flat = torch.full((eng.n_grad,), ctx.fill)
+            return g * 2.0, None, None, N._token_grad(eng, flat, ctx.own)
+
+    token = N.ParamHubFn.apply(eng, names, *[params[n] for n in names])
+    x = torch.ones(3, requires_grad=True)
+    y = Op.apply(x, ['a.w', 'a.b'], 1.0, token) + Op.apply(x, ['a.w', 'a.b'], 10.0, token) + Op.apply(x, ['b.w'], 100.0, token)
+    y.sum().backward()
+    assert torch.equal(params['a.w'].grad, torch.full((2, 3), 11.0)) and torch.equal(params['a.b'].grad, torch.full((2,), 11.0))
+    assert torch.equal(params['b.w'].grad, torch.full((4,), 100.0))
+    assert params['c.w'].grad is None                          # no op touched it
+    assert torch.equal(x.grad, torch.full((3,), 6.0))
