@@ -418,9 +418,11 @@ int nu_s2_refract_bwd(const float* d, const float* nrm, const float* ior, int M,
  *   nu_s2_far_points / _far_resample    importance pass of the rays that miss the mesh (:1786-1812, no gradient): 192 coarse nodes
  *                                       -> point records; alpha [M,192] -> 64 inverse-CDF samples merged in: zout [M,256] sorted */
 int nu_s2_hit_fwd(const float* o, const float* d, const long long* face, const float* verts, const float* vnrm, const long long* faces,
-                  int M, float* point, float* nrm, float* t, hipStream_t stream);
+                  int M, float* point, float* nrm, float* t, const float* vcurv /* optional [V]: per-vertex Gaussian curvature */,
+                  float* gk /* [M]: its barycentric interpolation (DiffRender.py:116) */, hipStream_t stream);
 int nu_s2_hit_bwd(const float* o, const float* d, const long long* face, const float* verts, const float* vnrm, const long long* faces,
-                  int M, const float* g_point, const float* g_nrm, const float* g_t, float* g_o, float* g_d, hipStream_t stream);
+                  int M, const float* g_point, const float* g_nrm, const float* g_t, float* g_o, float* g_d, const float* vcurv,
+                  const float* g_gk, hipStream_t stream);
 int nu_s2_far_points(const float* start, const float* dirs, const float* zo, int M, int S, float* pt, int* idx, hipStream_t stream);
 int nu_s2_far_resample(const float* alpha, const float* zo, int M, int S, int n_new, float* zout, hipStream_t stream);
 /*   nu_s2_shade_combine_fwd / _bwd      AppShadingNetwork_S2.forward's BRDF mix (field.py:909-1010) on raw head outputs, layouts as

@@ -535,7 +535,8 @@ static __device__ inline S2Tri s2_load_tri(const float* __restrict__ verts, cons
 __global__ __launch_bounds__(256) void s2_hit_fwd_kernel(const float* __restrict__ o, const float* __restrict__ d,
                                                          const long long* __restrict__ face, const float* __restrict__ verts,
                                                          const float* __restrict__ vnrm, const long long* __restrict__ faces, int M,
-                                                         float* __restrict__ point, float* __restrict__ nrm, float* __restrict__ tout) {
+                                                         float* __restrict__ point, float* __restrict__ nrm, float* __restrict__ tout,
+                                                         const float* __restrict__ vcurv, float* __restrict__ gk) {
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= M) return;
     const S2Tri T = s2_load_tri(verts, vnrm, faces, face[m]);
@@ -562,13 +563,18 @@ __global__ __launch_bounds__(256) void s2_hit_fwd_kernel(const float* __restrict
         point[m * 3LL + c] = oo[c] + t * dd[c];
     }
     tout[m] = t;
+    if (vcurv) {                       // per-vertex Gaussian curvature, interpolated like the normal (DiffRender.py:116)
+        const long long f = face[m];
+        gk[m] = (1.0f - u - v) * vcurv[faces[f * 3]] + u * vcurv[faces[f * 3 + 1]] + v * vcurv[faces[f * 3 + 2]];
+    }
 }
 
 __global__ __launch_bounds__(256) void s2_hit_bwd_kernel(const float* __restrict__ o, const float* __restrict__ d,
                                                          const long long* __restrict__ face, const float* __restrict__ verts,
                                                          const float* __restrict__ vnrm, const long long* __restrict__ faces, int M,
                                                          const float* __restrict__ g_point, const float* __restrict__ g_nrm,
-                                                         const float* __restrict__ g_t, float* __restrict__ g_o, float* __restrict__ g_d) {
+                                                         const float* __restrict__ g_t, float* __restrict__ g_o, float* __restrict__ g_d,
+                                                         const float* __restrict__ vcurv, const float* __restrict__ g_gk) {
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= M) return;
     const S2Tri T = s2_load_tri(verts, vnrm, faces, face[m]);
@@ -608,6 +614,12 @@ __global__ __launch_bounds__(256) void s2_hit_bwd_kernel(const float* __restrict
         gu += gnr * (T.n1[c] - T.n0[c]);
         gv += gnr * (T.n2[c] - T.n0[c]);
     }
+    if (vcurv && g_gk) {               // g_k = (1 - u - v) k0 + u k1 + v k2
+        const long long f = face[m];
+        const float k0 = vcurv[faces[f * 3]];
+        gu += g_gk[m] * (vcurv[faces[f * 3 + 1]] - k0);
+        gv += g_gk[m] * (vcurv[faces[f * 3 + 2]] - k0);
+    }
     float gq[3], gtv[3], gpv[3];
     float ginv = gt * eq + gv * dq + gu * tp;
 #pragma unroll
@@ -633,17 +645,20 @@ __global__ __launch_bounds__(256) void s2_hit_bwd_kernel(const float* __restrict
 }
 
 extern "C" int nu_s2_hit_fwd(const float* o, const float* d, const long long* face, const float* verts, const float* vnrm,
-                             const long long* faces, int M, float* point, float* nrm, float* t, hipStream_t stream) {
+                             const long long* faces, int M, float* point, float* nrm, float* t, const float* vcurv, float* gk,
+                             hipStream_t stream) {
     if (M <= 0) return NU_OK;
-    hipLaunchKernelGGL(s2_hit_fwd_kernel, dim3(nu_cdiv(M, 256)), dim3(256), 0, stream, o, d, face, verts, vnrm, faces, M, point, nrm, t);
+    if (vcurv && !gk) return NU_ERR_ARG;
+    hipLaunchKernelGGL(s2_hit_fwd_kernel, dim3(nu_cdiv(M, 256)), dim3(256), 0, stream, o, d, face, verts, vnrm, faces, M, point, nrm, t,
+                       vcurv, gk);
     return nu_launch_status();
 }
 extern "C" int nu_s2_hit_bwd(const float* o, const float* d, const long long* face, const float* verts, const float* vnrm,
                              const long long* faces, int M, const float* g_point, const float* g_nrm, const float* g_t, float* g_o,
-                             float* g_d, hipStream_t stream) {
+                             float* g_d, const float* vcurv, const float* g_gk, hipStream_t stream) {
     if (M <= 0) return NU_OK;
     hipLaunchKernelGGL(s2_hit_bwd_kernel, dim3(nu_cdiv(M, 256)), dim3(256), 0, stream, o, d, face, verts, vnrm, faces, M, g_point, g_nrm,
-                       g_t, g_o, g_d);
+                       g_t, g_o, g_d, vcurv, g_gk);
     return nu_launch_status();
 }
 

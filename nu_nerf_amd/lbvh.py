@@ -89,6 +89,13 @@ class Scene:
         vn = torch.zeros_like(self.vertices)
         vn.index_add_(0, self.faces.reshape(-1), (ang[:, :, None] * fn[:, None, :]).reshape(-1, 3))
         self.normals = vn / vn.norm(dim=1, keepdim=True)
+        # Per-vertex Gaussian curvature (DiffRender.py:331,360 takes PyMesh's "vertex_gaussian_curvature" and clips it to
+        # [-10, 10]): angle defect 2 pi - sum of the corner angles at the vertex, over the vertex area (a third of the incident
+        # faces' area).  PyMesh is absent here: pinned analytically (sphere: 1 / r^2), not against PyMesh output.
+        area = 0.5 * torch.linalg.norm(torch.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0], dim=1), dim=1)
+        ang_sum = torch.zeros(len(self.vertices), device=ang.device, dtype=ang.dtype).index_add_(0, self.faces.reshape(-1), ang.reshape(-1))
+        v_area = torch.zeros_like(ang_sum).index_add_(0, self.faces.reshape(-1), (area / 3.0)[:, None].expand(-1, 3).reshape(-1))
+        self.gaussian_curvatures = torch.clamp((2.0 * math.pi - ang_sum) / v_area.clamp_min(1e-20), -10.0, 10.0)[:, None]
 
     def intersect(self, origin, direction):
         hit, idx = self.bvh.intersect(torch.cat([origin, direction], 1))

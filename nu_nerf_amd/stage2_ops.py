@@ -172,34 +172,40 @@ def refract(eng, d, nrm, ior, point, outside):
 
 class _HitFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, eng, o, d, face, verts, vnrm, faces):
+    def forward(ctx, eng, o, d, face, verts, vnrm, faces, vcurv):
         o, d = o.detach().contiguous(), d.detach().contiguous()
         M = o.shape[0]
         point, nrm, t = torch.empty_like(o), torch.empty_like(o), torch.empty(M, device=o.device)
+        gk = torch.zeros(M, device=o.device)
         L.check(eng.lib.nu_s2_hit_fwd(c_p(addr(o)), c_p(addr(d)), c_p(addr(face)), c_p(addr(verts)), c_p(addr(vnrm)), c_p(addr(faces)), M,
-                                      c_p(addr(point)), c_p(addr(nrm)), c_p(addr(t)), eng.stream()), "nu_s2_hit_fwd")
-        ctx.eng, ctx.consts = eng, (face, verts, vnrm, faces)
+                                      c_p(addr(point)), c_p(addr(nrm)), c_p(addr(t)), c_p(addr(vcurv)), c_p(addr(gk)), eng.stream()),
+                "nu_s2_hit_fwd")
+        ctx.eng, ctx.consts = eng, (face, verts, vnrm, faces, vcurv)
         ctx.save_for_backward(o, d)
         ctx.set_materialize_grads(False)
-        return point, nrm, t
+        return point, nrm, t, gk
 
     @staticmethod
-    def backward(ctx, g_point, g_nrm, g_t):
+    def backward(ctx, g_point, g_nrm, g_t, g_gk):
         o, d = ctx.saved_tensors
-        face, verts, vnrm, faces = ctx.consts
+        face, verts, vnrm, faces, vcurv = ctx.consts
         M = o.shape[0]
         g_o, g_d = torch.zeros_like(o), torch.zeros_like(d)
         cg = lambda t: t.contiguous() if t is not None else None
-        g_point, g_nrm, g_t = cg(g_point), cg(g_nrm), cg(g_t)
+        g_point, g_nrm, g_t, g_gk = cg(g_point), cg(g_nrm), cg(g_t), cg(g_gk)
         L.check(ctx.eng.lib.nu_s2_hit_bwd(c_p(addr(o)), c_p(addr(d)), c_p(addr(face)), c_p(addr(verts)), c_p(addr(vnrm)), c_p(addr(faces)), M,
                                           c_p(addr(g_point)), c_p(addr(g_nrm)), c_p(addr(g_t)), c_p(addr(g_o)), c_p(addr(g_d)),
-                                          ctx.eng.stream()), "nu_s2_hit_bwd")
-        return None, g_o, g_d, None, None, None, None
+                                          c_p(addr(vcurv)), c_p(addr(g_gk if vcurv is not None else None)), ctx.eng.stream()), "nu_s2_hit_bwd")
+        return None, g_o, g_d, None, None, None, None, None
 
 
-def hit(eng, scene, o, d, face):
-    """Differentiable intersection of the rays (o, d) [M,3] with the faces `face` [M] the LBVH found: (point, unit normal, t)."""
-    return _HitFn.apply(eng, o, d, face.contiguous(), scene.vertices, scene.normals, scene.faces)
+def hit(eng, scene, o, d, face, curvature=False):
+    """Differentiable intersection of the rays (o, d) [M,3] with the faces `face` [M] the LBVH found: (point, unit normal, t),
+    plus the interpolated per-vertex Gaussian curvature g_k [M] with curvature=True (DiffRender.py:116, the non-zero-thickness
+    stage-2 model's input)."""
+    vcurv = scene.gaussian_curvatures.reshape(-1).contiguous() if curvature else None
+    point, nrm, t, gk = _HitFn.apply(eng, o, d, face.contiguous(), scene.vertices, scene.normals, scene.faces, vcurv)
+    return (point, nrm, t, gk) if curvature else (point, nrm, t)
 
 
 def far_importance_nodes(eng, start, dirs):
