@@ -157,6 +157,13 @@ int nu_skinny_bwd_enqueue(const float* dy, int ldy, const float* H, int ldh, int
                           int NO, float* dH, int lddh, int relu_mask, int accumulate, float* dWs, int lddw, float* db,
                           void* workspace, long long workspace_bytes, NuReduceDesc* descs, int* ndesc, int cap,
                           hipStream_t stream);
+/* bf16-storage forms (NuOpCtx.h16): the hidden rows H -- and the dH written -- are __bf16; head weights, dy, outputs and every
+ * reduction stay fp32 */
+int nu_skinny_fwd_h16(const void* H, int ldh, int P, int K, const float* Ws, int ldw, const float* b, int NO, float* out, int ldo,
+                      hipStream_t stream);
+int nu_skinny_bwd_enqueue_h16(const float* dy, int ldy, const void* H, int ldh, int P, int K, const float* Ws, int ldw, int NO,
+                              void* dH, int lddh, int relu_mask, int accumulate, float* dWs, int lddw, float* db, void* workspace,
+                              long long workspace_bytes, NuReduceDesc* descs, int* ndesc, int cap, hipStream_t stream);
 long long nu_colsum_workspace_bytes(int ncols);
 int nu_colsum_enqueue(const float* A, int lda, int P, int ncols, float* out, int accumulate, void* workspace,
                       long long workspace_bytes, NuReduceDesc* descs, int* ndesc, int cap, hipStream_t stream);
@@ -288,9 +295,10 @@ typedef struct NuLin {
 /* NuOpCtx.h16 != 0 (with prec == 1): bf16 STORAGE.  Every NT GEMM reads the bf16 weight tables and the hidden activations
  * that only GEMMs touch live in HBM as bf16; the caller allocates exactly these buffers as __bf16 (same shapes and leading
  * dimensions, in elements), everything else stays fp32:
- *   SDF      H[1..3], H[5..7];  D[0..2], D[4..6];  Q[1..3], Q[5..7];  C[l] / Aux[l] for l in {0,1,2,4,5,6}
- *   NeRF++   H[1..4], H[6..7];  dA[1..4], dA[6..8]
- *   shading  M[0], M[1], dM[0], dM[1];  hidden [0], [1] and tmp[0], tmp[1] of every light predictor
+ *   SDF      H[1..3], H[5..7] (and H[8] in the no-gradient form, want_feat == 0);  D[0..2], D[4..6];  Q[1..3], Q[5..7];
+ *            C[l] / Aux[l] for l in {0,1,2,4,5,6}
+ *   NeRF++   H[1..4], H[6..8];  dA[1..4], dA[6..8];  dH8a
+ *   shading  M[0..2], dM[0..2];  hidden [0..2], tmp[0], tmp[1] and dH3 of every light predictor
  * Optional per-launch timing: when `ev` is set, every GEMM launch is bracketed by hipEventRecord on ev[nev], ev[nev + 1]
  * and described in ev_meta[nev / 2] = {kind (0 NT, 1 TN), algorithmic flops, algorithmic bytes} until ev_cap is reached. */
 typedef struct NuOpCtx {

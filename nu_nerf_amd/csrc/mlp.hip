@@ -95,8 +95,25 @@ extern "C" int nu_reduce_desc_size() { return (int)sizeof(NuReduceDesc); }
 // ------------------------------------------------------------------------------------------------
 // skinny heads: out[p, j] = sum_k H[p, k] * Ws[j, k] + b[j],  j < NO <= 8.   HBM-bound (reads H once).
 // ------------------------------------------------------------------------------------------------
+// H16 (bf16-storage mode, NuOpCtx.h16): the hidden rows H -- and the dH the backward writes -- are __bf16 behind the float*
+// (leading dimensions in elements); arithmetic stays fp32
+template <bool H16> static __device__ __forceinline__ f32x4 sk_ld4(const float* base, long long idx) {
+    if (H16) {
+        const uint2 r = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(base) + idx * 2);
+        f32x4 o;
+        o[0] = __uint_as_float(r.x << 16); o[1] = __uint_as_float(r.x & 0xffff0000u);
+        o[2] = __uint_as_float(r.y << 16); o[3] = __uint_as_float(r.y & 0xffff0000u);
+        return o;
+    }
+    return *reinterpret_cast<const f32x4*>(base + idx);
+}
+template <bool H16> static __device__ __forceinline__ void sk_st4(float* base, long long idx, f32x4 v) {
+    if (H16) *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(base) + idx * 2) = nu_to_bf16x4(v);
+    else *reinterpret_cast<f32x4*>(base + idx) = v;
+}
+
 // One wave per row (K = 128: two rows per wave), head weights held in registers, two rows in flight per wave.
-template <int NO, int K>
+template <int NO, int K, bool H16 = false>
 __global__ __launch_bounds__(256) void skinny_fwd_kernel(const float* __restrict__ H, int ldh, int P,
                                                          const float* __restrict__ Ws, int ldw,
                                                          const float* __restrict__ b, float* __restrict__ out, int ldo) {
@@ -140,8 +157,8 @@ __global__ __launch_bounds__(256) void skinny_fwd_kernel(const float* __restrict
         f32x4 ha[KQ], hb[KQ];
 #pragma unroll
         for (int t = 0; t < KQ; ++t) {
-            ha[t] = *reinterpret_cast<const f32x4*>(H + (long long)p * ldh + 4 * ln + 256 * t);
-            hb[t] = *reinterpret_cast<const f32x4*>(H + (long long)(p + step) * ldh + 4 * ln + 256 * t);
+            ha[t] = sk_ld4<H16>(H, (long long)p * ldh + 4 * ln + 256 * t);
+            hb[t] = sk_ld4<H16>(H, (long long)(p + step) * ldh + 4 * ln + 256 * t);
         }
         finish(p, ha);
         finish(p + step, hb);
@@ -149,18 +166,31 @@ __global__ __launch_bounds__(256) void skinny_fwd_kernel(const float* __restrict
     if (p < P) {
         f32x4 ha[KQ];
 #pragma unroll
-        for (int t = 0; t < KQ; ++t) ha[t] = *reinterpret_cast<const f32x4*>(H + (long long)p * ldh + 4 * ln + 256 * t);
+        for (int t = 0; t < KQ; ++t) ha[t] = sk_ld4<H16>(H, (long long)p * ldh + 4 * ln + 256 * t);
         finish(p, ha);
     }
 }
 
+static int skinny_fwd_launch(const float* H, int ldh, int P, int K, const float* Ws, int ldw, const float* b, int NO, float* out, int ldo,
+                             bool h16, hipStream_t stream);
 extern "C" int nu_skinny_fwd(const float* H, int ldh, int P, int K, const float* Ws, int ldw, const float* b, int NO,
                              float* out, int ldo, hipStream_t stream) {
+    return skinny_fwd_launch(H, ldh, P, K, Ws, ldw, b, NO, out, ldo, false, stream);
+}
+// H is __bf16 [P, ldh] (bf16-storage mode)
+extern "C" int nu_skinny_fwd_h16(const void* H, int ldh, int P, int K, const float* Ws, int ldw, const float* b, int NO,
+                                 float* out, int ldo, hipStream_t stream) {
+    return skinny_fwd_launch(static_cast<const float*>(H), ldh, P, K, Ws, ldw, b, NO, out, ldo, true, stream);
+}
+static int skinny_fwd_launch(const float* H, int ldh, int P, int K, const float* Ws, int ldw, const float* b, int NO, float* out, int ldo,
+                             bool h16, hipStream_t stream) {
     if (P <= 0) return NU_OK;
     if ((K & 3) || (ldh & 3) || (ldw & 3)) return NU_ERR_ARG;
     const int blocks = nu_cdiv(P, 8) < 2048 ? nu_cdiv(P, 8) : 2048;
     dim3 grid(blocks), block(256);
-#define NU_CASE(n, k) if (NO == n && K == k) { hipLaunchKernelGGL((skinny_fwd_kernel<n, k>), grid, block, 0, stream, H, ldh, P, Ws, ldw, b, out, ldo); return nu_launch_status(); }
+#define NU_CASE(n, k) if (NO == n && K == k) { if (h16) hipLaunchKernelGGL((skinny_fwd_kernel<n, k, true>), grid, block, 0, stream, H, ldh, P, Ws, ldw, b, out, ldo); \
+                                               else hipLaunchKernelGGL((skinny_fwd_kernel<n, k, false>), grid, block, 0, stream, H, ldh, P, Ws, ldw, b, out, ldo); \
+                                               return nu_launch_status(); }
     NU_CASE(1, 128) NU_CASE(2, 128) NU_CASE(3, 128) NU_CASE(4, 128)
     NU_CASE(1, 256) NU_CASE(2, 256) NU_CASE(3, 256) NU_CASE(4, 256)
     NU_CASE(6, 1024)
@@ -176,7 +206,7 @@ extern "C" int nu_skinny_fwd(const float* H, int ldh, int P, int K, const float*
 // is cut into 256-column slices along grid.y -- dH and dWs are column-local), four waves per block on interleaved
 // rows, two rows in flight per wave; the four waves' weight-gradient partials are summed through LDS in a fixed order
 // before the block writes its slab.
-template <int NO, int K>
+template <int NO, int K, bool H16 = false>
 __global__ __launch_bounds__(256) void skinny_bwd_kernel(const float* __restrict__ dy, int ldy,
                                                          const float* __restrict__ H, int ldh, int P,
                                                          const float* __restrict__ Ws, int ldw, float* __restrict__ dH,
@@ -185,7 +215,7 @@ __global__ __launch_bounds__(256) void skinny_bwd_kernel(const float* __restrict
     constexpr int KQ = 1;                               // float4 chunks per lane
     constexpr int RPW = K >= 256 ? 1 : 2;               // rows per wave per pass
     const int cb = blockIdx.y * K;                      // first column of this block's slice
-    H += cb; Ws += cb; dH += cb;
+    Ws += cb;                                           // (H and dH: the column offset goes into the element index)
     constexpr int LPR = 64 / RPW;                       // lanes per row
     __shared__ float red[4 * K];
     __shared__ float bred[4][8];
@@ -227,9 +257,9 @@ __global__ __launch_bounds__(256) void skinny_bwd_kernel(const float* __restrict
 #pragma unroll
                 for (int e = 0; e < 4; ++e) d[e] = h[t][e] > 0.f ? d[e] : 0.f;
             }
-            float* q = dH + (long long)p * lddh + 4 * ln + 256 * t;
-            if (accumulate) d += *reinterpret_cast<const f32x4*>(q);
-            *reinterpret_cast<f32x4*>(q) = d;
+            const long long qi = (long long)p * lddh + cb + 4 * ln + 256 * t;
+            if (accumulate) d += sk_ld4<H16>(dH, qi);
+            sk_st4<H16>(dH, qi, d);
         }
     };
     int p = p0 + wave * RPW + sub;
@@ -237,8 +267,8 @@ __global__ __launch_bounds__(256) void skinny_bwd_kernel(const float* __restrict
         f32x4 ha[KQ], hb[KQ];
 #pragma unroll
         for (int t = 0; t < KQ; ++t) {
-            ha[t] = *reinterpret_cast<const f32x4*>(H + (long long)p * ldh + 4 * ln + 256 * t);
-            hb[t] = *reinterpret_cast<const f32x4*>(H + (long long)(p + STEP) * ldh + 4 * ln + 256 * t);
+            ha[t] = sk_ld4<H16>(H, (long long)p * ldh + cb + 4 * ln + 256 * t);
+            hb[t] = sk_ld4<H16>(H, (long long)(p + STEP) * ldh + cb + 4 * ln + 256 * t);
         }
         row_body(p, ha);
         row_body(p + STEP, hb);
@@ -246,7 +276,7 @@ __global__ __launch_bounds__(256) void skinny_bwd_kernel(const float* __restrict
     for (; p < p1; p += STEP) {
         f32x4 ha[KQ];
 #pragma unroll
-        for (int t = 0; t < KQ; ++t) ha[t] = *reinterpret_cast<const f32x4*>(H + (long long)p * ldh + 4 * ln + 256 * t);
+        for (int t = 0; t < KQ; ++t) ha[t] = sk_ld4<H16>(H, (long long)p * ldh + cb + 4 * ln + 256 * t);
         row_body(p, ha);
     }
     // block reduction, one output row j at a time: red[wave][k] (for K = 128 the two half-waves add first)
@@ -285,10 +315,27 @@ extern "C" long long nu_skinny_bwd_workspace_bytes(int K, int NO) {
     return (long long)NU_SKINNY_BLOCKS * NO * (K + 1) * sizeof(float);
 }
 
+static int skinny_bwd_launch(const float* dy, int ldy, const float* H, int ldh, int P, int K, const float* Ws, int ldw, int NO, float* dH,
+                             int lddh, int relu_mask, int accumulate, float* dWs, int lddw, float* db, void* workspace,
+                             long long workspace_bytes, NuReduceDesc* descs, int* ndesc, int cap, bool h16, hipStream_t stream);
 extern "C" int nu_skinny_bwd_enqueue(const float* dy, int ldy, const float* H, int ldh, int P, int K, const float* Ws,
                                      int ldw, int NO, float* dH, int lddh, int relu_mask, int accumulate, float* dWs,
                                      int lddw, float* db, void* workspace, long long workspace_bytes,
                                      NuReduceDesc* descs, int* ndesc, int cap, hipStream_t stream) {
+    return skinny_bwd_launch(dy, ldy, H, ldh, P, K, Ws, ldw, NO, dH, lddh, relu_mask, accumulate, dWs, lddw, db, workspace, workspace_bytes,
+                             descs, ndesc, cap, false, stream);
+}
+// H and dH are __bf16 (bf16-storage mode); dy, the head weights and every reduction stay fp32
+extern "C" int nu_skinny_bwd_enqueue_h16(const float* dy, int ldy, const void* H, int ldh, int P, int K, const float* Ws,
+                                         int ldw, int NO, void* dH, int lddh, int relu_mask, int accumulate, float* dWs,
+                                         int lddw, float* db, void* workspace, long long workspace_bytes,
+                                         NuReduceDesc* descs, int* ndesc, int cap, hipStream_t stream) {
+    return skinny_bwd_launch(dy, ldy, static_cast<const float*>(H), ldh, P, K, Ws, ldw, NO, static_cast<float*>(dH), lddh, relu_mask,
+                             accumulate, dWs, lddw, db, workspace, workspace_bytes, descs, ndesc, cap, true, stream);
+}
+static int skinny_bwd_launch(const float* dy, int ldy, const float* H, int ldh, int P, int K, const float* Ws, int ldw, int NO, float* dH,
+                             int lddh, int relu_mask, int accumulate, float* dWs, int lddw, float* db, void* workspace,
+                             long long workspace_bytes, NuReduceDesc* descs, int* ndesc, int cap, bool h16, hipStream_t stream) {
     if (P <= 0) return NU_ERR_ARG;
     if (workspace_bytes < nu_skinny_bwd_workspace_bytes(K, NO)) return NU_ERR_WORKSPACE;
     if (*ndesc + 2 > cap) return NU_ERR_WORKSPACE;
@@ -300,19 +347,19 @@ extern "C" int nu_skinny_bwd_enqueue(const float* dy, int ldy, const float* H, i
     if ((ldh & 3) || (lddh & 3) || (ldw & 3)) return NU_ERR_ARG;
     if (K == 128) {
         switch (NO) {
-            case 1: hipLaunchKernelGGL((skinny_bwd_kernel<1, 128>), dim3(blocks), dim3(256), 0, stream, NU_ARGS); break;
-            case 3: hipLaunchKernelGGL((skinny_bwd_kernel<3, 128>), dim3(blocks), dim3(256), 0, stream, NU_ARGS); break;
+            case 1: if (h16) hipLaunchKernelGGL((skinny_bwd_kernel<1, 128, true>), dim3(blocks), dim3(256), 0, stream, NU_ARGS); else hipLaunchKernelGGL((skinny_bwd_kernel<1, 128, false>), dim3(blocks), dim3(256), 0, stream, NU_ARGS); break;
+            case 3: if (h16) hipLaunchKernelGGL((skinny_bwd_kernel<3, 128, true>), dim3(blocks), dim3(256), 0, stream, NU_ARGS); else hipLaunchKernelGGL((skinny_bwd_kernel<3, 128, false>), dim3(blocks), dim3(256), 0, stream, NU_ARGS); break;
             default: return NU_ERR_ARG;
         }
     } else if (K == 256) {
         switch (NO) {
-            case 1: hipLaunchKernelGGL((skinny_bwd_kernel<1, 256>), dim3(blocks), dim3(256), 0, stream, NU_ARGS); break;
-            case 3: hipLaunchKernelGGL((skinny_bwd_kernel<3, 256>), dim3(blocks), dim3(256), 0, stream, NU_ARGS); break;
+            case 1: if (h16) hipLaunchKernelGGL((skinny_bwd_kernel<1, 256, true>), dim3(blocks), dim3(256), 0, stream, NU_ARGS); else hipLaunchKernelGGL((skinny_bwd_kernel<1, 256, false>), dim3(blocks), dim3(256), 0, stream, NU_ARGS); break;
+            case 3: if (h16) hipLaunchKernelGGL((skinny_bwd_kernel<3, 256, true>), dim3(blocks), dim3(256), 0, stream, NU_ARGS); else hipLaunchKernelGGL((skinny_bwd_kernel<3, 256, false>), dim3(blocks), dim3(256), 0, stream, NU_ARGS); break;
             default: return NU_ERR_ARG;
         }
     } else if (K == 1024) {
         switch (NO) {
-            case 6: hipLaunchKernelGGL((skinny_bwd_kernel<6, 256>), dim3(blocks, 4), dim3(256), 0, stream, NU_ARGS); break;
+            case 6: if (h16) hipLaunchKernelGGL((skinny_bwd_kernel<6, 256, true>), dim3(blocks, 4), dim3(256), 0, stream, NU_ARGS); else hipLaunchKernelGGL((skinny_bwd_kernel<6, 256, false>), dim3(blocks, 4), dim3(256), 0, stream, NU_ARGS); break;
             default: return NU_ERR_ARG;
         }
     } else {

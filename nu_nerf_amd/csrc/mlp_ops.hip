@@ -14,6 +14,9 @@
 #define CHK(x) do { const int rc_ = (x); if (rc_ != NU_OK) return rc_; } while (0)
 
 extern "C" int nu_skinny_fwd(const float*, int, int, int, const float*, int, const float*, int, float*, int, hipStream_t);
+extern "C" int nu_skinny_fwd_h16(const void*, int, int, int, const float*, int, const float*, int, float*, int, hipStream_t);
+extern "C" int nu_skinny_bwd_enqueue_h16(const float*, int, const void*, int, int, int, const float*, int, int, void*, int, int, int,
+                                         float*, int, float*, void*, long long, NuReduceDesc*, int*, int, hipStream_t);
 extern "C" long long nu_skinny_bwd_workspace_bytes(int, int);
 extern "C" int nu_skinny_bwd_enqueue(const float*, int, const float*, int, int, int, const float*, int, int, float*, int, int, int,
                                      float*, int, float*, void*, long long, NuReduceDesc*, int*, int, hipStream_t);
@@ -126,14 +129,23 @@ static int wgrad(NuOpCtx* c, const float* A0, int lda0, const float* B0, int ldb
     return rc;
 }
 
+// h16: the hidden rows H and the dH written are bf16 under NuOpCtx.h16 (the last hidden layer in front of a skinny head)
 static int skinny_bwd(NuOpCtx* c, const float* dy, int ldy, const float* H, int ldh, int P, int K, const float* Ws, int ldw, int NO,
-                      float* dH, int lddh, int relu_mask, float* dWs, int lddw, float* db, hipStream_t stream) {
+                      float* dH, int lddh, int relu_mask, float* dWs, int lddw, float* db, hipStream_t stream, bool h16 = false) {
     if (P <= 0) return NU_OK;
     float* ws;
     long long nb;
     CHK(ctx_take(c, nu_skinny_bwd_workspace_bytes(K, NO), 2, stream, &ws, &nb));
+    if (h16 && c->h16)
+        return nu_skinny_bwd_enqueue_h16(dy, ldy, H, ldh, P, K, Ws, ldw, NO, dH, lddh, relu_mask, 0, dWs, lddw, db, ws, nb, c->descs,
+                                         &c->ndesc, c->cap, stream);
     return nu_skinny_bwd_enqueue(dy, ldy, H, ldh, P, K, Ws, ldw, NO, dH, lddh, relu_mask, 0, dWs, lddw, db, ws, nb, c->descs, &c->ndesc,
                                  c->cap, stream);
+}
+static int skinny_fwd(const NuOpCtx* c, const float* H, int ldh, int P, int K, const float* Ws, int ldw, const float* b, int NO, float* out,
+                      int ldo, hipStream_t stream, bool h16) {
+    if (h16 && c->h16) return nu_skinny_fwd_h16(H, ldh, P, K, Ws, ldw, b, NO, out, ldo, stream);
+    return nu_skinny_fwd(H, ldh, P, K, Ws, ldw, b, NO, out, ldo, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -157,7 +169,8 @@ extern "C" int nu_sdf_mlp_fwd(NuOpCtx* c, const NuSdfNet* net, const float* X, i
         const NuLin& L = net->lin[l];
         NtArgs g = {src, lds, L.Wp, L.Kp, P, L.N, K, a->H[l + 1], 256, NU_EPI_BIAS_SOFTPLUS};
         g.bias = L.bias; g.zero_to = L.N; g.ktrue = L.K;
-        g.B16 = w16(L.Wp16, 0); g.st = (sdfH16(l) ? A16 : 0) | (sdfH16(l + 1) ? C16 : 0);
+        // the no-gradient form (sampler chain, want_feat == 0) also keeps H[8] in bf16: only the sdf head reads it
+        g.B16 = w16(L.Wp16, 0); g.st = (sdfH16(l) ? A16 : 0) | ((sdfH16(l + 1) || (l == 7 && !want_feat)) ? C16 : 0);
         CHK(nt(c, g, stream));
         src = a->H[l + 1]; lds = 256; K = 256;
     }
@@ -168,7 +181,7 @@ extern "C" int nu_sdf_mlp_fwd(NuOpCtx* c, const NuSdfNet* net, const float* X, i
         g.bias = L8.bias + 1; g.B16 = w16(L8.Wp16, 256);
         CHK(nt(c, g, stream));
     } else {
-        CHK(nu_skinny_fwd(a->H[8], 256, P, 256, L8.Wp, 256, L8.bias, 1, a->sdf, 1, stream));
+        CHK(skinny_fwd(c, a->H[8], 256, P, 256, L8.Wp, 256, L8.bias, 1, a->sdf, 1, stream, true));
     }
     return NU_OK;
 }
@@ -254,7 +267,7 @@ extern "C" int nu_sdf_mlp_bwd(NuOpCtx* c, const NuSdfNet* net, NuSdfBufs* a, con
 
 // ---------------------------------------------------------------------------------------------------------
 // make_predictor stacks (field.py:371-408): 3 hidden ReLU layers + a 1..3-wide head
-// h16: hidden [0], [1] and the backward scratch tmp[0], tmp[1] are bf16; hidden [2] (read by the skinny head) and dH3 fp32
+// h16: the hidden activations [0..2], the backward scratch tmp[0], tmp[1] and dH3 are bf16 (the skinny head kernels read / write bf16)
 // ---------------------------------------------------------------------------------------------------------
 static int relu_stack_fwd(NuOpCtx* c, const NuLin* ls, const float* X, int ldx, int rows, float* const* Hs, unsigned long long* const* masks,
                           int nct, hipStream_t stream) {
@@ -263,7 +276,7 @@ static int relu_stack_fwd(NuOpCtx* c, const NuLin* ls, const float* X, int ldx, 
     for (int j = 0; j < 3; ++j) {
         NtArgs g = {src, lds, ls[j].Wp, ls[j].Kp, rows, 256, ls[j].Kp, Hs[j], 256, NU_EPI_BIAS_RELU};
         g.bias = ls[j].bias; g.mask = masks[j]; g.mask_nct = nct;
-        g.B16 = w16(ls[j].Wp16, 0); g.st = (j > 0 ? A16 : 0) | (j < 2 ? C16 : 0);
+        g.B16 = w16(ls[j].Wp16, 0); g.st = (j > 0 ? A16 : 0) | C16;
         CHK(nt(c, g, stream));
         src = Hs[j]; lds = 256;
     }
@@ -277,7 +290,7 @@ static int relu_stack_bwd(NuOpCtx* c, const NuLin* ls, const float* X, int ldx, 
     for (int j = 2; j >= 0; --j) {
         const float* u = j == 0 ? X : Hs[j - 1];
         const int ldu = j == 0 ? ldx : 256;
-        const int a16 = j < 2;                      // dA is tmp[j] (bf16) below the top layer
+        const int a16 = 1;                          // dA: dH3 (written by the skinny head's backward) or tmp[j], bf16 both
         CHK(wgrad(c, dA, 256, u, ldu, rows, 256, ls[j].Kp, ls[j].dWp, ls[j].ldd, c->flat + ls[j].db_off, stream,
                   (a16 ? NU_TN_A0_16 : 0) | (j > 0 ? NU_TN_B0_16 : 0)));
         if (j > 0) {
@@ -298,12 +311,12 @@ static int relu_stack_bwd(NuOpCtx* c, const NuLin* ls, const float* X, int ldx, 
 // ---------------------------------------------------------------------------------------------------------
 // NeRF++ (field.py:265-289): 8 x 256 ReLU with the 84-d embedding re-concatenated before layer 5, alpha / feature heads,
 // one 283 -> 128 view layer, rgb head
-// h16: H[1..4], H[6..7] and dA[1..4], dA[6..8] are bf16
+// h16: H[1..4], H[6..8], dA[1..4], dA[6..8] and dH8a are bf16
 // ---------------------------------------------------------------------------------------------------------
 extern "C" int nu_nerf_net_size(void) { return (int)sizeof(NuNerfNet); }
 extern "C" int nu_nerf_bufs_size(void) { return (int)sizeof(NuNerfBufs); }
-static inline bool nerfH16(int i) { return i == 1 || i == 2 || i == 3 || i == 4 || i == 6 || i == 7; }
-static inline bool nerfdA16(int i) { return nerfH16(i) || i == 8; }
+static inline bool nerfH16(int i) { return i == 1 || i == 2 || i == 3 || i == 4 || i == 6 || i == 7 || i == 8; }
+static inline bool nerfdA16(int i) { return nerfH16(i); }
 
 extern "C" int nu_nerfpp_mlp_fwd(NuOpCtx* c, const NuNerfNet* net, const float* pt, int pt_ld, NuNerfBufs* b, hipStream_t stream) {
     const int P = b->P;
@@ -320,9 +333,9 @@ extern "C" int nu_nerfpp_mlp_fwd(NuOpCtx* c, const NuNerfNet* net, const float* 
         CHK(nt(c, g, stream));
         src = b->H[i + 1]; lds = ldc;
     }
-    CHK(nu_skinny_fwd(b->H[8], 256, P, 256, net->alpha.Wp, 256, net->alpha.bias, 1, b->sig, 1, stream));
+    CHK(skinny_fwd(c, b->H[8], 256, P, 256, net->alpha.Wp, 256, net->alpha.bias, 1, b->sig, 1, stream, true));
     NtArgs gf = {b->H[8], 256, net->feat.Wp, 256, P, 256, 256, b->V, 288, NU_EPI_BIAS_NONE};
-    gf.bias = net->feat.bias; gf.B16 = w16(net->feat.Wp16, 0);
+    gf.bias = net->feat.bias; gf.B16 = w16(net->feat.Wp16, 0); gf.st = A16;
     CHK(nt(c, gf, stream));
     NtArgs gv = {b->V, 288, net->view.Wp, 288, P, 128, 288, b->HV, 128, NU_EPI_BIAS_RELU};
     gv.bias = net->view.bias; gv.B16 = w16(net->view.Wp16, 0);
@@ -342,11 +355,12 @@ extern "C" int nu_nerfpp_mlp_bwd(NuOpCtx* c, const NuNerfNet* net, const float* 
     NtArgs gF = {b->dHV, 128, net->view.WpT, net->view.ldT, P, ldf, 128, b->dF, ldf, NU_EPI_PLAIN};
     gF.B16 = w16(net->view.WpT16, 0);
     CHK(nt(c, gF, stream));
-    CHK(wgrad(c, b->dF, ldf, b->H[8], 256, P, 256, 256, net->feat.dWp, 256, c->flat + net->feat.db_off, stream));
-    CHK(skinny_bwd(c, dsig, 1, b->H[8], 256, P, 256, net->alpha.Wp, 256, 1, b->dH8a, 256, 1, net->alpha.dWp, 256, c->flat + net->alpha.db_off, stream));
+    CHK(wgrad(c, b->dF, ldf, b->H[8], 256, P, 256, 256, net->feat.dWp, 256, c->flat + net->feat.db_off, stream, NU_TN_B0_16));
+    CHK(skinny_bwd(c, dsig, 1, b->H[8], 256, P, 256, net->alpha.Wp, 256, 1, b->dH8a, 256, 1, net->alpha.dWp, 256, c->flat + net->alpha.db_off, stream,
+                   true));
     NtArgs g8 = {b->dF, ldf, net->feat.WpT, net->feat.ldT, P, 256, 256, b->dA[8], 256, NU_EPI_B_RELU};
     g8.H = b->H[8]; g8.ldh = 256; g8.Cadd = b->dH8a; g8.ldadd = 256; g8.mask = b->mask[8]; g8.mask_nct = 2;
-    g8.B16 = w16(net->feat.WpT16, 0); g8.st = C16;
+    g8.B16 = w16(net->feat.WpT16, 0); g8.st = C16 | X16;          // H[8] and dH8a are bf16
     CHK(nt(c, g8, stream));
     const float* dA = b->dA[8];
     int lda = 256;
@@ -386,7 +400,7 @@ extern "C" int nu_nerfpp_mlp_bwd(NuOpCtx* c, const NuNerfNet* net, const float* 
 
 // ---------------------------------------------------------------------------------------------------------
 // Shading stack (field.py:684-777): 4 material predictors (batched), the encodings, 4 light predictors, BRDF combine
-// h16: M[0], M[1], dM[0], dM[1] are bf16 (M[2] feeds the skinny head and stays fp32)
+// h16: M[0..2] and dM[0..2] are bf16
 // ---------------------------------------------------------------------------------------------------------
 extern "C" int nu_shade_net_size(void) { return (int)sizeof(NuShadeNet); }
 extern "C" int nu_shade_bufs_size(void) { return (int)sizeof(NuShadeBufs); }
@@ -403,10 +417,10 @@ extern "C" int nu_shading_stack_fwd(NuOpCtx* c, const NuShadeNet* net, NuShadeBu
     for (int j = 1; j <= 2; ++j) {
         NtArgs g = {s->M[j - 1], 1024, net->WpM[j], 256, P, 256, 256, s->M[j], 1024, NU_EPI_BIAS_RELU};
         g.bias = net->bM[j]; g.groups = 4; g.sA = 256; g.sB = 65536; g.sC = 256; g.sBias = 256; g.mask = s->maskM[j]; g.mask_nct = 8;
-        g.B16 = w16(net->WpM16[j], 0); g.st = A16 | (j < 2 ? C16 : 0);
+        g.B16 = w16(net->WpM16[j], 0); g.st = A16 | C16;
         CHK(nt(c, g, stream));
     }
-    CHK(nu_skinny_fwd(s->M[2], 1024, P, 1024, net->Ws6, 1024, net->b6, 6, s->Mraw, 8, stream));
+    CHK(skinny_fwd(c, s->M[2], 1024, P, 1024, net->Ws6, 1024, net->b6, 6, s->Mraw, 8, stream, true));
     CHK(nu_shade_encode_fwd(nrm, pt, 8, E, s->Mraw, 8, P, net->sphere, net->ld_ol, net->refrac_dim, net->ld_rl, s->OLin, s->ILin, s->IWin,
                             s->RLin, s->SD, stream));
     if (R > 0) CHK(nu_spec_encode(s->extra_dirs, s->extra_pts, R, s->extra_pts ? net->sphere : 0, s->OLin + (long long)3 * P * net->ld_ol,
@@ -415,10 +429,10 @@ extern "C" int nu_shading_stack_fwd(NuOpCtx* c, const NuShadeNet* net, NuShadeBu
     CHK(relu_stack_fwd(c, net->inner_light, s->ILin, 128, 2 * P, s->ILh, s->maskIL, 2, stream));
     CHK(relu_stack_fwd(c, net->inner_weight, s->IWin, 96, P, s->IWh, s->maskIW, 2, stream));
     CHK(relu_stack_fwd(c, net->refrac_light, s->RLin, net->ld_rl, P, s->RLh, s->maskRL, 2, stream));
-    CHK(nu_skinny_fwd(s->OLh[2], 256, rows_ol, 256, net->outer_light[3].Wp, 256, net->outer_light[3].bias, 3, s->OLo, 4, stream));
-    CHK(nu_skinny_fwd(s->ILh[2], 256, 2 * P, 256, net->inner_light[3].Wp, 256, net->inner_light[3].bias, 3, s->ILo, 4, stream));
-    CHK(nu_skinny_fwd(s->IWh[2], 256, P, 256, net->inner_weight[3].Wp, 256, net->inner_weight[3].bias, 1, s->IWo, 1, stream));
-    CHK(nu_skinny_fwd(s->RLh[2], 256, P, 256, net->refrac_light[3].Wp, 256, net->refrac_light[3].bias, 3, s->RLo, 4, stream));
+    CHK(skinny_fwd(c, s->OLh[2], 256, rows_ol, 256, net->outer_light[3].Wp, 256, net->outer_light[3].bias, 3, s->OLo, 4, stream, true));
+    CHK(skinny_fwd(c, s->ILh[2], 256, 2 * P, 256, net->inner_light[3].Wp, 256, net->inner_light[3].bias, 3, s->ILo, 4, stream, true));
+    CHK(skinny_fwd(c, s->IWh[2], 256, P, 256, net->inner_weight[3].Wp, 256, net->inner_weight[3].bias, 1, s->IWo, 1, stream, true));
+    CHK(skinny_fwd(c, s->RLh[2], 256, P, 256, net->refrac_light[3].Wp, 256, net->refrac_light[3].bias, 3, s->RLo, 4, stream, true));
     return nu_shade_combine_fwd(s->Mraw, 8, s->OLo, s->ILo, s->IWo, s->RLo, s->SD, net->lut, idx, P, net->exp_max, color_rm, s->aux, stream);
 }
 
@@ -442,15 +456,17 @@ extern "C" int nu_shading_stack_bwd(NuOpCtx* c, const NuShadeNet* net, NuShadeBu
         {net->refrac_light, s->RLh, s->maskRL, s->dRLo, 4, P, 3, s->RLin, net->ld_rl, nullptr, 0, 0, s->dH3[3], s->tmpRL}};
     for (const Pred& p : preds) {
         const NuLin& head = p.ls[3];
-        CHK(skinny_bwd(c, p.dy, p.ldy, p.Hs[2], 256, p.rows, 256, head.Wp, 256, p.no, p.dH3, 256, 1, head.dWp, head.ldd, c->flat + head.db_off, stream));
+        CHK(skinny_bwd(c, p.dy, p.ldy, p.Hs[2], 256, p.rows, 256, head.Wp, 256, p.no, p.dH3, 256, 1, head.dWp, head.ldd, c->flat + head.db_off, stream,
+                       true));
         CHK(relu_stack_bwd(c, p.ls, p.X, p.ldx, p.rows, p.Hs, p.masks, 2, p.dH3, p.tmp, p.dX, p.lddx, p.dxc, stream));
     }
     CHK(nu_shade_encode_bwd(nrm, pt, 8, s->SD, s->dOLin, net->ld_ol, net->sphere, s->dILin, s->dNoV, P, s->dn, s->dMraw, 8, stream));
     // materials backward
-    CHK(skinny_bwd(c, s->dMraw, 8, s->M[2], 1024, P, 1024, net->Ws6, 1024, 6, s->dM[2], 1024, 1, net->dWs6, 1024, c->flat + net->db6_off, stream));
+    CHK(skinny_bwd(c, s->dMraw, 8, s->M[2], 1024, P, 1024, net->Ws6, 1024, 6, s->dM[2], 1024, 1, net->dWs6, 1024, c->flat + net->db6_off, stream,
+                   true));
     const float* dA = s->dM[2];
     for (int j = 2; j >= 1; --j) {
-        const int a16 = j < 2;                     // dM[2] comes from the skinny head (fp32); dM[1], dM[0] are bf16
+        const int a16 = 1;                         // dM[2] (skinny head backward), dM[1], dM[0]: bf16
         CHK(wgrad(c, dA, 1024, s->M[j - 1], 1024, P, 256, 256, net->dWpM[j], 256, c->flat + net->dbM_off[j], stream,
                   (a16 ? NU_TN_A0_16 : 0) | NU_TN_B0_16, nullptr, 0, nullptr, 0, 4, 256, 256, 65536, 256));
         NtArgs g = {dA, 1024, net->WpTM[j], 256, P, 256, 256, s->dM[j - 1], 1024, NU_EPI_MUL_DRELU};

@@ -645,12 +645,13 @@ class Stage1Engine:
         a['U4'] = e(P, 256)
         a['YX'] = e(P, 288) if want_feat else None
         ls = self.sdf
-        eh = self.empty_h               # H[1..3], H[5..7]: bf16 in the bf16-storage mode; U4 (= H[4]) and H[8] fp32
+        eh = self.empty_h               # H[1..3], H[5..7]: bf16 in the bf16-storage mode; U4 (= H[4]) and the kept H[8] fp32
+        h8 = e if want_feat else eh     # without the feature head only the sdf head reads H[8]: bf16 too (NuOpCtx.h16 rule)
         if keep:
-            H = [None] + [eh(P, 256) for _ in range(3)] + [a['U4']] + [eh(P, 256) for _ in range(3)] + [e(P, 256)]
+            H = [None] + [eh(P, 256) for _ in range(3)] + [a['U4']] + [eh(P, 256) for _ in range(3)] + [h8(P, 256)]
         else:
             t0, t1 = eh(P, 256), eh(P, 256)
-            H = [None, t0, t1, t0, a['U4'], t0, t1, t0, e(P, 256) if self.h16 else t1]
+            H = [None, t0, t1, t0, a['U4'], t0, t1, t0, t1 if not want_feat else e(P, 256)]
         a['H'] = H
         if self._use_c():          # one C call sequences the embedding, the eight hidden GEMMs and the output layer
             cb = SdfBufs(P=P, E=addr(a['E']), U4=addr(a['U4']), YX=addr(a['YX']))
@@ -907,8 +908,8 @@ class Stage1Engine:
         ld_ol, ld_rl = self.ld_ol, self.ld_rl
         s = {'P': P, 'R': R, 'rows_ol': rows_ol}
         cb = ShadeBufs(P=P, R=R, extra_dirs=addr(extra_dirs), extra_pts=addr(extra_pts))
-        eh = self.empty_h              # M[0], M[1] and hidden [0], [1] of the light predictors: bf16 in the bf16-storage mode
-        M = [eh(P, 1024), eh(P, 1024), e(P, 1024)]
+        eh = self.empty_h              # the material and light-predictor hidden layers: bf16 in the bf16-storage mode
+        M = [eh(P, 1024), eh(P, 1024), eh(P, 1024)]
         for j in range(3):
             cb.M[j], cb.maskM[j] = addr(M[j]), addr(self.relu_mask(M[j], P, 1024))
         s.update(M1=M[0], M2=M[1], M3=M[2], Mraw=e(P, 8), OLin=e(rows_ol, ld_ol), ILin=e(2 * P, 128), IWin=e(P, 96), RLin=e(P, ld_rl),
@@ -917,7 +918,7 @@ class Stage1Engine:
             setattr(cb, k, addr(s[k]))
         for key, rows, arr, marr in (('OLh', rows_ol, cb.OLh, cb.maskOL), ('ILh', 2 * P, cb.ILh, cb.maskIL),
                                      ('IWh', P, cb.IWh, cb.maskIW), ('RLh', P, cb.RLh, cb.maskRL)):
-            Hs = [eh(rows, 256), eh(rows, 256), e(rows, 256)]
+            Hs = [eh(rows, 256), eh(rows, 256), eh(rows, 256)]
             for j in range(3):
                 arr[j], marr[j] = addr(Hs[j]), addr(self.relu_mask(Hs[j], rows, 256))
             s[key] = Hs
@@ -946,7 +947,7 @@ class Stage1Engine:
             dIWo += d_occ_raw
         keep = []
         for i, rows in enumerate((rows_ol, 2 * P, P, P)):
-            t = e(rows, 256)
+            t = self.empty_h(rows, 256)
             keep.append(t)
             cb.dH3[i] = addr(t)
         for arr, rows in ((cb.tmpOL, rows_ol), (cb.tmpIL, 2 * P), (cb.tmpIW, P), (cb.tmpRL, P)):
@@ -955,7 +956,7 @@ class Stage1Engine:
                 keep.append(t)
                 arr[j] = addr(t)
         dOLin, dILin, dn, dYX = e(rows_ol, self.ld_ol), e(2 * P, 128), e(P, 3), e(P, 288)
-        dM = [self.empty_h(P, 1024), self.empty_h(P, 1024), e(P, 1024)]
+        dM = [self.empty_h(P, 1024), self.empty_h(P, 1024), self.empty_h(P, 1024)]
         cb.dOLin, cb.dILin, cb.dn, cb.dYX = addr(dOLin), addr(dILin), addr(dn), addr(dYX)
         for j in range(3):
             cb.dM[j] = addr(dM[j])
@@ -1029,8 +1030,8 @@ class Stage1Engine:
         b = {'P': P}
         E4, U5, V = e(P, 96), e(P, 352), e(P, 288)
         if self._use_c():
-            # H[1..4], H[6..7]: bf16 in the bf16-storage mode (H[5] = U5 carries the embedding, H[8] feeds the skinny head)
-            H = [E4] + [U5 if i == 4 else (e(P, 256) if i == 7 else self.empty_h(P, 256)) for i in range(8)]
+            # H[1..4], H[6..8]: bf16 in the bf16-storage mode (H[5] = U5 carries the embedding)
+            H = [E4] + [U5 if i == 4 else self.empty_h(P, 256) for i in range(8)]
             cb = NerfBufs(P=P)
             for i in range(9):
                 cb.H[i] = addr(H[i])
@@ -1093,7 +1094,7 @@ class Stage1Engine:
                     if i > 0:
                         cb.mask[i] = addr(getattr(H[i], '_nu_mask', None))
             ldf = 288 if want_in else 256
-            keep = [e(P, 128), e(P, ldf), e(P, 256)]
+            keep = [e(P, 128), e(P, ldf), self.empty_h(P, 256)]
             cb.dHV, cb.dF, cb.dH8a = (addr(t) for t in keep)
             for i in range(1, 9):
                 t = e(P, 352 if want_in else 256) if i == 5 else self.empty_h(P, 256)

@@ -33,7 +33,8 @@ def test_header_declares_the_expected_surface():
                  "nu_shading_stack_bwd", "nu_ctx_flush", "nu_loss_fwd", "nu_loss_bwd", "nu_lbvh_build", "nu_lbvh_trace",
                  "nu_s2_seg_count", "nu_s2_seg_write", "nu_s2_ddist", "nu_s2_seg_bwd", "nu_s2_composite_fwd", "nu_s2_composite_bwd",
                  "nu_s2_refract_fwd", "nu_s2_refract_bwd", "nu_s2_hit_fwd", "nu_s2_hit_bwd", "nu_s2_far_points", "nu_s2_far_resample",
-                 "nu_s2_shade_combine_fwd", "nu_s2_shade_combine_bwd", "nu_s2_neus_alpha_fwd", "nu_s2_neus_alpha_bwd"):
+                 "nu_s2_shade_combine_fwd", "nu_s2_shade_combine_bwd", "nu_s2_neus_alpha_fwd", "nu_s2_neus_alpha_bwd",
+                 "nu_skinny_fwd_h16", "nu_skinny_bwd_enqueue_h16"):
         assert must in names
     assert len(names) >= 50
 

@@ -428,3 +428,39 @@ def test_gemm_throughput_smoke(gpu):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 10
     print(f"\n[gemm_nt 262144x256x256 softplus] {ms:.3f} ms  {2 * M * N * K / ms / 1e9:.1f} TFLOP/s")
+
+
+@pytest.mark.parametrize("P,K,NO", [(1000, 256, 1), (777, 256, 3), (513, 1024, 6), (300, 128, 3)])
+def test_bf16_storage_skinny_heads(gpu, P, K, NO):
+    """The 1..6-wide heads on bf16-stored hidden rows (nu_skinny_fwd_h16 / nu_skinny_bwd_enqueue_h16): fp32 arithmetic on the stored
+    values; dH comes back as bf16 (one rounding)."""
+    from nu_nerf_amd import _lib as L
+    from nu_nerf_amd.engine import ReduceDesc, addr
+    lib = L.load()
+    lib.nu_skinny_bwd_workspace_bytes.restype = ctypes.c_longlong
+    torch.manual_seed(P + K)
+    H = torch.relu(torch.randn(P, K, device=gpu)).bfloat16()
+    W = torch.randn(NO, K, device=gpu) / K ** 0.5
+    b = torch.randn(NO, device=gpu)
+    out = torch.full((P, 8), float("nan"), device=gpu)
+    cp = ctypes.c_void_p
+    L.check(lib.nu_skinny_fwd_h16(cp(addr(H)), K, P, K, cp(addr(W)), K, cp(addr(b)), NO, cp(addr(out)), 8, L.stream()), "nu_skinny_fwd_h16")
+    ref = H.double() @ W.double().t() + b.double()
+    torch.testing.assert_close(out[:, :NO].double(), ref, rtol=2e-5, atol=2e-5)
+    dy = torch.randn(P, 8, device=gpu)
+    dH = torch.full((P, K), float("nan"), device=gpu, dtype=torch.bfloat16)
+    dW = torch.zeros(NO, K, device=gpu)
+    db = torch.zeros(NO, device=gpu)
+    wsb = lib.nu_skinny_bwd_workspace_bytes(K, NO)
+    ws = torch.empty(wsb // 4, device=gpu)
+    descs = (ReduceDesc * 4)()
+    nd = ctypes.c_int(0)
+    L.check(lib.nu_skinny_bwd_enqueue_h16(cp(addr(dy)), 8, cp(addr(H)), K, P, K, cp(addr(W)), K, NO, cp(addr(dH)), K, 1, 0, cp(addr(dW)), K,
+                                          cp(addr(db)), cp(addr(ws)), ctypes.c_longlong(wsb), descs, ctypes.byref(nd), 4, L.stream()),
+            "nu_skinny_bwd_enqueue_h16")
+    L.check(lib.nu_slab_reduce_batched(descs, nd.value, L.stream()), "nu_slab_reduce_batched")
+    g = dy[:, :NO].double()
+    want_dH = (g @ W.double()) * (H.double() > 0)
+    torch.testing.assert_close(dH.double(), want_dH, rtol=8e-3, atol=1e-6)
+    torch.testing.assert_close(dW.double(), g.t() @ H.double(), rtol=2e-5, atol=2e-4)
+    torch.testing.assert_close(db.double(), g.sum(0), rtol=2e-5, atol=2e-4)
