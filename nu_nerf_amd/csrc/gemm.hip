@@ -1959,25 +1959,38 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(NuGemmTN g) {
 
 // The split both launch paths use: enough workgroups for the chip, as few and as large slabs as possible.  The 256-wide kernel
 // takes the shapes whose N1 and N2 are multiples of 256 in exact fp32 (one workgroup per CU: 256 of them).
+// Does a weight-gradient launch with this split take the 256 x 256-tile kernels?  Only when that grid fills the chip: with few
+// reduced rows (small batches: P / 256 splits at most) the 128-tile kernels put four times as many workgroups on the CUs.
+static bool nu_tn_big_tile(int N1, int N2, int groups, int prec, int S) {
+    static const bool tn128_env = getenv("NU_TN_128") && atoi(getenv("NU_TN_128")) != 0;      // development switch: 128 x 128 tiles only
+    if ((prec & 3) == 2 || tn128_env || (N1 % 256) != 0 || (N2 % 256) != 0) return false;
+    return (long long)(N1 / 256) * (N2 / 256) * (groups > 0 ? groups : 1) * S >= 192;
+}
+// The split both launch paths use: enough workgroups for the chip, as few and as large slabs as possible.
 extern "C" int nu_wgrad_pick_split(int P, int N1, int N2, int groups, int prec) {
     if (groups < 1) groups = 1;
-    static const bool tn128_env = getenv("NU_TN_128") && atoi(getenv("NU_TN_128")) != 0;      // development switch (see the launcher)
-    const bool big_tile = (prec & 3) != 2 && !tn128_env && (N1 % 256) == 0 && (N2 % 256) == 0;
-    const int tiles = big_tile ? (N1 / 256) * (N2 / 256) * groups : nu_cdiv(N1, 128) * nu_cdiv(N2, 128) * groups;
-    int S = (big_tile ? 256 : 512) / tiles;
+    const int cap = (P + 255) / 256 > 0 ? (P + 255) / 256 : 1;
+    if ((N1 % 256) == 0 && (N2 % 256) == 0) {
+        int S = 256 / ((N1 / 256) * (N2 / 256) * groups);
+        if (S < 1) S = 1;
+        if (S > cap) S = cap;
+        if (nu_tn_big_tile(N1, N2, groups, prec, S)) return S;
+    }
+    int S = 512 / (nu_cdiv(N1, 128) * nu_cdiv(N2, 128) * groups);
     if (S < 1) S = 1;
-    const int cap = (P + 255) / 256;
     if (S > cap) S = cap;
-    return S < 1 ? 1 : S;
+    // (a 128-tile split must not look like a 256-tile one to the launcher: it never does, S x tiles256 stays below 192 here
+    // exactly when the 256-tile grid was too small above; with cap large the 256-tile branch has already returned)
+    return S;
 }
 
 int nu_gemm_tn_launch(const NuGemmTN& g, hipStream_t stream) {
     if (g.N1 <= 0 || g.N2 <= 0 || g.S <= 0) return NU_ERR_ARG;
     if ((g.lda0 & 3) || (g.ldb0 & 3) || (g.A1 && ((g.lda1 & 3) || (g.ldb1 & 3)))) return NU_ERR_ARG;
-    static const bool tn128_env = getenv("NU_TN_128") && atoi(getenv("NU_TN_128")) != 0;      // development switch: 128 x 128 tiles only
     const int prec = g.bf16 & 3;
     if (prec == 3 || ((g.bf16 & ~3) && prec != 1)) return NU_ERR_ARG;
-    if ((g.bf16 & 3) == 0 && !tn128_env && (g.N1 % 256) == 0 && (g.N2 % 256) == 0) {
+    const bool big_tile = nu_tn_big_tile(g.N1, g.N2, g.groups, g.bf16, g.S);
+    if ((g.bf16 & 3) == 0 && big_tile) {
         dim3 grid2((g.N1 / 256) * (g.N2 / 256), g.S, g.groups > 0 ? g.groups : 1);
         const long long mld = (g.lda0 > g.ldb0 ? g.lda0 : g.ldb0) > (g.A1 ? (g.lda1 > g.ldb1 ? g.lda1 : g.ldb1) : 0)
                                   ? (g.lda0 > g.ldb0 ? g.lda0 : g.ldb0) : (g.lda1 > g.ldb1 ? g.lda1 : g.ldb1);
@@ -1997,7 +2010,7 @@ int nu_gemm_tn_launch(const NuGemmTN& g, hipStream_t stream) {
                          ((g.sA0 | g.sB0 | g.sA1 | g.sB1) & 7) == 0;
         static const bool tn_scalar_env = getenv("NU_TN_SCALAR") && atoi(getenv("NU_TN_SCALAR")) != 0;      // development switch
         if (vec && !tn_scalar_env) {
-            if (!tn128_env && (g.N1 % 256) == 0 && (g.N2 % 256) == 0) {
+            if (big_tile) {
                 dim3 grid2((g.N1 / 256) * (g.N2 / 256), g.S, g.groups > 0 ? g.groups : 1);
                 hipLaunchKernelGGL(gemm_tn16x256_kernel, grid2, dim3(512), 0, stream, g);
             } else {

@@ -86,7 +86,8 @@ def test_nt_derivative_epilogues(gpu):
     torch.testing.assert_close(C.double(), 0.5 * v * sp + Cadd.double(), rtol=2e-5, atol=2e-5)
 
 
-@pytest.mark.parametrize("P,N1,N2,S", [(1, 1, 1, 1), (1000, 257, 256, 7), (5000, 256, 39, 16), (333, 3, 256, 4)])
+@pytest.mark.parametrize("P,N1,N2,S", [(1, 1, 1, 1), (1000, 257, 256, 7), (5000, 256, 39, 16), (333, 3, 256, 4), (4000, 256, 256, 8),
+                                      (60001, 256, 256, 200), (50000, 256, 512, 100)])          # the last two: 256 x 256-tile kernel
 def test_tn_weight_grad(gpu, P, N1, N2, S):
     from nu_nerf_amd import _lib as L
     lib = L.load()
@@ -333,7 +334,8 @@ def test_bf16_storage_nt_grouped_and_sign_bits(gpu):
 
 
 @pytest.mark.parametrize("P,N1,N2,S,flags", [(1000, 257, 256, 7, 16 | 32 | 64 | 128), (5000, 256, 96, 16, 16 | 128), (333, 3, 256, 4, 32 | 64),
-                                             (3001, 256, 256, 5, 16 | 32 | 64 | 128), (2000, 512, 256, 3, 32 | 64), (777, 256, 512, 2, 0)])
+                                             (3001, 256, 256, 5, 16 | 32 | 64 | 128), (2000, 512, 256, 3, 32 | 64), (777, 256, 512, 2, 0),
+                                             (60001, 256, 256, 200, 16 | 32 | 64 | 128), (50000, 512, 256, 100, 32 | 64)])   # 256-tile kernel
 def test_bf16_storage_tn_weight_grad(gpu, P, N1, N2, S, flags):
     from nu_nerf_amd import _lib as L
     from nu_nerf_amd.engine import GemmTN, addr
