@@ -240,6 +240,21 @@ class Stage1Engine:
     def stream(self):
         return c_p(torch.cuda.current_stream(self.dev).cuda_stream)
 
+    # Small batches leave the chip half empty (a 256 -> 256 layer on 8 192 points is 128 tiles for 256 CUs): the NeRF++ chain of the
+    # outer points and the SDF / shading chain of the inner points are independent between the partition and the composite, so
+    # below `_TWO_STREAM_SAMPLES` ray samples the NeRF++ chain runs on a second HIP stream.  Both chains push their split reductions
+    # to the shared arena from this (single) host thread; the batched reduction runs after the join.
+    _TWO_STREAM_SAMPLES = int(os.environ.get('NU_TWO_STREAM_SAMPLES', 200000))
+
+    def _fork(self):
+        if getattr(self, '_side', None) is None:
+            self._side = torch.cuda.Stream(self.dev)
+        self._side.wait_stream(torch.cuda.current_stream(self.dev))
+        return self._side
+
+    def _join(self):
+        torch.cuda.current_stream(self.dev).wait_stream(self._side)
+
     def relu_mask(self, act, rows, ncols):
         """Sign-bit buffer for a [rows, ncols] ReLU activation (2 KB per 128x128 tile): written by the BIAS_RELU GEMM that
         produces `act`, read by the backward GEMMs instead of `act` itself.  Rides on the activation tensor so that it lives
@@ -1228,7 +1243,12 @@ class Stage1Engine:
         alpha_rm, color_rm = e(R * S), e(R * S, 4)
         ctx = dict(R=R, S=S, P_in=P_in, P_out=P_out, P_in_dev=tot[:1], pt_in=pt_in, idx_in=idx_in, pt_out=pt_out, idx_out=idx_out,
                    inner_rm=inner_rm, alpha_rm=alpha_rm, color_rm=color_rm, anneal=float(anneal))
-        if P_out > 0:
+        two = P_out > 0 and P_in > 0 and R * S <= self._TWO_STREAM_SAMPLES
+        ctx['two_streams'] = two
+        if two:
+            with torch.cuda.stream(self._fork()):
+                ctx['nerf'] = self.nerf_forward(pt_out, idx_out, P_out, alpha_rm, color_rm)
+        elif P_out > 0:
             ctx['nerf'] = self.nerf_forward(pt_out, idx_out, P_out, alpha_rm, color_rm)
         out = {}
         # unit ray directions for the per-ray mirror query (dirs[:,0,:] in the reference)
@@ -1249,6 +1269,8 @@ class Stage1Engine:
             out['sdf_in'] = a['YX'][:, 0]
             out['aux'] = s['aux']
             out['normal_raw'] = a['n']
+        if two:
+            self._join()
         weights = e(R, S) if want_weights else None
         rgb, acc, rgb_bg, nrm_sum = e(R, 3), e(R), e(R, 3), e(R)
         L.check(lib.nu_composite_fwd(c_p(addr(alpha_rm)), c_p(addr(color_rm)), c_p(addr(inner_rm)), R, S,
@@ -1274,7 +1296,11 @@ class Stage1Engine:
         L.check(lib.nu_composite_bwd(c_p(addr(ctx['alpha_rm'])), c_p(addr(ctx['color_rm'])), c_p(addr(ctx['inner_rm'])),
                                      R, S, c_p(addr(d_rgb)), c_p(addr(d_acc)), c_p(addr(d_rgb_bg)), c_p(addr(d_nrm_sum)),
                                      c_p(addr(dalpha_rm)), c_p(addr(dcolor_rm)), S_), "nu_composite_bwd")
-        if P_out > 0:
+        two = ctx.get('two_streams', False)
+        if two:
+            with torch.cuda.stream(self._fork()):
+                self.nerf_backward(ctx['nerf'], ctx['pt_out'], ctx['idx_out'], dalpha_rm, dcolor_rm, flat)
+        elif P_out > 0:
             self.nerf_backward(ctx['nerf'], ctx['pt_out'], ctx['idx_out'], dalpha_rm, dcolor_rm, flat)
         else:
             self.zero_stale_wgrads(self.nerf + [self.nerf_feat, self.nerf_alpha, self.nerf_view, self.nerf_rgb])
@@ -1296,6 +1322,8 @@ class Stage1Engine:
             if d_sdf_in is not None:
                 dYX[:, 0] += d_sdf_in
             self.sdf_backward(a, dYX, nbar, flat)
+        if two:
+            self._join()
         self.unpack_grads(flat)
         return flat
 
