@@ -233,6 +233,13 @@ extern "C" int nu_neus_alpha_fwd(const float* YX, int ldy, const float* nrm, con
 
 // backward: dalpha_rm (ray-major), dgerr[p] (per-point cotangent of gradient_error), dn_shade (may be null)
 //   -> dYX[p, 0] = d sdf ;  nbar[p, 0:3] = total cotangent of the raw normal ;  dvar += d variance
+// The variance gradient is a sum over all points: every block leaves its partial in a device array and the block that finishes
+// LAST adds them up in index order -- no float atomics, so the gradient does not depend on the order the blocks happened to run in
+// (it used to: one atomicAdd per block made d variance differ by an ulp from run to run).  One launch at a time per process
+// (the launcher is only ever called on the engine's main stream).
+#define NU_DVAR_MAX_BLOCKS 65536
+__device__ float nu_dvar_partial[NU_DVAR_MAX_BLOCKS];
+__device__ unsigned nu_dvar_done;
 __global__ __launch_bounds__(256) void neus_alpha_bwd_kernel(const float* __restrict__ YX, int ldy,
                                                              const float* __restrict__ nrm, const float* __restrict__ pt,
                                                              const int* __restrict__ idx, int P,
@@ -272,10 +279,29 @@ __global__ __launch_bounds__(256) void neus_alpha_bwd_kernel(const float* __rest
         dinv = nu_wave_sum(dinv);
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dinv;
         __syncthreads();
+        __shared__ bool last;
         if (threadIdx.x == 0) {
-            const float s = red[0] + red[1] + red[2] + red[3];
-            const bool pass = raw >= 1e-6f && raw <= 1e6f;
-            if (pass && s != 0.f) atomicAdd(dvar, s * raw * 10.0f);
+            nu_dvar_partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+            __threadfence();
+            last = atomicAdd(&nu_dvar_done, 1u) == gridDim.x - 1;
+        }
+        __syncthreads();
+        if (last) {                                  // whole block: strided partial sums, then a fixed tree
+            __threadfence();
+            float s = 0.f;
+            for (unsigned i = threadIdx.x; i < gridDim.x; i += 256) s += __builtin_nontemporal_load(&nu_dvar_partial[i]);
+            __shared__ float tree[256];
+            tree[threadIdx.x] = s;
+            __syncthreads();
+            for (int o = 128; o > 0; o >>= 1) {
+                if ((int)threadIdx.x < o) tree[threadIdx.x] += tree[threadIdx.x + o];
+                __syncthreads();
+            }
+            if (threadIdx.x == 0) {
+                const bool pass = raw >= 1e-6f && raw <= 1e6f;
+                if (pass && tree[0] != 0.f) *dvar += tree[0] * raw * 10.0f;
+                nu_dvar_done = 0;
+            }
         }
     }
 }
@@ -284,6 +310,7 @@ extern "C" int nu_neus_alpha_bwd(const float* YX, int ldy, const float* nrm, con
                                  const float* dn_shade, const float* dcolor_rm, float* dYX, int lddy, float* nbar,
                                  float* dvar, hipStream_t stream) {
     if (P <= 0) return NU_OK;
+    if (dvar && nu_cdiv(P, 256) > NU_DVAR_MAX_BLOCKS) return NU_ERR_ARG;
     hipLaunchKernelGGL(neus_alpha_bwd_kernel, dim3(nu_cdiv(P, 256)), dim3(256), 0, stream, YX, ldy, nrm, pt, idx, P,
                        variance, anneal, dalpha_rm, dgerr, dn_shade, dcolor_rm, dYX, lddy, nbar, dvar);
     return nu_launch_status();

@@ -253,3 +253,38 @@ def test_network_level_c_entries_equal_launch_by_launch_sequencing(gpu):
     assert set(res[0][2]) == set(res[1][2])
     for n in res[0][2]:
         assert torch.equal(res[0][2][n], res[1][2][n]), n
+
+
+@pytest.mark.parametrize("mlp_dtype", ["fp32", "bf16"])
+def test_gradients_are_bitwise_reproducible(gpu, mlp_dtype):
+    """No float atomics anywhere on the path: two evaluations of one step give bit-identical outputs and gradients for every
+    parameter, incl. d variance (a sum over all inner points: per-block partials added in index order by the block that finishes
+    last -- it used to be one atomicAdd per block, an ulp of run-to-run noise that 60 optimizer steps amplified to 1e-5 in the loss).
+    Large enough that the variance sum spans hundreds of blocks."""
+    from nu_nerf_amd.renderer import NeROShapeRenderer
+    from nu_nerf_amd.params import init_stage1_params
+    from nu_nerf_amd.synthetic import make_object_rays
+    from nu_nerf_amd.loss import name2loss, SPHEREPOT_LOSSES, fused_stage1_loss
+    cfg = {'name': 'det', 'network': 'shape', 'database_name': 'synthetic/64', 'is_nerf': True, 'apply_occ_loss': True,
+           'occ_loss_step': 15000, 'freeze_inv_s_step': 15000, 'eikonal_weight': 0.1, 'outer_reg_loss_weight': 0.1,
+           'n_samples': 64, 'n_importance': 64, 'n_bg_samples': 32, 'mlp_dtype': mlp_dtype}
+    net = NeROShapeRenderer(cfg, training=False)
+    net.load_param_dict(init_stage1_params(6033))
+    net = net.to(gpu)
+    losses = [name2loss[n](cfg) for n in SPHEREPOT_LOSSES]
+    rays = make_object_rays(2048, seed=901, aim_radius=0.9)
+    batch = {k: torch.from_numpy(v).to(gpu) for k, v in rays.items()}
+    runs = []
+    for _ in range(3):
+        net.zero_grad(set_to_none=True)
+        torch.manual_seed(5)                                   # the occlusion subsample and the jitter draw from torch's generator
+        total, log, out = fused_stage1_loss(net, batch, 20000, losses)
+        total.backward()
+        runs.append((out['ray_rgb'].detach().clone(), {n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None}))
+    assert net.engine().last_ctx['P_in'] > 256 * 200
+    assert 'deviation_network.variance' in runs[0][1]
+    for rgb, grads in runs[1:]:
+        assert torch.equal(rgb, runs[0][0])
+        assert set(grads) == set(runs[0][1])
+        for n, g in grads.items():
+            assert torch.equal(g, runs[0][1][n]), n
