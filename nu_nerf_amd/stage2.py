@@ -320,7 +320,11 @@ class Stage2Renderer(nn.Module):
                     r_i, s_i = where[:, 0], where[:, 1]
                     seglen = torch.linalg.norm(nodes[:, 1:] - nodes[:, :-1], dim=-1)
                     seglen = torch.cat([seglen, seglen[..., -1:]], -1)
-                    x_in, d_in, len_in = nodes[r_i, s_i], sg['dirs'].index_select(0, r_i), seglen[r_i, s_i]
+                    # (directions through an expanded view, not index_select(0, r_i): its backward would add the many samples of
+                    # a ray with float atomics; this way the per-sample cotangents land at unique (ray, sample) slots and the sum
+                    # over a ray's samples is an ordinary reduction -- bitwise reproducible)
+                    d_in = sg['dirs'][:, None, :].expand(N, nodes.shape[1], 3)[r_i, s_i]
+                    x_in, len_in = nodes[r_i, s_i], seglen[r_i, s_i]
                     y, grads = n2.sdf(x_in)
                     s = torch.exp(self.deviation_network_inner.variance * 10.0).clip(1e-6, 1e6)
                     if self.cfg['freeze_inv_s_step'] is not None and step < self.cfg['freeze_inv_s_step']:
