@@ -77,6 +77,27 @@ def dintersect(origin, direction, triangles, normals):
     return u, v, t, n / n.norm(dim=1, keepdim=True)
 
 
+def vertex_normals_and_curvature(Vc, Fc):
+    """Angle-weighted unit vertex normals [V,3] (DiffRender.py:343-358) and per-vertex Gaussian curvature [V,1], on the host.
+
+    Per-vertex quantities are sums over the incident faces; they are accumulated on the CPU in face order (index_add_ on the device
+    adds with float atomics: the vertex normals -- and every refracted direction after them -- would differ by an ulp from run to
+    run); a mesh is preprocessed once.  Curvature: DiffRender.py:331,360 takes PyMesh's "vertex_gaussian_curvature" and clips it to
+    [-10, 10]; here angle defect 2 pi - sum of the corner angles at the vertex, over the vertex area (a third of the incident
+    faces' area).  PyMesh is absent: pinned analytically (sphere: 1 / r^2), not against PyMesh output."""
+    Vc, Fc = Vc.detach().to(torch.float32).cpu(), Fc.detach().to(torch.long).cpu()
+    tri = Vc[Fc]
+    ang, fn = corner_angles_and_face_normals(tri)
+    vn = torch.zeros_like(Vc)
+    vn.index_add_(0, Fc.reshape(-1), (ang[:, :, None] * fn[:, None, :]).reshape(-1, 3))
+    normals = vn / vn.norm(dim=1, keepdim=True)
+    area = 0.5 * torch.linalg.norm(torch.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0], dim=1), dim=1)
+    ang_sum = torch.zeros(len(Vc), dtype=ang.dtype).index_add_(0, Fc.reshape(-1), ang.reshape(-1))
+    v_area = torch.zeros_like(ang_sum).index_add_(0, Fc.reshape(-1), (area / 3.0)[:, None].expand(-1, 3).reshape(-1))
+    curv = torch.clamp((2.0 * math.pi - ang_sum) / v_area.clamp_min(1e-20), -10.0, 10.0)[:, None]
+    return normals, curv
+
+
 class Scene:
     """Triangle mesh + LBVH with the reference Scene's tracing surface (DiffRender.py:318-360, :539-549)."""
 
@@ -84,23 +105,9 @@ class Scene:
         self.vertices = vertices.detach().to(torch.float32).contiguous()
         self.faces = faces.detach().to(torch.long).contiguous()
         self.bvh = LBVH(self.vertices, self.faces)
-        # Per-vertex quantities are sums over the incident faces.  They are accumulated on the host in face order (index_add_ on the
-        # device adds with float atomics: the vertex normals -- and every refracted direction after them -- would differ by an ulp
-        # from run to run); a mesh is preprocessed once.
         dev = self.vertices.device
-        Vc, Fc = self.vertices.cpu(), self.faces.cpu()
-        tri = Vc[Fc]
-        ang, fn = corner_angles_and_face_normals(tri)
-        vn = torch.zeros_like(Vc)
-        vn.index_add_(0, Fc.reshape(-1), (ang[:, :, None] * fn[:, None, :]).reshape(-1, 3))
-        self.normals = (vn / vn.norm(dim=1, keepdim=True)).to(dev)
-        # Per-vertex Gaussian curvature (DiffRender.py:331,360 takes PyMesh's "vertex_gaussian_curvature" and clips it to
-        # [-10, 10]): angle defect 2 pi - sum of the corner angles at the vertex, over the vertex area (a third of the incident
-        # faces' area).  PyMesh is absent here: pinned analytically (sphere: 1 / r^2), not against PyMesh output.
-        area = 0.5 * torch.linalg.norm(torch.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0], dim=1), dim=1)
-        ang_sum = torch.zeros(len(Vc), dtype=ang.dtype).index_add_(0, Fc.reshape(-1), ang.reshape(-1))
-        v_area = torch.zeros_like(ang_sum).index_add_(0, Fc.reshape(-1), (area / 3.0)[:, None].expand(-1, 3).reshape(-1))
-        self.gaussian_curvatures = torch.clamp((2.0 * math.pi - ang_sum) / v_area.clamp_min(1e-20), -10.0, 10.0)[:, None].to(dev)
+        normals, curv = vertex_normals_and_curvature(self.vertices.cpu(), self.faces.cpu())
+        self.normals, self.gaussian_curvatures = normals.to(dev), curv.to(dev)
 
     def intersect(self, origin, direction):
         hit, idx = self.bvh.intersect(torch.cat([origin, direction], 1))

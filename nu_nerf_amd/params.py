@@ -189,3 +189,27 @@ def init_stage2_params(seed=6033, inner_seed=7044, shader_cfg=None):
         if k.startswith('color_network.'):
             p['color_network_inner.' + k[len('color_network.'):]] = v
     return p
+
+
+def params_from_manifest(manifest, seed):
+    """Seed-reproducible values for a list of (name, shape) state-dict entries, by name pattern only (no module semantics):
+    weight-norm directions and plain weights ~ N(0, 1/fan_in), weight_g ~ 1 +- 5 %, biases ~ N(0, 0.05), anything 0-d or 1-d
+    without a known suffix ~ N(0, 0.1).  Parity fixtures of models whose initialisers are not restated here carry the manifest and
+    the seed (oracle/gen_golden_stage2_thick.py); the values have no training meaning."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    out = OrderedDict()
+    for name, shape in manifest:
+        shape = tuple(int(x) for x in shape)
+        if name.endswith('FG_LUT'):
+            raise ValueError("the FG LUT is an asset, not a parameter to generate")
+        if name.endswith(('weight_v', 'weight')) and len(shape) == 2:
+            v = rng.standard_normal(shape) / np.sqrt(max(shape[1], 1))
+        elif name.endswith('weight_g'):
+            v = 1.0 + 0.05 * rng.standard_normal(shape)
+        elif name.endswith('bias'):
+            v = 0.05 * rng.standard_normal(shape)
+        else:
+            v = 0.1 * rng.standard_normal(shape)
+        out[name] = v.astype(np.float32)
+    return out
+

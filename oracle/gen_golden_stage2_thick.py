@@ -1,6 +1,12 @@
 """Golden vectors for the NON-zero-thickness stage-2 model (network/renderer.py: Stage2Renderer), from the
-reference's own class under the shims of oracle/gen_golden.py (build container only).  Work in progress: this script first
-probes that the class constructs and steps under the shims."""
+reference's own class under the shims of oracle/gen_golden.py (build container only).
+
+The OptiX / PyMesh-backed `Scene` is replaced by a brute-force scene with the same `Dintersect` contract; PyMesh's
+"vertex_gaussian_curvature" (absent here) by the angle-defect estimate of nu_nerf_amd/lbvh.py -- that input is therefore NOT pinned
+by the reference, everything computed from it is.  Parameters: the stage-1 part from nu_nerf_amd/params.py, every other state-dict
+entry from `nu_nerf_amd.params.params_from_manifest` (names + shapes + seed -> values), so the fixture carries the manifest and
+the product can rebuild the same weights.  Output: tests/golden/stage2_thick_step6000_r24.npz (inputs, per-ray outputs, TIR mask,
+segment geometry, loss terms, gradient norms of every trained parameter).  The product side of this model is not built yet."""
 import os
 import sys
 import tempfile
@@ -75,17 +81,75 @@ def main():
         tops[k.split('.')[0]] = tops.get(k.split('.')[0], 0) + 1
     print(tops)
     from nu_nerf_amd.synthetic import make_object_rays
+    from nu_nerf_amd.params import params_from_manifest
+    from network.loss import name2loss
+    # ---- parameters: stage 1 from its own generator (both aliases), everything else from the manifest rule ----
+    sd = net.state_dict()
+    own = [k for k in keys if not k.startswith(('stage1_network.', 'color_network.stage1_network.', 'infinity_far_bkgr.'))
+           and not k.endswith('FG_LUT')]                         # the LUT is an asset both sides load from the same file
+    manifest = [(k, tuple(sd[k].shape)) for k in own]
+    p2 = params_from_manifest(manifest, seed=7044)
+    for k, v in s1.items():
+        p2['stage1_network.' + k] = v
+        p2['color_network.stage1_network.' + k] = v
+        if k.startswith('infinity_far_bkgr.'):
+            p2[k] = v
+    for k in keys:
+        if k.endswith('FG_LUT') and k not in p2:
+            p2[k] = sd[k].numpy()
+    missing = [k for k in keys if k not in p2]
+    print("own entries", len(own), "missing", missing[:5])
+    print("load:", net.load_state_dict(to_t({k: p2[k] for k in keys}), strict=True))
+    losses = [name2loss[n](cfg) for n in cfg['loss']]
     R, step = 24, 6000
     rays = make_object_rays(R, seed=500)
     o, d, rgbs = (torch.from_numpy(rays[k]) for k in ('rays_o', 'rays_d', 'rgbs'))
     dn = torch.nn.functional.normalize(d, dim=-1)
     mask = torch.ones(R, 1)
-    res = net.ray_trace(o, dn, mask)
-    pathes, converges = res[0], res[1]
+    net.zero_grad()
+    pathes, converges, directions, ior_ratios, infinity_bkgr, gradient_mesh, tir_mask = net.ray_trace(o, dn, mask)
     print("segments", len(pathes), "converged per bounce", [int(c.sum()) for c in converges], "rays per segment",
-          [int(p.shape[0]) for p in pathes], "samples", [int(p.shape[1]) for p in pathes])
-    out = net.render(o, dn, mask, None, None, None, -1, net.get_anneal_val(step), is_train=True, step=step, is_nerf=False)
-    print({k: (tuple(v.shape) if hasattr(v, 'shape') else v) for k, v in out.items()})
+          [int(p.shape[0]) for p in pathes], "samples", [int(p.shape[1]) for p in pathes], "tir", int(tir_mask.sum()))
+    net.zero_grad()
+    outputs = net.render(o, dn, mask, None, None, None, -1, net.get_anneal_val(step), is_train=True, step=step, is_nerf=False)
+    outputs['loss_rgb'] = net.compute_rgb_loss(outputs['ray_rgb'] * outputs['tir_mask'].detach() * mask,
+                                               rgbs * outputs['tir_mask'].detach() * mask)
+    log = {}
+    for ls in losses:
+        log.update(ls(outputs, {}, step))
+    total = 0
+    for k, v in log.items():
+        if k.startswith('loss'):
+            total = total + torch.mean(v)
+    total.backward()
+    res = {'rays_o': rays['rays_o'], 'rays_d': rays['rays_d'], 'rgbs': rays['rgbs'], 'step': np.asarray(step),
+           'manifest_names': np.asarray([k for k, _ in manifest]),
+           'manifest_shapes': np.asarray([','.join(str(x) for x in shp) for _, shp in manifest]),
+           'manifest_seed': np.asarray(7044), 'state_dict_keys': np.asarray(keys),
+           'vertex_gaussian_curvature': net.scene.gaussian_curvatures.numpy(),
+           'total_loss': total.detach().numpy(), 'out_ray_rgb': outputs['ray_rgb'].detach().numpy(),
+           'out_tir_mask': outputs['tir_mask'].numpy(), 'out_gradient_error': outputs['gradient_error'].detach().numpy(),
+           'out_std': outputs['std'].detach().numpy(), 'out_normal': outputs['normal'].detach().numpy(),
+           'out_specular_color': outputs['specular_color'].detach().numpy()}
+    for i in range(len(pathes)):
+        res['path%d' % i] = pathes[i].detach().numpy()
+        res['conv%d' % i] = converges[i].numpy()
+        res['dir%d' % i] = directions[i].detach().numpy()
+    for i, r in enumerate(ior_ratios):
+        res['ior%d' % i] = r.detach().numpy()
+    for i, gm in enumerate(gradient_mesh):
+        res['normal_mesh%d' % i] = gm.detach().numpy()
+    for k, v in log.items():
+        if k.startswith('loss'):
+            res['term_' + k] = torch.mean(v).detach().numpy()
+    gn = {n: p.grad for n, p in net.named_parameters() if p.grad is not None}
+    res['grad_names'] = np.asarray(sorted(gn.keys()))
+    res['grad_norms'] = np.asarray([float(gn[k].double().norm()) for k in sorted(gn.keys())])
+    os.makedirs(OUT, exist_ok=True)
+    np.savez_compressed(os.path.join(OUT, "stage2_thick_step6000_r24.npz"), **res)
+    print("loss", float(total), {k: float(v) for k, v in res.items() if k.startswith('term_')}, "n grads", len(gn),
+          "rgb range", float(outputs['ray_rgb'].min()), float(outputs['ray_rgb'].max()))
+    print("params without grad:", sorted(set(n.split('.')[0] for n, p in net.named_parameters() if p.grad is None)))
 
 
 if __name__ == "__main__":

@@ -297,3 +297,33 @@ def test_stage2_parameter_hub_hands_each_parameter_its_slice_once_cpu_side():
     assert torch.equal(params['b.w'].grad, torch.full((4,), 100.0))
     assert params['c.w'].grad is None                          # no op touched it
     assert torch.equal(x.grad, torch.full((3,), 6.0))
+
+
+def test_stage2_thick_fixture_is_reproducible_from_its_manifest():
+    """Groundwork for SURVEY 8(f) N3 (the non-zero-thickness stage-2 model, not built yet): the reference-generated fixture
+    tests/golden/stage2_thick_step6000_r24.npz (oracle/gen_golden_stage2_thick.py) carries a parameter manifest + seed instead of
+    13 MB of weights, and the per-vertex Gaussian curvature its run used -- PyMesh's attribute in the reference, the angle-defect
+    estimate here.  Pin both: the generator reproduces the same values, the product's curvature equals the fixture's."""
+    import hashlib
+    from helpers import golden
+    from nu_nerf_amd.params import params_from_manifest
+    from nu_nerf_amd.lbvh import icosphere, vertex_normals_and_curvature
+    g = golden("stage2_thick_step6000_r24.npz")
+    names = [str(n) for n in g['manifest_names']]
+    shapes = [tuple(int(x) for x in str(s).split(',') if x) for s in g['manifest_shapes']]
+    assert len(names) == 197 and len(set(names)) == 197
+    assert {n.split('.')[0] for n in names} == {'IORs', 'nerf_network', 'IORs_pred', 'IoRint_pred', 'thickness_pred', 'sdf_network_inner',
+                                                'deviation_network_inner', 'color_network_inner'}
+    p = params_from_manifest(list(zip(names, shapes)), int(g['manifest_seed']))
+    q = params_from_manifest(list(zip(names, shapes)), int(g['manifest_seed']))
+    h = hashlib.sha256()
+    for n in names:
+        assert p[n].shape == shapes[names.index(n)] and p[n].dtype == np.float32 and np.array_equal(p[n], q[n])
+        h.update(p[n].tobytes())
+    assert sum(v.size for v in p.values()) > 2_000_000
+    V, Fc = icosphere(3, 0.5)
+    _, curv = vertex_normals_and_curvature(torch.from_numpy(V), torch.from_numpy(Fc.astype(np.int64)))
+    np.testing.assert_allclose(curv.numpy(), g['vertex_gaussian_curvature'], rtol=1e-6, atol=0)
+    # what the reference run produced with those inputs (the numbers the product will have to match)
+    assert g['out_ray_rgb'].shape == (24, 3) and int(g['out_tir_mask'].sum()) == 23 and len(g['grad_names']) == 295
+    assert [g['path%d' % i].shape[:2] for i in range(3)] == [(24, 64), (15, 128), (15, 64)]
