@@ -282,7 +282,10 @@ class Stage1Engine:
     def _ensure_arena(self, n=0):
         if self._arena is None or n > self._arena.numel():
             self._arena = None
-            self._arena = torch.empty(max(n, 1 << 29), dtype=torch.float32, device=self.dev)   # >= 2 GiB: one step's slabs
+            # >= 4 GiB: the split-reduction slabs of one step come to 1.5-2 GB at every batch size (the split count is capped, not
+            # the point count), so the arena never fills inside a step and the one batched reduction runs after the last producer
+            # -- which is also what makes the two-stream mode safe (an early flush would reduce slabs the other stream still writes)
+            self._arena = torch.empty(max(n, 1 << 30), dtype=torch.float32, device=self.dev)
             self._ctx.arena, self._ctx.arena_floats = self._arena.data_ptr(), self._arena.numel()
 
     def flush_reductions(self):
