@@ -13,7 +13,7 @@ from nu_nerf_amd.loss import name2loss, SPHEREPOT_LOSSES, total_loss
 from nu_nerf_amd.train_glue import FusedAdam
 
 dev = torch.device('cuda:0')
-R = 4096
+R = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 cfg = bench.build_cfg(R)
 net = NeROShapeRenderer(cfg, training=False)
 net.load_param_dict(init_stage1_params(6033))
