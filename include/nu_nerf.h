@@ -177,6 +177,11 @@ int nu_rowscale_dsp(const float* H, int ldh, int P, int K, const float* w, float
  * --------------------------------------------------------------------------------------------------------- */
 /* get_embedder(6,3) of the SDF input (field.py:14-61, :133-136): E[P,64], skip-concat slot of U4[P,256], x-slot of YX */
 int nu_sdf_embed(const float* pt, int pt_ld, int P, float* E, float* U4, float* YX, hipStream_t stream);
+/* Generic get_embedder(n_freq <= 10, 3) (network/field.py:14-61) for the widths the SDF path does not use -- the 8-frequency position
+ * code and the 2-frequency refraction codes of AppShadingNetwork_SpecInner (field.py:1351-1354): out [P, ldo >= 3 + 6 n_freq];
+ * _bwd: g [P, ldg] -> dx [P,3]. */
+int nu_embed_n_fwd(const float* x, int P, int n_freq, float* out, int ldo, hipStream_t stream);
+int nu_embed_n_bwd(const float* x, const float* g, int ldg, int P, int n_freq, float* dx, hipStream_t stream);
 /* n = J_emb^T (G0 + Gs): last step of d sdf / d x (field.py:163-170);  q0 = J_emb nbar: first step of its adjoint */
 int nu_embed_jt(const float* E, const float* G0, int ldg0, const float* Gs, int ldgs, int P, float* n, hipStream_t stream);
 int nu_embed_j(const float* E, const float* nbar, int P, float* Q0, float* Q4, hipStream_t stream);
@@ -420,6 +425,20 @@ int nu_s2_refract_fwd(const float* d, const float* nrm, const float* ior, const 
                       float* eta, float* nd, float* ns, hipStream_t stream);
 int nu_s2_refract_bwd(const float* d, const float* nrm, const float* ior, int M, int outside, const float* g_nd, const float* g_ns,
                       const float* g_eta, float* dd, float* dn, float* dior, float* dpoint, hipStream_t stream);
+/*   nu_s2_shell_fwd / _bwd              thin-shell refraction of the NON-zero-thickness stage-2 model (network/renderer.py:1692-2032,
+ *                                       Stage2Renderer.ray_trace): per hit ray the two refractions through a shell of learned thickness
+ *                                       whose faces are concentric spheres of the local curvature radius.  In: d, raw interpolated
+ *                                       normal, hit point [M,3], raw IoR / thickness network outputs and Gaussian curvature [M];
+ *                                       `inside`: the ray leaves the object.  Out: refracts / tir_ok flags [M] u8, eta [M] (the first
+ *                                       face's ratio), unit normal facing the ray, end point of the incoming segment, next origin, next
+ *                                       direction [M,3].  _bwd: cotangents of the four [M,3] outputs (each may be NULL) -> d d, d normal,
+ *                                       d point, d ior, d g_k, d thickness (a 12 x 12 forward-mode Jacobian per ray in registers). */
+int nu_s2_shell_fwd(const float* d, const float* nraw, const float* p, const float* ior_raw, const float* gk, const float* th_raw, int M,
+                    int inside, unsigned char* refracts, unsigned char* tir_ok, float* eta, float* nrm, float* pend, float* ns, float* nd,
+                    hipStream_t stream);
+int nu_s2_shell_bwd(const float* d, const float* nraw, const float* p, const float* ior_raw, const float* gk, const float* th_raw, int M,
+                    int inside, const float* g_nrm, const float* g_pend, const float* g_ns, const float* g_nd, float* g_d, float* g_nraw,
+                    float* g_p, float* g_ior, float* g_gk, float* g_th, hipStream_t stream);
 /*   nu_s2_hit_fwd / _bwd                differentiable Moeller-Trumbore + vertex-normal interpolation of the rays that hit
  *                                       (Scene.Dintersect, network/DiffRender.py:61-125): face [M] int64 from nu_lbvh_trace, faces [F,3]
  *                                       int64, verts / vnrm [V,3] constants; backward -> d o, d d

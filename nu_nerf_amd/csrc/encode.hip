@@ -681,3 +681,52 @@ extern "C" int nu_nerf_embed_bwd(const float* pt, int pt_ld, const float* E4, co
                        dx, ddir);
     return nu_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------
+// Generic positional embedding of 3-vectors, n_freq <= 10 (get_embedder(n_freq, 3), network/field.py:14-61):
+//   out[p, 0:3] = x, out[p, 3 + 6k + c] = sin(2^k x_c), out[p, 6 + 6k + c] = cos(2^k x_c)
+// Used where the width is not the SDF network's 6 frequencies: the 8-frequency position code of AppShadingNetwork_SpecInner
+// (field.py:1351), the 2-frequency refraction codes (field.py:1353-1354).  One wave per point, lanes over columns; the
+// backward recomputes sin / cos from x:  dx_c = g[c] + sum_k 2^k (cos(a) g_sin - sin(a) g_cos).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void embed_n_fwd_kernel(const float* __restrict__ x, int P, int n_freq, float* __restrict__ out,
+                                                          int ldo) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwave = (gridDim.x * blockDim.x) >> 6;
+    const int ncol = 3 + 6 * n_freq;
+    for (int p = wave; p < P; p += nwave) {
+        const float xv[3] = {x[p * 3LL], x[p * 3LL + 1], x[p * 3LL + 2]};
+        if (lane < ncol) out[(long long)p * ldo + lane] = nu_embed_col(xv, 3, lane);
+    }
+}
+__global__ __launch_bounds__(256) void embed_n_bwd_kernel(const float* __restrict__ x, const float* __restrict__ g, int ldg, int P,
+                                                          int n_freq, float* __restrict__ dx) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const float* gp = g + (long long)p * ldg;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float xc = x[p * 3LL + c];
+        float acc = gp[c];
+        for (int k = 0; k < n_freq; ++k) {
+            const float f = (float)(1 << k), a = xc * f;
+            acc += f * (cosf(a) * gp[3 + 6 * k + c] - sinf(a) * gp[6 + 6 * k + c]);
+        }
+        dx[p * 3LL + c] = acc;
+    }
+}
+extern "C" int nu_embed_n_fwd(const float* x, int P, int n_freq, float* out, int ldo, hipStream_t stream) {
+    if (P <= 0) return NU_OK;
+    if (n_freq < 0 || n_freq > 10 || ldo < 3 + 6 * n_freq) return NU_ERR_ARG;
+    int blocks = nu_cdiv(P, 4);
+    blocks = blocks < 8192 ? blocks : 8192;
+    hipLaunchKernelGGL(embed_n_fwd_kernel, dim3(blocks), dim3(256), 0, stream, x, P, n_freq, out, ldo);
+    return nu_launch_status();
+}
+extern "C" int nu_embed_n_bwd(const float* x, const float* g, int ldg, int P, int n_freq, float* dx, hipStream_t stream) {
+    if (P <= 0) return NU_OK;
+    if (n_freq < 0 || n_freq > 10 || ldg < 3 + 6 * n_freq) return NU_ERR_ARG;
+    hipLaunchKernelGGL(embed_n_bwd_kernel, dim3(nu_cdiv(P, 256)), dim3(256), 0, stream, x, g, ldg, P, n_freq, dx);
+    return nu_launch_status();
+}

@@ -858,3 +858,258 @@ extern "C" int nu_s2_neus_alpha_bwd(const float* sdf, const float* nrm, const fl
                        (float*)nullptr, g_alpha, g_sdf, g_nrm, g_dir, g_dist, g_s);
     return nu_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------
+// Thin-shell refraction of the non-zero-thickness stage-2 model (network/renderer.py:1692-2032), one thread per ray that hit the
+// mesh.  The surface is a shell of learned thickness around the stage-1 mesh; where it is crossed the shell is replaced by two
+// concentric spheres of the local curvature radius R = 1 / sqrt(max(|g_k|, 1e-6)) (g_k: interpolated Gaussian curvature):
+//   entering (outside = the ray comes from the air side): refract at the mesh point with ratio r, walk the chord of the shell
+//     (length |R cos_t - sqrt((R cos_t)^2 -+ 2 R th + th^2)| + 1e-3), refract again at the inner sphere's normal with ratio r';
+//   leaving (inside): first step BACK along the ray to the inner sphere (the mesh is the outer face), refract there with the
+//     sphere's normal, walk the chord, refract at the outer face.
+//   r = 1 / (sigmoid(ior) + 0.6) (the IoR network's raw output), inner medium 1 / 1.0001, r' = inner / r; leaving swaps and inverts
+//   them; th = 0.01 sigmoid(thick).  Total internal reflection at the first face ends the path (flag 0); at the later faces the
+//   sine is clamped and only the validity mask (tir_ok) drops.
+// Inputs with gradients: d, the RAW interpolated normal, the hit point, the two raw network outputs, g_k (12 scalars per ray).
+// Outputs with gradients: unit normal facing the ray (what shades the surface), the end point of the incoming segment (the mesh
+// point entering, the inner-sphere point leaving), next origin, next direction (12 scalars).
+// The forward is written once over a scalar type; the backward instantiates it with a 12-wide forward-mode dual number -- the
+// full 12 x 12 Jacobian per ray in registers -- and contracts it with the cotangents.  clamp / abs / sqrt differentiate as
+// torch does (clamp passes the gradient on its closed interval, abs -> sign).
+// ------------------------------------------------------------------------------------------------
+#define S2_SHELL_NIN 12
+struct S2Dual {
+    float v;
+    float d[S2_SHELL_NIN];
+};
+static __device__ inline float s2v(float x) { return x; }
+static __device__ inline float s2v(const S2Dual& x) { return x.v; }
+static __device__ inline void s2_set(float& x, float c) { x = c; }
+static __device__ inline void s2_set(S2Dual& x, float c) {
+    x.v = c;
+#pragma unroll
+    for (int i = 0; i < S2_SHELL_NIN; ++i) x.d[i] = 0.f;
+}
+static __device__ inline S2Dual operator+(const S2Dual& a, const S2Dual& b) {
+    S2Dual r; r.v = a.v + b.v;
+#pragma unroll
+    for (int i = 0; i < S2_SHELL_NIN; ++i) r.d[i] = a.d[i] + b.d[i];
+    return r;
+}
+static __device__ inline S2Dual operator-(const S2Dual& a, const S2Dual& b) {
+    S2Dual r; r.v = a.v - b.v;
+#pragma unroll
+    for (int i = 0; i < S2_SHELL_NIN; ++i) r.d[i] = a.d[i] - b.d[i];
+    return r;
+}
+static __device__ inline S2Dual operator-(const S2Dual& a) {
+    S2Dual r; r.v = -a.v;
+#pragma unroll
+    for (int i = 0; i < S2_SHELL_NIN; ++i) r.d[i] = -a.d[i];
+    return r;
+}
+static __device__ inline S2Dual operator*(const S2Dual& a, const S2Dual& b) {
+    S2Dual r; r.v = a.v * b.v;
+#pragma unroll
+    for (int i = 0; i < S2_SHELL_NIN; ++i) r.d[i] = a.d[i] * b.v + a.v * b.d[i];
+    return r;
+}
+static __device__ inline S2Dual operator/(const S2Dual& a, const S2Dual& b) {
+    S2Dual r; const float ib = 1.0f / b.v; r.v = a.v * ib;
+#pragma unroll
+    for (int i = 0; i < S2_SHELL_NIN; ++i) r.d[i] = (a.d[i] - r.v * b.d[i]) * ib;
+    return r;
+}
+static __device__ inline S2Dual operator+(const S2Dual& a, float c) { S2Dual r = a; r.v += c; return r; }
+static __device__ inline S2Dual operator*(const S2Dual& a, float c) {
+    S2Dual r; r.v = a.v * c;
+#pragma unroll
+    for (int i = 0; i < S2_SHELL_NIN; ++i) r.d[i] = a.d[i] * c;
+    return r;
+}
+static __device__ inline S2Dual s2_chain(const S2Dual& x, float fv, float dfdx) {
+    S2Dual r; r.v = fv;
+#pragma unroll
+    for (int i = 0; i < S2_SHELL_NIN; ++i) r.d[i] = x.d[i] * dfdx;
+    return r;
+}
+static __device__ inline float s2_chain(float, float fv, float) { return fv; }
+template <class T> static __device__ inline T s2_sqrt(const T& x) { const float r = sqrtf(s2v(x)); return s2_chain(x, r, 0.5f / r); }
+template <class T> static __device__ inline T s2_abs(const T& x) {
+    const float v = s2v(x);
+    return s2_chain(x, fabsf(v), v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f));
+}
+template <class T> static __device__ inline T s2_clamp_min(const T& x, float m) {
+    const float v = s2v(x);
+    return s2_chain(x, fmaxf(v, m), v >= m ? 1.f : 0.f);
+}
+template <class T> static __device__ inline T s2_clamp_max(const T& x, float m) {
+    const float v = s2v(x);
+    return s2_chain(x, fminf(v, m), v <= m ? 1.f : 0.f);
+}
+template <class T> static __device__ inline T s2_sigm(const T& x) {
+    const float s = 1.0f / (1.0f + expf(-s2v(x)));
+    return s2_chain(x, s, s * (1.0f - s));
+}
+template <class T> static __device__ inline T s2_recip(const T& x) { const float r = 1.0f / s2v(x); return s2_chain(x, r, -r * r); }
+template <class T> static __device__ inline T s2_dot3(const T* a, const T* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+// x / (|x| + 1e-4)
+template <class T> static __device__ inline void s2_unit_eps(T* x) {
+    const T inv = s2_recip(s2_sqrt(s2_dot3(x, x)) + 0.0001f);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) x[c] = x[c] * inv;
+}
+
+template <class T>
+static __device__ inline void s2_shell_core(const T* d, const T* nraw, const T* p, const T& ior_raw, const T& gk, const T& th_raw, bool inside,
+                                            T* nrm, T* pend, T* ns, T* nd, float& eta, bool& refr, bool& tir_ok) {
+    T zero; s2_set(zero, 0.f);
+    // F.normalize(n), flipped to face the ray inside the object
+    {
+        const T inv = s2_recip(s2_clamp_min(s2_sqrt(s2_dot3(nraw, nraw)), 1e-12f));
+#pragma unroll
+        for (int c = 0; c < 3; ++c) nrm[c] = inside ? -(nraw[c] * inv) : nraw[c] * inv;
+    }
+    T r = s2_recip(s2_sigm(ior_raw) * 1.0f + 0.6f);
+    T inner; s2_set(inner, 1.0f / 1.0001f);
+    T ro = inner / r;
+    if (inside) { const T tmp = r; r = s2_recip(ro); ro = s2_recip(tmp); }
+    const T th = s2_sigm(th_raw) * 0.01f;
+    const T cos_i = -s2_dot3(nrm, d);
+    T one; s2_set(one, 1.0f);
+    const T sin2_i = one - cos_i * cos_i;
+    refr = !(s2v(r * r * sin2_i) > 0.999f);
+    tir_ok = refr;
+    eta = s2v(r);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { pend[c] = p[c]; ns[c] = zero; nd[c] = zero; }
+    if (!refr) return;
+    const T sin2_t = sin2_i * r * r;
+    T R = s2_recip(s2_sqrt(s2_clamp_min(s2_abs(gk), 0.000001f)));
+    if (s2v(R) != s2v(R)) s2_set(R, 0.1f);
+    const T cos_t = s2_sqrt(s2_clamp_min(one - sin2_t, 0.0001f));
+    const bool positive = inside ? (s2v(gk) <= 0.f) : (s2v(gk) >= 0.f);
+    const T two_R_th = R * th * 2.0f, th2 = th * th;
+    T pm[3], nm[3], din[3];
+    if (!inside) {
+        const T f = r * cos_i - cos_t;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { din[c] = r * d[c] + f * nrm[c]; pm[c] = p[c]; nm[c] = nrm[c]; }
+        s2_unit_eps(din);
+    } else {
+        const T ci = R * cos_i;
+        const T delta2 = positive ? (ci * ci - two_R_th + th2) : (ci * ci + two_R_th + th2);
+        const T len = s2_abs(ci - s2_sqrt(s2_clamp_min(delta2, 0.0001f)));
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const T center = positive ? (p[c] - nrm[c] * R) : (p[c] + nrm[c] * R);
+            pm[c] = p[c] - len * d[c];
+            nm[c] = positive ? (pm[c] - center) : (center - pm[c]);
+            pend[c] = pm[c];
+        }
+        s2_unit_eps(nm);
+        const T cos_im = -s2_dot3(nm, d);
+        const T x = (one - cos_im * cos_im) * r * r;
+        if (s2v(x) > 0.999f) tir_ok = false;
+        const T f = r * cos_im - s2_sqrt(s2_clamp_min(one - s2_clamp_max(x, 0.999f), 0.0001f));
+#pragma unroll
+        for (int c = 0; c < 3; ++c) din[c] = r * d[c] + f * nm[c];
+        s2_unit_eps(din);
+    }
+    // the chord through the shell and the second face
+    const T cr = R * cos_t;
+    const T delta2 = positive ? (cr * cr - two_R_th + th2) : (cr * cr + two_R_th + th2);
+    const T len = s2_abs(cr - s2_sqrt(s2_clamp_min(delta2, 0.0001f))) + 0.001f;
+    T na[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const T center = positive ? (pm[c] - nm[c] * R) : (pm[c] + nm[c] * R);
+        ns[c] = pm[c] + din[c] * len;
+        na[c] = positive ? (ns[c] - center) : (center - ns[c]);
+    }
+    s2_unit_eps(na);
+    const T cos_i2 = -s2_dot3(na, din);
+    const T x2 = (one - cos_i2 * cos_i2) * ro * ro;
+    if (s2v(x2) > 0.999f) tir_ok = false;
+    const T f2 = ro * cos_i2 - s2_sqrt(s2_clamp_min(one - s2_clamp_max(x2, 0.999f), 0.0001f));
+#pragma unroll
+    for (int c = 0; c < 3; ++c) nd[c] = ro * din[c] + f2 * na[c];
+    s2_unit_eps(nd);
+}
+
+__global__ __launch_bounds__(256) void s2_shell_fwd_kernel(const float* __restrict__ d, const float* __restrict__ nraw,
+                                                           const float* __restrict__ p, const float* __restrict__ ior_raw,
+                                                           const float* __restrict__ gk, const float* __restrict__ th_raw, int M, int inside,
+                                                           unsigned char* __restrict__ refracts, unsigned char* __restrict__ tir_ok,
+                                                           float* __restrict__ eta, float* __restrict__ nrm, float* __restrict__ pend,
+                                                           float* __restrict__ ns, float* __restrict__ nd) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    float dd[3], nn[3], pp[3], on[3], oe[3], os[3], od[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { dd[c] = d[m * 3LL + c]; nn[c] = nraw[m * 3LL + c]; pp[c] = p[m * 3LL + c]; }
+    float e; bool rf, ok;
+    s2_shell_core<float>(dd, nn, pp, ior_raw[m], gk[m], th_raw[m], inside != 0, on, oe, os, od, e, rf, ok);
+    refracts[m] = rf ? 1 : 0;
+    tir_ok[m] = ok ? 1 : 0;
+    eta[m] = e;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { nrm[m * 3LL + c] = on[c]; pend[m * 3LL + c] = oe[c]; ns[m * 3LL + c] = os[c]; nd[m * 3LL + c] = od[c]; }
+}
+
+__global__ __launch_bounds__(64) void s2_shell_bwd_kernel(const float* __restrict__ d, const float* __restrict__ nraw,
+                                                          const float* __restrict__ p, const float* __restrict__ ior_raw,
+                                                          const float* __restrict__ gk, const float* __restrict__ th_raw, int M, int inside,
+                                                          const float* __restrict__ g_nrm, const float* __restrict__ g_pend,
+                                                          const float* __restrict__ g_ns, const float* __restrict__ g_nd,
+                                                          float* __restrict__ g_d, float* __restrict__ g_nraw, float* __restrict__ g_p,
+                                                          float* __restrict__ g_ior, float* __restrict__ g_gk, float* __restrict__ g_th) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    S2Dual in[S2_SHELL_NIN];
+#pragma unroll
+    for (int i = 0; i < S2_SHELL_NIN; ++i) {
+        float v;
+        if (i < 3) v = d[m * 3LL + i];
+        else if (i < 6) v = nraw[m * 3LL + i - 3];
+        else if (i < 9) v = p[m * 3LL + i - 6];
+        else v = i == 9 ? ior_raw[m] : (i == 10 ? gk[m] : th_raw[m]);
+        s2_set(in[i], v);
+        in[i].d[i] = 1.0f;
+    }
+    S2Dual on[3], oe[3], os[3], od[3];
+    float e; bool rf, ok;
+    s2_shell_core<S2Dual>(in, in + 3, in + 6, in[9], in[10], in[11], inside != 0, on, oe, os, od, e, rf, ok);
+    float acc[S2_SHELL_NIN];
+#pragma unroll
+    for (int i = 0; i < S2_SHELL_NIN; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float a = g_nrm ? g_nrm[m * 3LL + c] : 0.f, b = g_pend ? g_pend[m * 3LL + c] : 0.f;
+        const float s = g_ns ? g_ns[m * 3LL + c] : 0.f, t = g_nd ? g_nd[m * 3LL + c] : 0.f;
+#pragma unroll
+        for (int i = 0; i < S2_SHELL_NIN; ++i) acc[i] += a * on[c].d[i] + b * oe[c].d[i] + s * os[c].d[i] + t * od[c].d[i];
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { g_d[m * 3LL + c] = acc[c]; g_nraw[m * 3LL + c] = acc[3 + c]; g_p[m * 3LL + c] = acc[6 + c]; }
+    g_ior[m] = acc[9];
+    g_gk[m] = acc[10];
+    g_th[m] = acc[11];
+}
+
+extern "C" int nu_s2_shell_fwd(const float* d, const float* nraw, const float* p, const float* ior_raw, const float* gk, const float* th_raw,
+                               int M, int inside, unsigned char* refracts, unsigned char* tir_ok, float* eta, float* nrm, float* pend,
+                               float* ns, float* nd, hipStream_t stream) {
+    if (M <= 0) return NU_OK;
+    hipLaunchKernelGGL(s2_shell_fwd_kernel, dim3(nu_cdiv(M, 256)), dim3(256), 0, stream, d, nraw, p, ior_raw, gk, th_raw, M, inside, refracts,
+                       tir_ok, eta, nrm, pend, ns, nd);
+    return nu_launch_status();
+}
+extern "C" int nu_s2_shell_bwd(const float* d, const float* nraw, const float* p, const float* ior_raw, const float* gk, const float* th_raw,
+                               int M, int inside, const float* g_nrm, const float* g_pend, const float* g_ns, const float* g_nd, float* g_d,
+                               float* g_nraw, float* g_p, float* g_ior, float* g_gk, float* g_th, hipStream_t stream) {
+    if (M <= 0) return NU_OK;
+    hipLaunchKernelGGL(s2_shell_bwd_kernel, dim3(nu_cdiv(M, 64)), dim3(64), 0, stream, d, nraw, p, ior_raw, gk, th_raw, M, inside, g_nrm,
+                       g_pend, g_ns, g_nd, g_d, g_nraw, g_p, g_ior, g_gk, g_th);
+    return nu_launch_status();
+}

@@ -144,8 +144,11 @@ class Stage1Engine:
         self.p = params  # dict name -> Parameter/Tensor on device
         self.exp_max = float(cfg.get('light_exp_max', 3.0))
         self.sphere_direction = bool(cfg.get('sphere_direction', False))
-        if int(cfg.get('light_pos_freq', 6)) != 6:
-            raise NotImplementedError("light_pos_freq != 6 (no shipped config changes it)")
+        # 6 everywhere in stage 1; AppShadingNetwork_SpecInner (the inner surface of the non-zero-thickness stage-2 model,
+        # field.py:1321-1330) defaults to 8 -- supported by the network-level ops (nets.py), not by the fused stage-1 shading
+        self.light_pos_freq = int(cfg.get('light_pos_freq', 6))
+        if 3 + 6 * self.light_pos_freq + 72 > 128:
+            raise NotImplementedError("light_pos_freq > 8: the inner_light input would not fit its 128-column tile")
         self.refrac_dim = 3 + 6 * int(cfg.get('refrac_freq', 6))       # field.py:590-591 (real_bottle uses refrac_freq 3)
         self.ld_ol = 160 if self.sphere_direction else 96               # outer_light input 144 / 72 (field.py:594-597)
         self.ld_rl = rup(2 * self.refrac_dim, 32)
@@ -423,12 +426,15 @@ class Stage1Engine:
         self.inner_weight = predictor('inner_weight', 96)
         self.refrac_light = predictor('refrac_light', self.ld_rl)
         layers += self.outer_light + self.inner_light + self.inner_weight + self.refrac_light
-        # ---- stage 2: the IoR network (field.py:1046-1066: 39 -> 256 ReLU -> 256 ReLU -> 256 -> 1), when the owner has one ----
-        self.ior = None
-        if 'ior_network.0.weight_v' in p:
-            self.ior = []
+        # ---- stage 2: the IoR / thickness networks (field.py:1046-1087: 39 -> 256 ReLU -> 256 ReLU -> 256 -> 1), when the owner
+        # has them ----
+        self.small = {}
+        for pre in ('ior_network', 'thickness_network'):
+            if pre + '.0.weight_v' not in p:
+                continue
+            net = []
             for j, idx in enumerate((0, 2, 4, 5)):
-                q = f'ior_network.{idx}'
+                q = f'{pre}.{idx}'
                 v = p[q + '.weight_v']
                 N, K = v.shape
                 Kp = 64 if j == 0 else 256
@@ -439,8 +445,10 @@ class Stage1Engine:
                 lay.dWp, lay.ldd = (z(N, Kp), 0), Kp
                 lay.dv_off, lay.dg_off, lay.db_off = galloc(N * K), galloc(N), galloc(N)
                 reg(q + '.weight_v', lay.dv_off); reg(q + '.weight_g', lay.dg_off); reg(q + '.bias', lay.db_off)
-                self.ior.append(lay)
-            layers += self.ior
+                net.append(lay)
+            self.small[pre] = net
+            layers += net
+        self.ior = self.small.get('ior_network')
         self.layers = layers
         self.n_grad = self._goff
         # bf16 copies of every NT-side weight table (written by the same pack launch): same shapes, same element offsets
@@ -871,6 +879,9 @@ class Stage1Engine:
         """Materials -> encodings -> 4 light predictors -> combine (field.py:684-777).
         a: SDF activations (YX, E, n).  extra_dirs [R,3]: per-ray directions whose mirror query IDE(d,0)
         rides along the outer_light batch (colour_spec, renderer_zerothick.py:780-781)."""
+        if self.light_pos_freq != 6:
+            raise NotImplementedError("the fused stage-1 shading encodes positions with 6 frequencies (every stage-1 config); "
+                                      "light_pos_freq != 6 runs through the network-level ops (nets.py / shading_glue.py)")
         lib, S = self.lib, self.stream()
         e = self.empty
         s = {'P': P}

@@ -122,11 +122,15 @@ class Scene:
         return dict(u=u, v=v, t=t, n=n, point=o + t[:, None] * d, origin=o, direction=d, faces_ind=faces_ind[hitted]), hitted
 
 
-def dintersect_hip(scene, eng, origin, direction):
-    """Scene.Dintersect on the HIP kernels (nu_lbvh_trace + nu_s2_hit_fwd/_bwd): -> dict(n, point, t, faces_ind), hitted mask."""
+def dintersect_hip(scene, eng, origin, direction, curvature=False):
+    """Scene.Dintersect on the HIP kernels (nu_lbvh_trace + nu_s2_hit_fwd/_bwd): -> dict(n, point, t, faces_ind[, g_k]), hitted
+    mask.  curvature=True adds the interpolated per-vertex Gaussian curvature (DiffRender.py:116, Intersection.g_k)."""
     from . import stage2_ops as O
     faces_ind, hitted = scene.intersect(origin, direction)
     fi = faces_ind[hitted]
+    if curvature:
+        point, n, t, gk = O.hit(eng, scene, origin[hitted], direction[hitted], fi, curvature=True)
+        return dict(n=n, point=point, t=t, faces_ind=fi, g_k=gk), hitted
     point, n, t = O.hit(eng, scene, origin[hitted], direction[hitted], fi)
     return dict(n=n, point=point, t=t, faces_ind=fi), hitted
 

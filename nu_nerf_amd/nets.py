@@ -215,14 +215,13 @@ class MaterialsFn(torch.autograd.Function):
 
 
 class IorFn(torch.autograd.Function):
-    """The stage-2 IoR network on the HIP GEMMs (field.py:1046-1066): X [rows, 39] (the 6-frequency embedding of the hit point)
+    """The stage-2 IoR / thickness networks on the HIP GEMMs (field.py:1046-1087; `ls` = the engine's layer list): X [rows, 39] (the 6-frequency embedding of the hit point)
     -> 256 ReLU -> 256 ReLU -> 256 (no activation) -> 1 raw output (the caller applies the sigmoid); gradients w.r.t. X and the
     weight-normed parameters."""
 
     @staticmethod
-    def forward(ctx, eng, X, names, token):
+    def forward(ctx, eng, ls, X, names, token):
         from .engine import EPI_BIAS_NONE, EPI_BIAS_RELU
-        ls = eng.ior
         rows, K = X.shape
         Xp = eng.zeros(rows, 64)
         Xp[:, :K] = X.detach()
@@ -232,14 +231,14 @@ class IorFn(torch.autograd.Function):
         eng.nt(addr(H[1]), 256, addr(*ls[2].Wp), 256, rows, 256, 256, addr(H[2]), 256, EPI_BIAS_NONE, bias=addr(ls[2].b))
         out = eng.empty(rows, 1)
         eng.skinny_fwd(addr(H[2]), 256, rows, 256, addr(*ls[3].Wp), 256, addr(ls[3].b), 1, addr(out), 1)
-        ctx.eng, ctx.names, ctx.Xp, ctx.H, ctx.K = eng, names, Xp, H, K
+        ctx.eng, ctx.ls, ctx.names, ctx.Xp, ctx.H, ctx.K = eng, ls, names, Xp, H, K
         ctx.set_materialize_grads(False)
         return out[:, 0].clone()
 
     @staticmethod
     def backward(ctx, dout):
         from .engine import EPI_MUL_DRELU, EPI_PLAIN
-        eng, ls, Xp, H = ctx.eng, ctx.eng.ior, ctx.Xp, ctx.H
+        eng, ls, Xp, H = ctx.eng, ctx.ls, ctx.Xp, ctx.H
         rows = Xp.shape[0]
         flat = eng.zeros(eng.n_grad)
         dy = (dout.contiguous() if dout is not None else eng.zeros(rows)).reshape(rows, 1).contiguous()
@@ -257,7 +256,7 @@ class IorFn(torch.autograd.Function):
         eng.nt(addr(d0), 256, addr(*ls[0].WpT), ls[0].ldT, rows, 64, 256, addr(dX), 64, EPI_PLAIN)
         eng.unpack_grads(flat)
         ctx.H = ctx.Xp = None
-        return None, dX[:, :ctx.K], None, _token_grad(eng, flat, ctx.names)
+        return None, None, dX[:, :ctx.K], None, _token_grad(eng, flat, ctx.names)
 
 
 class Stage1Nets:
@@ -283,6 +282,7 @@ class Stage1Nets:
             names, params = sel(lambda n, nm=nm: n.startswith('color_network.' + nm + '.'))
             self.stack[nm] = (layers, names, params)
         self.ior_names, _ = sel(lambda n: n.startswith('ior_network.'))
+        self.thick_names, _ = sel(lambda n: n.startswith('thickness_network.'))
         self.all_names = [n for n in g if n in named and isinstance(named[n], torch.nn.Parameter)]
         self._token = None
 
@@ -312,7 +312,13 @@ class Stage1Nets:
         """Raw (pre-sigmoid) output of the IoR network on encoded points X [rows, 39]."""
         if X.shape[0] == 0:
             return X.new_zeros(0)
-        return IorFn.apply(self.eng, X, self.ior_names, self.token())
+        return IorFn.apply(self.eng, self.eng.small['ior_network'], X, self.ior_names, self.token())
+
+    def thickness(self, X):
+        """Raw (pre-sigmoid) output of the thickness network (field.py:1068-1087) on encoded points X [rows, 39]."""
+        if X.shape[0] == 0:
+            return X.new_zeros(0)
+        return IorFn.apply(self.eng, self.eng.small['thickness_network'], X, self.thick_names, self.token())
 
     def predictor(self, name, X):
         layers, names, params = self.stack[name]

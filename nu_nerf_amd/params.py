@@ -44,22 +44,23 @@ def _put_wn(p, prefix, w, bias):
     p[prefix + ".weight_v"] = w.astype(np.float32)
 
 
-def predictor_dims(sphere_direction=False, refrac_freq=6):
+def predictor_dims(sphere_direction=False, refrac_freq=6, light_pos_freq=6):
     """(name, in_dim, out_dim, last-bias constant or None) of every make_predictor stack."""
+    pos = 3 + 6 * light_pos_freq
     return [
         ("metallic_predictor", 259, 1, None),
         ("roughness_predictor", 259, 1, None),
         ("albedo_predictor", 259, 3, None),
         ("outer_light", 144 if sphere_direction else 72, 3, math.log(0.5)),
-        ("inner_light", 39 + 72, 3, math.log(0.5)),
-        ("inner_weight", 39 + 39, 1, -0.95),
+        ("inner_light", pos + 72, 3, math.log(0.5)),
+        ("inner_weight", pos + 39, 1, -0.95),
         ("transmisstion_weight", 259, 1, None),
         ("iors", 259, 1, None),
         ("refrac_light", 2 * (3 + 6 * refrac_freq), 3, math.log(0.5)),
     ]
 
 
-def init_stage1_params(seed=6033, sphere_direction=False, sdf_bias=0.5, inv_s_init=0.3, refrac_freq=6):
+def init_stage1_params(seed=6033, sphere_direction=False, sdf_bias=0.5, inv_s_init=0.3, refrac_freq=6, light_pos_freq=6):
     """OrderedDict name -> np.float32 array, in the reference module-construction order
     (renderer_zerothick.py:144-162)."""
     rng = np.random.Generator(np.random.PCG64(seed))
@@ -106,7 +107,7 @@ def init_stage1_params(seed=6033, sphere_direction=False, sdf_bias=0.5, inv_s_in
 
     # ---- AppShadingNetwork predictors (field.py:575-611) ----
     p["color_network.FG_LUT"] = load_fg_lut()
-    for name, k, n_out, last_bias in predictor_dims(sphere_direction, refrac_freq):
+    for name, k, n_out, last_bias in predictor_dims(sphere_direction, refrac_freq, light_pos_freq):
         chain = [(k, 256), (256, 256), (256, 256), (256, n_out)]
         for j, (ki, no) in enumerate(chain):
             w, b = _linear_default(rng, no, ki)
@@ -181,6 +182,33 @@ def init_stage2_params(seed=6033, inner_seed=7044, shader_cfg=None):
             p[k] = v
     for k, v in s1.items():
         p['color_network.stage1_network.' + k] = v
+    for k, v in inner.items():
+        if k.startswith('sdf_network.'):
+            p['sdf_network_inner.' + k[len('sdf_network.'):]] = v
+    p['deviation_network_inner.variance'] = inner['deviation_network.variance']
+    for k, v in inner.items():
+        if k.startswith('color_network.'):
+            p['color_network_inner.' + k[len('color_network.'):]] = v
+    return p
+
+
+def init_stage2_thick_own_params(seed=7044, shader_cfg=None):
+    """Initial values of what the NON-zero-thickness Stage2Renderer owns besides the stage-1 network (renderer.py:963-1024):
+    nerf_network, IORs, the IoR / inner-IoR / thickness networks, the inner SDF (geometric init), its variance and the inner
+    AppShadingNetwork_SpecInner predictors (8 position / 2 refraction frequencies, field.py:1321-1330)."""
+    shader_cfg = shader_cfg or {}
+    sd = bool(shader_cfg.get('sphere_direction', False))
+    inner = init_stage1_params(seed, sphere_direction=sd, refrac_freq=int(shader_cfg.get('refrac_freq', 2)),
+                               light_pos_freq=int(shader_cfg.get('light_pos_freq', 8)))
+    rng = np.random.Generator(np.random.PCG64(seed + 17))
+    p = OrderedDict()
+    p['IORs'] = np.zeros(10, np.float32)
+    for k, v in init_stage1_params(seed + 1).items():
+        if k.startswith('outer_nerf.'):
+            p['nerf_network.' + k[len('outer_nerf.'):]] = v
+    p.update(init_ior_params(rng, 'IORs_pred'))
+    p.update(init_ior_params(rng, 'IoRint_pred'))
+    p.update(init_ior_params(rng, 'thickness_pred'))
     for k, v in inner.items():
         if k.startswith('sdf_network.'):
             p['sdf_network_inner.' + k[len('sdf_network.'):]] = v

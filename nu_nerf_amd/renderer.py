@@ -112,7 +112,7 @@ class AppShadingNetwork(nn.Module):
         self.cfg = {**self.default_cfg, **cfg}
         if self.cfg['human_light']:
             raise NotImplementedError("human_light=True is outside the stage-1 hot path of the supported configs")
-        for name, k, n_out, _ in predictor_dims(self.cfg['sphere_direction'], self.cfg['refrac_freq']):
+        for name, k, n_out, _ in predictor_dims(self.cfg['sphere_direction'], self.cfg['refrac_freq'], self.cfg['light_pos_freq']):
             setattr(self, name, _predictor(k, n_out))
         self.register_buffer('FG_LUT', torch.zeros(1, 256, 256, 2))
 

@@ -33,7 +33,7 @@ def sphere_point(points, dirs):
     return F.normalize(sp + dirs * get_sphere_intersection(sp, dirs), dim=-1)
 
 
-def lights(nets, exp_max, points, n, refl, rough, sphere=False, detail=False):
+def lights(nets, exp_max, points, n, refl, rough, sphere=False, detail=False, pos_freq=6):
     """The three outer_light and two inner_light queries + the occlusion weight (field.py:636-682), row-batched."""
     P = points.shape[0]
     one, zero = torch.ones_like(rough), torch.zeros_like(rough)
@@ -45,7 +45,7 @@ def lights(nets, exp_max, points, n, refl, rough, sphere=False, detail=False):
     else:
         enc_ol = enc
     lo = torch.exp(torch.clamp(nets.predictor('outer_light', enc_ol), max=exp_max))
-    pe = G.embed(points, 6)
+    pe = G.embed(points, pos_freq)
     li = torch.exp(torch.clamp(nets.predictor('inner_light', torch.cat([torch.cat([pe, enc[P:2 * P]], -1),
                                                                           torch.cat([pe, enc[2 * P:]], -1)], 0)), max=exp_max))
     occ = nets.predictor('inner_weight', torch.cat([pe.detach(), G.embed(refl, 6).detach()], -1)) * 0.5 + 0.5
@@ -57,7 +57,7 @@ def lights(nets, exp_max, points, n, refl, rough, sphere=False, detail=False):
     return lo[:P], light, light0
 
 
-def raw_lights(nets, points, n, refl, rough, sphere=False):
+def raw_lights(nets, points, n, refl, rough, sphere=False, pos_freq=6):
     """Raw (pre-activation) heads of the light predictors, row-batched as `lights` does: outer_light [3P,3], inner_light [2P,3],
     inner_weight [P,1]."""
     P = points.shape[0]
@@ -69,7 +69,7 @@ def raw_lights(nets, points, n, refl, rough, sphere=False):
     else:
         enc_ol = enc
     ol = nets.predictor('outer_light', enc_ol)
-    pe = G.embed(points, 6)
+    pe = G.embed(points, pos_freq)
     il = nets.predictor('inner_light', torch.cat([torch.cat([pe, enc[P:2 * P]], -1), torch.cat([pe, enc[2 * P:]], -1)], 0))
     iw = nets.predictor('inner_weight', torch.cat([pe.detach(), G.embed(refl, 6).detach()], -1))
     return ol, il, iw
@@ -80,6 +80,8 @@ def shade(nets, scfg, lut, points, normals, view_dirs, feats, s2=False, is_inter
     Without inter_results the BRDF mix runs as one HIP kernel pair on the raw head outputs (stage2_ops.shade_combine); the
     eager formulation below it serves the validation images (inter_results=True)."""
     exp_max = scfg['light_exp_max']
+    rl_max = scfg.get('refrac_exp_max', exp_max)
+    pos_freq = int(scfg.get('light_pos_freq', 6))
     sphere = bool(scfg.get('sphere_direction', False))
     n, v = F.normalize(normals, dim=-1), F.normalize(view_dirs, dim=-1)
     nov = torch.sum(n * v, -1, keepdim=True)
@@ -88,16 +90,18 @@ def shade(nets, scfg, lut, points, normals, view_dirs, feats, s2=False, is_inter
         from . import stage2_ops as O
         m_raw = nets.materials(feats, points)
         rough = torch.sigmoid(m_raw[:, 1:2])
-        ol, il, iw = raw_lights(nets, points, n, refl, rough, sphere)
+        ol, il, iw = raw_lights(nets, points, n, refl, rough, sphere, pos_freq)
         rl = None
         if not s2:
             rf = scfg.get('refrac_freq', 6)
             rl = nets.predictor('refrac_light', torch.cat([G.embed(points, rf), G.embed(v, rf)], -1))
+            if rl_max < exp_max:     # AppShadingNetwork_SpecInner's refrac_light caps at exp(-0.2) (field.py:1373): clamp the raw head,
+                rl = torch.clamp(rl, max=rl_max)     # the kernel's own min(., exp_max) is then the identity
         color, rc = O.shade_combine(nets.eng, m_raw, ol, il, iw, rl, nov, lut, exp_max, s2=s2, internal=is_internal)
         return color, (rc if s2 else None)
     m = torch.sigmoid(nets.materials(feats, points))
     metallic, rough, albedo, trans = m[:, 0:1], m[:, 1:2], m[:, 2:5], m[:, 5:6]
-    diffuse_light, light, light0, occ, indirect = lights(nets, exp_max, points, n, refl, rough, sphere, detail=True)
+    diffuse_light, light, light0, occ, indirect = lights(nets, exp_max, points, n, refl, rough, sphere, detail=True, pos_freq=pos_freq)
     t = torch.clamp(1 - nov, 0.0, 1.0)
     fres = torch.clamp(0.04 + 0.96 * t * t * t * t * t, 0.0, 1.0)
     fg = G.lut_bilinear_clamp(lut[0], torch.cat([torch.clamp(nov, 0.0, 1.0), torch.clamp(rough, 0.0, 1.0)], -1))
@@ -114,7 +118,7 @@ def shade(nets, scfg, lut, points, normals, view_dirs, feats, s2=False, is_inter
         return G.linear_to_srgb(color), (1 - fres) * trans
     rf = scfg.get('refrac_freq', 6)
     refrac = torch.exp(torch.clamp(nets.predictor('refrac_light', torch.cat([G.embed(points, rf), G.embed(v, rf)], -1)),
-                                   max=exp_max))
+                                   max=min(exp_max, rl_max)))
     color = G.linear_to_srgb(base + (fres * light0 + (1 - fres) * refrac) * trans)
     if not inter_results:
         return color, None

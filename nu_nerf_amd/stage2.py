@@ -375,6 +375,7 @@ class Stage2Renderer(nn.Module):
             ret['_paths'] = [self.path_points(sg) for sg in segs]       # materialised for inspection only
         ret['_ior_ratios'] = [sg['eta'] for sg in segs if sg['n_cont'] > 0]
         ret['_directions'] = [sg['dirs'] for sg in segs]
+        ret['_normals'] = [sg['normal'] for sg in segs if sg['n_cont'] > 0]
         return ret
 
     def train_step_rays(self, batch, step):

@@ -7,6 +7,7 @@
                   (renderer_zerothick.py:1835-1870, :1531-1540)
   SegmentComposite  linear-RGB composite of one segment with the running transmittance (renderer_zerothick.py:1976-1990)
   Refract         Snell refraction / total internal reflection of the rays that hit the mesh (renderer_zerothick.py:1642-1684)
+  ShellRefract    the two refractions through the shell of the non-zero-thickness model (renderer.py:1692-2032)
 
 A segment is (start [N,3], v [N,3], z [N,S1]): nodes x_j = start + v * z_j, z without gradient (csrc/stage2.hip).
 """
@@ -168,6 +169,47 @@ def refract(eng, d, nrm, ior, point, outside):
     point [M,3].  -> (refracts [M] bool, eta [M], next direction [M,3], next origin [M,3]); rows of totally reflected rays are 0."""
     flag, eta, nd, ns = _RefractFn.apply(eng, d, nrm, ior, point, outside)
     return flag.bool(), eta, nd, ns
+
+
+class _ShellFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, eng, d, nraw, point, ior_raw, gk, th_raw, inside):
+        d, nraw, point, ior_raw, gk, th_raw = (t.detach().contiguous() for t in (d, nraw, point, ior_raw, gk, th_raw))
+        M, dev = d.shape[0], d.device
+        refr, ok = torch.zeros(M, dtype=torch.uint8, device=dev), torch.zeros(M, dtype=torch.uint8, device=dev)
+        eta = torch.zeros(M, device=dev)
+        nrm, pend, ns, nd = (torch.zeros(M, 3, device=dev) for _ in range(4))
+        L.check(eng.lib.nu_s2_shell_fwd(c_p(addr(d)), c_p(addr(nraw)), c_p(addr(point)), c_p(addr(ior_raw)), c_p(addr(gk)), c_p(addr(th_raw)),
+                                        M, 1 if inside else 0, c_p(addr(refr)), c_p(addr(ok)), c_p(addr(eta)), c_p(addr(nrm)),
+                                        c_p(addr(pend)), c_p(addr(ns)), c_p(addr(nd)), eng.stream()), "nu_s2_shell_fwd")
+        ctx.eng, ctx.inside = eng, inside
+        ctx.save_for_backward(d, nraw, point, ior_raw, gk, th_raw)
+        ctx.mark_non_differentiable(refr, ok, eta)
+        ctx.set_materialize_grads(False)
+        return refr, ok, eta, nrm, pend, ns, nd
+
+    @staticmethod
+    def backward(ctx, _g0, _g1, _g2, g_nrm, g_pend, g_ns, g_nd):
+        d, nraw, point, ior_raw, gk, th_raw = ctx.saved_tensors
+        M = d.shape[0]
+        g_d, g_n, g_p = torch.zeros_like(d), torch.zeros_like(d), torch.zeros_like(d)
+        g_i, g_k, g_t = torch.zeros_like(gk), torch.zeros_like(gk), torch.zeros_like(gk)
+        cg = lambda t: t.contiguous() if t is not None else None
+        g_nrm, g_pend, g_ns, g_nd = cg(g_nrm), cg(g_pend), cg(g_ns), cg(g_nd)
+        L.check(ctx.eng.lib.nu_s2_shell_bwd(c_p(addr(d)), c_p(addr(nraw)), c_p(addr(point)), c_p(addr(ior_raw)), c_p(addr(gk)),
+                                            c_p(addr(th_raw)), M, 1 if ctx.inside else 0, c_p(addr(g_nrm)), c_p(addr(g_pend)),
+                                            c_p(addr(g_ns)), c_p(addr(g_nd)), c_p(addr(g_d)), c_p(addr(g_n)), c_p(addr(g_p)), c_p(addr(g_i)),
+                                            c_p(addr(g_k)), c_p(addr(g_t)), ctx.eng.stream()), "nu_s2_shell_bwd")
+        return None, g_d, g_n, g_p, g_i, g_k, g_t, None
+
+
+def shell_refract(eng, d, n_raw, point, ior_raw, gk, th_raw, inside):
+    """Thin-shell refraction of the rays that hit the mesh (non-zero-thickness model, network/renderer.py:1692-2032): d [M,3]
+    incoming directions, n_raw [M,3] the interpolated normal as the hit op returns it, point [M,3], ior_raw / th_raw [M] the raw
+    IoR / thickness network outputs, gk [M] interpolated Gaussian curvature.  -> (refracts, tir_ok [M] bool, eta [M], unit normal
+    facing the ray, end point of the incoming segment, next origin, next direction [M,3])."""
+    refr, ok, eta, nrm, pend, ns, nd = _ShellFn.apply(eng, d, n_raw, point, ior_raw, gk, th_raw, bool(inside))
+    return refr.bool(), ok.bool(), eta, nrm, pend, ns, nd
 
 
 class _HitFn(torch.autograd.Function):

@@ -68,10 +68,37 @@ class _IdeFn(torch.autograd.Function):
         return dd, dk.reshape(ctx.kshape)
 
 
+class _EmbedNFn(torch.autograd.Function):
+    """get_embedder(n_freq <= 10, 3) on the generic HIP kernel pair (nu_embed_n_fwd / _bwd)."""
+
+    @staticmethod
+    def forward(ctx, x, n_freq):
+        from . import _lib as L
+        x = x.detach().contiguous()
+        P, nc = x.shape[0], 3 + 6 * n_freq
+        out = torch.empty(P, nc, device=x.device)
+        L.check(L.load().nu_embed_n_fwd(L.ptr(x), P, n_freq, L.ptr(out), nc, L.stream()), "nu_embed_n_fwd")
+        ctx.x, ctx.n_freq = x, n_freq
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        from . import _lib as L
+        x = ctx.x
+        g = dout.contiguous()
+        dx = torch.empty_like(x)
+        L.check(L.load().nu_embed_n_bwd(L.ptr(x), L.ptr(g), g.shape[1], x.shape[0], ctx.n_freq, L.ptr(dx), L.stream()), "nu_embed_n_bwd")
+        return dx, None
+
+
 def embed(x, n_freq):
-    """network/field.py:14-61.  CUDA tensors [P,3] with n_freq <= 6 run on the HIP kernels."""
-    if x.is_cuda and x.dim() == 2 and x.shape[1] == 3 and n_freq <= 6 and x.shape[0] > 0:
-        return _EmbedFn.apply(x, n_freq)
+    """network/field.py:14-61.  CUDA tensors [P,3] run on the HIP kernels (6 frequencies and fewer through the SDF path's
+    embedding, up to 10 through the generic pair)."""
+    if x.is_cuda and x.dim() == 2 and x.shape[1] == 3 and x.shape[0] > 0:
+        if n_freq <= 6:
+            return _EmbedFn.apply(x, n_freq)
+        if n_freq <= 10:
+            return _EmbedNFn.apply(x, n_freq)
     out = [x]
     for k in range(n_freq):
         f = float(2 ** k)

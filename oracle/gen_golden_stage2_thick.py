@@ -89,6 +89,14 @@ def main():
            and not k.endswith('FG_LUT')]                         # the LUT is an asset both sides load from the same file
     manifest = [(k, tuple(sd[k].shape)) for k in own]
     p2 = params_from_manifest(manifest, seed=7044)
+    # the inner SDF decides where the 64 importance samples of the inner segment fall (inverse CDF of NeuS weights): a network of
+    # random weights makes that placement ill-conditioned (1e-7 in an SDF value moves a sample by 1e-2), so the inner SDF and its
+    # variance take the perturbed geometric init of the zero-thickness fixture (a radius-0.5 sphere-like surface) instead
+    inner = randomize_for_parity(init_stage1_params(7044, sphere_direction=True), seed=3)
+    for k, v in inner.items():
+        if k.startswith('sdf_network.'):
+            p2['sdf_network_inner.' + k[len('sdf_network.'):]] = v
+    p2['deviation_network_inner.variance'] = inner['deviation_network.variance']
     for k, v in s1.items():
         p2['stage1_network.' + k] = v
         p2['color_network.stage1_network.' + k] = v

@@ -311,3 +311,63 @@ def train_step(params, cfg, scene, rays_o, rays_d, rgb_gt, step):
         total = total + torch.mean(v)
     out.update(paths=paths, converges=conv, directions=dirs, ior_ratios=iors)
     return total, terms, out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Non-zero-thickness model (network/renderer.py, Stage2Renderer.ray_trace): the thin-shell refraction of the rays that hit
+# ------------------------------------------------------------------------------------------------------------------
+def _unit_eps(x):
+    return x / (torch.linalg.norm(x, dim=-1, keepdim=True) + 0.0001)
+
+
+def shell_refraction(d, n_raw, point, ior_raw, gk, th_raw, inside):
+    """renderer.py:1650-2032 for the rays of one bounce that hit the mesh, restated row-wise (the reference's masked writes
+    `x[mask] = y[mask]` become `torch.where`): d [M,3] incoming directions, n_raw [M,3] the interpolated (unnormalised) normal,
+    point [M,3], ior_raw / th_raw [M] the PRE-sigmoid outputs of IORs_pred / thickness_pred, gk [M] the interpolated Gaussian
+    curvature.  Returns dict(refracts, tir_ok [M] bool, eta [M], normal, end, next_start, next_dir [M,3]); rows of rays that do
+    not refract hold end = point and zeros for next_*.  Differentiable (torch autograd) -- the checker of nu_s2_shell_*."""
+    normal = F.normalize(n_raw, dim=-1)                                           # :1650 / :1659
+    if inside:
+        normal = -normal
+    cos_i = torch.sum(normal * -d, dim=-1, keepdim=True)                          # :1692
+    sin2_i = 1 - cos_i * cos_i
+    r = 1 / (torch.sigmoid(ior_raw)[:, None] * 1.0 + 0.6)                         # :1727-1728
+    inner = torch.full_like(r, 1 / 1.0001)                                        # :1734 (the inner-IoR network is multiplied by 0)
+    ro = inner / r                                                                # :1739
+    th = torch.sigmoid(th_raw)[:, None] * 0.01                                    # :1741-1742
+    if inside:                                                                    # :1748-1751
+        r, ro = 1 / ro, 1 / r
+    refr = ~(r * r * sin2_i > 0.999)                                              # :1762
+    tir = refr.clone()                                                            # :1767
+    sin2_t = sin2_i * r * r                                                       # :1774
+    g = gk[:, None]
+    R = torch.nan_to_num(1 / torch.sqrt(torch.clamp(torch.abs(g), min=0.000001)), 0.1)   # :1792-1793
+    cos_t = torch.sqrt(torch.clamp(1 - sin2_t, min=0.0001))                       # :1800 / :1865
+    positive = (g <= 0) if inside else (g >= 0)                                   # :1802 / :1866
+
+    def chord(c):                                                                 # :1816-1819 / :1833-1836 and their twins
+        d2 = torch.where(positive, c * c - 2 * R * th + th * th, c * c + 2 * R * th + th * th)
+        return torch.abs(c - torch.sqrt(torch.clamp(d2, min=0.0001)))
+    if not inside:
+        d_in = _unit_eps(r * d + (r * cos_i - torch.sqrt(torch.clamp(1 - sin2_t, min=0.0001))) * normal)   # :1811-1812
+        pm, nm = point, normal
+    else:
+        length = chord(R * cos_i)                                                 # :1884-1887 / :1917-1920
+        center = torch.where(positive, point - normal * R, point + normal * R)    # :1908 / :1923
+        pm = point - length * d                                                   # :1910 / :1925
+        nm = _unit_eps(torch.where(positive, pm - center, center - pm))           # :1912 / :1926, :1931
+        cos_im = torch.sum(nm * -d, dim=-1, keepdim=True)                         # :1932
+        x = (1 - cos_im * cos_im) * r * r
+        tir = tir & ~(x > 0.999)                                                  # :1936
+        d_in = _unit_eps(r * d + (r * cos_im - torch.sqrt(torch.clamp(1 - torch.clamp(x, max=0.999), min=0.0001))) * nm)   # :1934-1939
+    length = chord(R * cos_t)                                                     # :1816-1819 / :1943-1946
+    center = torch.where(positive, pm - nm * R, pm + nm * R)                      # :1822 / :1839 / :1949 / :1979
+    next_start = pm + d_in * (length + 0.001)                                     # :1824 / :1951
+    n_after = _unit_eps(torch.where(positive, next_start - center, center - next_start))   # :1826-1827 / :1842-1843
+    cos_i2 = torch.sum(n_after * -d_in, dim=-1, keepdim=True)                     # :1853 / :1995
+    x2 = (1 - cos_i2 * cos_i2) * ro * ro
+    tir = tir & ~(x2 > 0.999)                                                     # :1855 / :2005
+    next_dir = _unit_eps(ro * d_in + (ro * cos_i2 - torch.sqrt(torch.clamp(1 - torch.clamp(x2, max=0.999), min=0.0001))) * n_after)
+    z = torch.zeros_like(point)
+    return dict(refracts=refr[:, 0], tir_ok=tir[:, 0], eta=r[:, 0], normal=normal, end=torch.where(refr, pm, point),
+                next_start=torch.where(refr, next_start, z), next_dir=torch.where(refr, next_dir, z))

@@ -300,7 +300,7 @@ def test_stage2_parameter_hub_hands_each_parameter_its_slice_once_cpu_side():
 
 
 def test_stage2_thick_fixture_is_reproducible_from_its_manifest():
-    """Groundwork for SURVEY 8(f) N3 (the non-zero-thickness stage-2 model, not built yet): the reference-generated fixture
+    """SURVEY 8(f) N3 (the non-zero-thickness stage-2 model; GPU parity in tests/test_stage2_thick_gpu.py): the reference-generated fixture
     tests/golden/stage2_thick_step6000_r24.npz (oracle/gen_golden_stage2_thick.py) carries a parameter manifest + seed instead of
     13 MB of weights, and the per-vertex Gaussian curvature its run used -- PyMesh's attribute in the reference, the angle-defect
     estimate here.  Pin both: the generator reproduces the same values, the product's curvature equals the fixture's."""

@@ -294,3 +294,69 @@ def test_vertex_gaussian_curvature_and_its_interpolation_at_hits(gpu):
     ref = torch.autograd.grad((want[:, 0] * g).sum(), (oh, dh))
     for a, b in zip(got, ref):
         torch.testing.assert_close(a, b, rtol=2e-3, atol=2e-4)
+
+
+@pytest.mark.parametrize("inside", [False, True])
+def test_shell_refraction_matches_the_oracle_restatement(gpu, inside):
+    """nu_s2_shell_* (the non-zero-thickness model's two refractions through the shell, network/renderer.py:1692-2032) against the
+    oracle's row-wise torch restatement in float64: flags, every output and the gradients w.r.t. all 12 inputs per ray.  The
+    inputs cover both curvature signs, shells thicker than the curvature radius allows (the clamped square roots) and total
+    internal reflection at each of the faces."""
+    from nu_nerf_amd import stage2_ops as O
+    from oracle.stage2_oracle import shell_refraction
+    net, n1 = _eng(gpu)
+    torch.manual_seed(11 + int(inside))
+    M = 600
+    d = F.normalize(torch.randn(M, 3), dim=-1)
+    n_raw = F.normalize(-d + 0.8 * torch.randn(M, 3), dim=-1) * (0.5 + torch.rand(M, 1))
+    if inside:
+        n_raw = -n_raw                                             # the mesh normal points out of the object; the op flips it
+    point = 0.5 * torch.randn(M, 3)
+    ior_raw, th_raw = 2.0 * torch.randn(M), 2.0 * torch.randn(M)
+    gk = torch.where(torch.rand(M) < 0.5, 1.0, -1.0) * torch.exp(1.5 * torch.randn(M))     # |g_k| from 1e-2 to 1e2, both signs
+    ins = [t.to(gpu).requires_grad_(True) for t in (d, n_raw, point, ior_raw, gk, th_raw)]
+    refr, ok, eta, nrm, pend, ns, nd = O.shell_refract(n1.eng, *ins, inside)
+    ref_in = [t.double().requires_grad_(True) for t in (d, n_raw, point, ior_raw, gk, th_raw)]
+    ref = shell_refraction(*ref_in, inside)
+    # rays within float rounding of a threshold may flip; they are excluded (and must be rare)
+    same = (refr.cpu() == ref['refracts']) & (ok.cpu() == ref['tir_ok'])
+    assert int((~same).sum()) <= 2
+    assert 0 < int(ref['refracts'].sum()) < M and int((ref['refracts'] & ~ref['tir_ok']).sum()) > 0
+    sel = same & ref['refracts']
+    for got, key in ((nrm, 'normal'), (pend, 'end'), (ns, 'next_start'), (nd, 'next_dir')):
+        torch.testing.assert_close(got.detach().cpu()[sel].double(), ref[key].detach()[sel], rtol=2e-4, atol=2e-5, msg=lambda m, key=key: f"{key}: {m}")
+    torch.testing.assert_close(eta.cpu()[same].double(), ref['eta'].detach()[same], rtol=1e-5, atol=0)
+    lost = same & ~ref['refracts']
+    assert float(nd.detach().cpu()[lost].abs().max()) == 0.0 and torch.equal(pend.detach().cpu()[lost], point[lost])
+    gs = [torch.randn(M, 3) * sel[:, None] for _ in range(4)]
+    got = torch.autograd.grad(sum((o * g.to(gpu)).sum() for o, g in zip((nrm, pend, ns, nd), gs)), ins)
+    want = torch.autograd.grad(sum((ref[k] * g.double()).sum() for k, g in zip(('normal', 'end', 'next_start', 'next_dir'), gs)), ref_in)
+    for a, b, name in zip(got, want, ('d', 'n_raw', 'point', 'ior_raw', 'gk', 'th_raw')):
+        a, b = a.cpu().double(), b
+        a = a * sel.reshape(-1, *([1] * (a.dim() - 1)))
+        scale = float(b.abs().max())
+        # the chord length R cos_t - sqrt((R cos_t)^2 -+ 2 R th + th^2) cancels in fp32 for flat surfaces (large R): its
+        # derivatives w.r.t. curvature and thickness carry that rounding, the fp64 checker does not
+        tol = 3e-3 if name in ('gk', 'th_raw') else 2e-4
+        assert float((a - b).abs().max()) <= tol * scale + 1e-6, (name, float((a - b).abs().max()), scale)
+
+
+@pytest.mark.parametrize("n_freq", [2, 8, 10])
+def test_generic_embedding_matches_the_eager_formula(gpu, n_freq):
+    """nu_embed_n_* (get_embedder(n_freq, 3), field.py:14-61) forward and backward against sin / cos in float64."""
+    from nu_nerf_amd import torch_glue as G
+    torch.manual_seed(n_freq)
+    x = (1.5 * torch.randn(777, 3, device=gpu)).requires_grad_(True)
+    out = G._EmbedNFn.apply(x, n_freq)
+    xr = x.detach().double().requires_grad_(True)
+    cols = [xr]
+    for k in range(n_freq):
+        cols += [torch.sin(xr * 2.0 ** k), torch.cos(xr * 2.0 ** k)]
+    ref = torch.cat(cols, -1)
+    assert out.shape == ref.shape == (777, 3 + 6 * n_freq)
+    # the argument 2^k x is exact in fp32; sinf / cosf of an argument up to ~2^10 carry ~1e-6 absolute error
+    torch.testing.assert_close(out.detach().double(), ref.detach(), rtol=0, atol=5e-6)
+    gcot = torch.randn_like(out)
+    (gx,) = torch.autograd.grad((out * gcot).sum(), x)
+    (rx,) = torch.autograd.grad((ref * gcot.double()).sum(), xr)
+    assert float((gx.double() - rx).abs().max()) <= 2e-5 * float(rx.abs().max())

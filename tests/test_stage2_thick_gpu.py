@@ -1,0 +1,127 @@
+"""GPU parity of the NON-zero-thickness stage-2 renderer (nu_nerf_amd/stage2_thick.py: HIP LBVH + curvature-aware hit op +
+shell-refraction kernel pair + IoR / thickness networks on the HIP GEMMs + the stage-2 segment ops) against the vectors the
+reference's own `network/renderer.py:Stage2Renderer` produced (oracle/gen_golden_stage2_thick.py): shell geometry (segment
+end points, refracted directions, IoR ratios, shading normals), the 64 / 128 / 64 sample layout, per-ray RGB, TIR mask, loss terms
+and the gradient norm of every trained parameter.  The parameters are rebuilt from the fixture's manifest + seed."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import golden
+
+pytestmark = pytest.mark.gpu
+
+
+def build_thick(gpu, g):
+    from nu_nerf_amd.stage2_thick import Stage2Renderer
+    from nu_nerf_amd.params import init_stage1_params, params_from_manifest, randomize_for_parity
+    from nu_nerf_amd.lbvh import icosphere
+    s1 = randomize_for_parity(init_stage1_params(6033, sphere_direction=True), seed=1)
+    shader = {'sphere_direction': True, 'human_light': False, 'light_exp_max': 5.0}
+    s1cfg = {'name': 's1', 'network': 'shape', 'get_mask': False, 'database_name': 'real/x/raw_1024', 'is_nerf': False,
+             'apply_occ_loss': True, 'occ_loss_step': 15000, 'freeze_inv_s_step': 15000, 'zero_thickness': False, 'shader_config': shader}
+    cfg = {'name': 'golden_s2t', 'network': 'stage2', 'get_mask': False, 'database_name': 'real/x/raw_1024', 'is_nerf': False,
+           'shader_config': shader, 'loss': ['eikonal', 'std', 'nerf_render'], 'eikonal_weight': 0.02, 'freeze_inv_s_step': 5000,
+           'stage1_cfg': s1cfg, 'stage1_mesh_arrays': icosphere(3, 0.5)}
+    net = Stage2Renderer(cfg, training=False)
+    keys = list(net.state_dict().keys())
+    assert keys == [str(k) for k in g['state_dict_keys']]
+    manifest = [(str(n), tuple(int(x) for x in str(s).split(',') if x)) for n, s in zip(g['manifest_names'], g['manifest_shapes'])]
+    p2 = params_from_manifest(manifest, int(g['manifest_seed']))
+    inner = randomize_for_parity(init_stage1_params(7044, sphere_direction=True), seed=3)     # as the generator: a well-conditioned
+    for k, v in inner.items():                                                                # inner SDF (perturbed geometric init)
+        if k.startswith('sdf_network.'):
+            p2['sdf_network_inner.' + k[len('sdf_network.'):]] = v
+    p2['deviation_network_inner.variance'] = inner['deviation_network.variance']
+    for k, v in s1.items():
+        p2['stage1_network.' + k] = v
+        p2['color_network.stage1_network.' + k] = v
+        if k.startswith('infinity_far_bkgr.'):
+            p2[k] = v
+    p2 = {k: v for k, v in p2.items() if not k.endswith('FG_LUT')}      # the LUT is the asset both sides load
+    net.load_param_dict(p2)
+    from nu_nerf_amd.params import load_fg_lut
+    with torch.no_grad():
+        lut = torch.from_numpy(load_fg_lut())
+        net.color_network_inner.FG_LUT.copy_(lut.reshape(net.color_network_inner.FG_LUT.shape))
+        net.stage1_network.color_network.FG_LUT.copy_(lut.reshape(net.stage1_network.color_network.FG_LUT.shape))
+    return net.to(gpu), cfg
+
+
+def _step(net, cfg, g, gpu):
+    from nu_nerf_amd.loss import name2loss, total_loss
+    step = int(g['step'])
+    batch = {k: torch.from_numpy(g[k]).to(gpu) for k in ('rays_o', 'rays_d', 'rgbs')}
+    net.zero_grad(set_to_none=True)
+    out = net.train_step_rays(batch, step)
+    total, log = total_loss(out, [name2loss[n](cfg) for n in cfg['loss']], step)
+    total.backward()
+    return out, total, log
+
+
+def _check_gradient_norms(net, g, rtol, atol):
+    named = dict(net.named_parameters())
+    worst = 0.0
+    for n, ref_norm in zip([str(n) for n in g['grad_names']], g['grad_norms']):
+        if ref_norm == 0.0:       # IoRint_pred: multiplied by 0 in the reference (zero gradients there, none here)
+            assert named[n].grad is None or float(named[n].grad.abs().sum()) == 0.0, n
+            continue
+        assert named[n].grad is not None, n
+        got = float(named[n].grad.double().norm())
+        worst = max(worst, abs(got - ref_norm) / ref_norm)
+        assert abs(got - ref_norm) <= rtol * ref_norm + atol, (n, got, ref_norm)
+    names = set(str(n) for n in g['grad_names'])
+    for n, p in named.items():
+        if n not in names:
+            assert p.grad is None or float(p.grad.abs().sum()) == 0.0, n
+    return worst
+
+
+def test_stage2_thick_train_step_vs_reference_golden(gpu):
+    g = golden("stage2_thick_step6000_r24.npz")
+    net, cfg = build_thick(gpu, g)
+    net.nets()                                                       # builds the engines and the LBVH scene
+    np.testing.assert_allclose(net.scene.gaussian_curvatures.cpu().numpy().reshape(-1), g['vertex_gaussian_curvature'].reshape(-1),
+                               rtol=1e-4, atol=1e-5)
+    out, total, log = _step(net, cfg, g, gpu)
+    assert np.array_equal(out['tir_mask'].cpu().numpy(), g['out_tir_mask'])
+    paths = [p.detach().cpu().numpy() for p in out['_paths']]
+    assert [p.shape for p in paths] == [g['path%d' % i].shape for i in range(3)]
+    np.testing.assert_allclose(paths[0], g['path0'], rtol=1e-5, atol=1e-5)
+    d1 = np.abs(paths[1] - g['path1'])
+    assert (d1 < 1e-5).mean() > 0.95 and d1.max() < 5e-3            # inverse-CDF placement against the inner SDF
+    # nodes out to |x| = 1000 along directions that agree to 1e-6: tolerance relative to the node's distance
+    assert np.all(np.abs(paths[2] - g['path2']) <= 3e-6 * np.linalg.norm(g['path2'], axis=-1, keepdims=True) + 1e-5)
+    for i in range(2):
+        np.testing.assert_allclose(out['_ior_ratios'][i].detach().cpu().numpy(), g['ior%d' % i], rtol=1e-5)
+        np.testing.assert_allclose(out['_normals'][i].detach().cpu().numpy(), g['normal_mesh%d' % i], rtol=1e-5, atol=2e-6)
+    for i in range(3):
+        np.testing.assert_allclose(out['_directions'][i].detach().cpu().numpy(), g['dir%d' % i], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(out['ray_rgb'].detach().cpu().numpy(), g['out_ray_rgb'], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(float(out['std'].detach()), float(g['out_std']), rtol=1e-5)
+    for k in g:
+        if k.startswith('term_'):
+            np.testing.assert_allclose(float(torch.mean(log[k[5:]]).detach()), float(g[k]), rtol=5e-4, err_msg=k)
+    np.testing.assert_allclose(float(total.detach()), float(g['total_loss']), rtol=5e-5)
+    # the 64 importance samples of the inner segment move by up to 2.5e-3 on 3 of the 15 rays (fp32 inverse CDF); the smallest
+    # gradients (IoR / thickness heads, norms ~1e-6) follow them at the 1 % level
+    _check_gradient_norms(net, g, rtol=5e-3, atol=2e-8)
+
+    # second pass with the sample placement of the reference run (fractions recovered from the fixture's inner-segment nodes):
+    # everything downstream of the placement then has to agree at fp32 rounding
+    P1 = torch.from_numpy(g['path1']).to(gpu)
+
+    def reference_placement(n2, start, dirs, end):
+        num = torch.linalg.norm(P1 - P1[:, :1], dim=-1)
+        return num / num[:, -1:]
+    net._upsample_inner = reference_placement
+    out, total, log = _step(net, cfg, g, gpu)
+    np.testing.assert_allclose(out['_paths'][1].cpu().numpy(), g['path1'], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(out['ray_rgb'].detach().cpu().numpy(), g['out_ray_rgb'], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(out['gradient_error'].detach().cpu().numpy(), g['out_gradient_error'], rtol=2e-3, atol=1e-6)
+    for k in g:
+        if k.startswith('term_'):
+            np.testing.assert_allclose(float(torch.mean(log[k[5:]]).detach()), float(g[k]), rtol=1e-5, err_msg=k)
+    np.testing.assert_allclose(float(total.detach()), float(g['total_loss']), rtol=1e-5)
+    worst = _check_gradient_norms(net, g, rtol=1e-3, atol=1e-10)
+    print("worst gradient-norm deviation at the reference's sample placement", worst)
