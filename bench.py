@@ -134,8 +134,19 @@ def main_stage2(args):
            'eikonal_weight': 0.02, 'freeze_inv_s_step': 5000,
            'stage1_cfg': {'is_nerf': True, 'apply_occ_loss': True, 'occ_loss_step': 15000, 'freeze_inv_s_step': 15000},
            'stage1_mesh_arrays': icosphere(5, 0.5)}
-    net = Stage2Renderer(cfg, training=False)
-    net.load_param_dict(p2)
+    if args.thick:
+        # the non-zero-thickness model (network/renderer.py:907-2398; every configs/stage2/real/*.yaml): shell refraction with
+        # curvature radius + thickness network, segment samples 64/128/64, SpecInner inner shading
+        from nu_nerf_amd.stage2_thick import Stage2Renderer as ThickRenderer
+        cfg.update({'get_mask': False, 'is_nerf': False})
+        cfg['stage1_cfg'] = dict(cfg['stage1_cfg'], get_mask=False, is_nerf=False)
+        net = ThickRenderer(cfg, training=False)
+        from nu_nerf_amd.params import init_stage2_thick_own_params
+        net.load_param_dict(init_stage2_thick_own_params(7044, net.color_network_inner.cfg))     # fixed seeds: the same step every run
+        net.load_param_dict({'stage1_network.' + k: v for k, v in s1.items()})
+    else:
+        net = Stage2Renderer(cfg, training=False)
+        net.load_param_dict(p2)
     net = net.to(dev)
     losses = [name2loss[n](cfg) for n in ('eikonal', 'std', 'nerf_render')]
     opt = FusedAdam([p for p in net.parameters() if p.requires_grad], lr=1e-3)
@@ -182,8 +193,10 @@ def main_stage2(args):
         "ms_per_step": 1e3 * dt, "median_ms_per_step": float(np.median(step_ms)), "p10_ms_per_step": float(np.percentile(step_ms, 10)),
         "p90_ms_per_step": float(np.percentile(step_ms, 90)), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "stage-2 train step, %d rays, icosphere 20480 faces (HIP LBVH), 3 bounces, segment samples "
-                               "256/128/256, fp32 (BASELINE.json configs[2])" % R,
+        "config": {"workload": ("stage-2 train step, NON-zero-thickness model, %d rays, icosphere 20480 faces (HIP LBVH), 3 shell crossings, "
+                                "segment samples 64/128/64, fp32" % R) if args.thick else
+                               ("stage-2 train step, %d rays, icosphere 20480 faces (HIP LBVH), 3 bounces, segment samples "
+                                "256/128/256, fp32 (BASELINE.json configs[2])" % R),
                    "rays": "object-aimed" if args.object_rays else "Spherepot-shaped cameras",
                    "frac_rays_entering_object": float(np.mean(entered)), "final_loss": float(last.detach()),
                    "max_mem_GB": torch.cuda.max_memory_allocated() / 2 ** 30}}
@@ -220,6 +233,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--workload', default='stage1', choices=['stage1', 'stage2'],
                     help="'stage1' = the headline (BASELINE configs[1]); 'stage2' = configs[2] on one GPU (a parity case, see DESIGN 9)")
+    ap.add_argument('--thick', action='store_true', help="with --workload stage2: the non-zero-thickness model (nu_nerf_amd/stage2_thick.py)")
     ap.add_argument('--object-rays', action='store_true',
                     help='aim every ray at the object: stage 1 -> inner-point share ~0.5 (the shading stack dominates); stage 2 -> all three bounces')
     ap.add_argument('--steps', type=int, default=50)
