@@ -75,7 +75,7 @@ def raw_lights(nets, points, n, refl, rough, sphere=False, pos_freq=6):
     return ol, il, iw
 
 
-def shade(nets, scfg, lut, points, normals, view_dirs, feats, s2=False, is_internal=False, inter_results=False):
+def shade(nets, scfg, lut, points, normals, view_dirs, feats, s2=False, is_internal=False, inter_results=False, aux=None):
     """AppShadingNetwork.forward (field.py:684-777) or, with s2=True, AppShadingNetwork_S2.forward (field.py:909-1010).
     Without inter_results the BRDF mix runs as one HIP kernel pair on the raw head outputs (stage2_ops.shade_combine); the
     eager formulation below it serves the validation images (inter_results=True)."""
@@ -97,6 +97,8 @@ def shade(nets, scfg, lut, points, normals, view_dirs, feats, s2=False, is_inter
             rl = nets.predictor('refrac_light', torch.cat([G.embed(points, rf), G.embed(v, rf)], -1))
             if rl_max < exp_max:     # AppShadingNetwork_SpecInner's refrac_light caps at exp(-0.2) (field.py:1373): clamp the raw head,
                 rl = torch.clamp(rl, max=rl_max)     # the kernel's own min(., exp_max) is then the identity
+        if aux is not None:      # what the occlusion probe of the caller needs (occ_info of field.py:1533-1537)
+            aux.update(occ_raw=iw, reflective=refl)
         color, rc = O.shade_combine(nets.eng, m_raw, ol, il, iw, rl, nov, lut, exp_max, s2=s2, internal=is_internal)
         return color, (rc if s2 else None)
     m = torch.sigmoid(nets.materials(feats, points))

@@ -202,8 +202,12 @@ class Stage2Renderer(nn.Module):
         alpha = 1.0 - torch.exp(-F.softplus(sig) * dists)
         return alpha, G.linear_to_srgb(torch.exp(torch.clamp(rgb, max=5.0)))
 
-    def _shading(self, nets, scfg, lut, points, normals, view_dirs, feats, s2=False, is_internal=False):
-        return shade(nets, scfg, lut, points, normals, view_dirs, feats, s2=s2, is_internal=is_internal)
+    def _shading(self, nets, scfg, lut, points, normals, view_dirs, feats, s2=False, is_internal=False, aux=None):
+        return shade(nets, scfg, lut, points, normals, view_dirs, feats, s2=s2, is_internal=is_internal, aux=aux)
+
+    def _inner_occ_loss(self, n2, x, sdf, grads, dirs, aux, step):
+        """Hook for the inner segment's occlusion loss: the zero-thickness model has none (renderer_zerothick.py:1890-1915)."""
+        return {}
 
     def _upsample_inner(self, n2, start, dirs, end):
         """Segment-1 hierarchical sampling against the inner SDF (renderer_zerothick.py:1742-1760): 64 uniform fractions,
@@ -330,7 +334,10 @@ class Stage2Renderer(nn.Module):
                     if self.cfg['freeze_inv_s_step'] is not None and step < self.cfg['freeze_inv_s_step']:
                         s = s.detach()
                     a = O.neus_alpha(n2.eng, y[:, 0], grads, d_in, len_in, s, cos_anneal_ratio)
-                    c, _ = self._shading(n2, self.color_network_inner.cfg, self.color_network_inner.FG_LUT, x_in, grads, -d_in, y[:, 1:])
+                    aux = {}
+                    c, _ = self._shading(n2, self.color_network_inner.cfg, self.color_network_inner.FG_LUT, x_in, grads, -d_in, y[:, 1:],
+                                         aux=aux)
+                    out.update(self._inner_occ_loss(n2, x_in, y[:, 0], grads, d_in, aux, step))
                     alpha = alpha.index_put((r_i, s_i), a)
                     col = col.index_put((r_i, s_i), torch.cat([c, torch.zeros_like(c[:, :1])], -1))
                     out['std'] = torch.mean(1 / s)

@@ -161,8 +161,29 @@ class Stage2Renderer(_ZeroThickStage2):
 
     def render_segments(self, segs, cos_anneal_ratio=0.0, step=None):
         out = super().render_segments(segs, cos_anneal_ratio=cos_anneal_ratio, step=step)
-        out['loss_occ'] = torch.zeros(1, device=segs[0]['start'].device)   # the inner occlusion probe (:2247-2255) is not built
+        out.setdefault('loss_occ', torch.zeros(1, device=segs[0]['start'].device))
         return out
+
+    def _inner_occ_loss(self, n2, x, sdf, grads, dirs, aux, step, perm=None):
+        """renderer.py:2247-2255 / :1580-1608: L1 between the inner shader's occlusion probability and the hit probability of the
+        reflected ray marched through the INNER SDF (no gradient; the stage-1 probe kernels on the inner engine), at the inner
+        samples close to the inner surface that face the ray; at most `occ_loss_max_pn` of them (random subset, as the reference)."""
+        cfg = self.cfg
+        dev = x.device
+        if not cfg['apply_occ_loss'] or step < cfg['occ_loss_step'] or 'occ_raw' not in aux:
+            return {'loss_occ': torch.zeros(1, device=dev)}
+        with torch.no_grad():
+            mask = (torch.norm(x, dim=-1) < 0.999) & (torch.sum(grads * dirs, -1) < 0) & (torch.abs(sdf) < cfg['occ_sdf_thresh'])
+            idx = torch.nonzero(mask)[:, 0]
+            if idx.numel() > cfg['occ_loss_max_pn']:
+                if perm is None:
+                    perm = torch.randperm(idx.numel(), device=dev)
+                idx = torch.sort(idx[perm[:cfg['occ_loss_max_pn']]])[0]
+            if idx.numel() == 0:
+                return {'loss_occ': torch.zeros(1, device=dev)}
+            occ_gt = n2.eng.occ_probe(x.detach()[idx], aux['reflective'].detach()[idx])
+        occ_prob = aux['occ_raw'][idx] * 0.5 + 0.5
+        return {'loss_occ': torch.nn.functional.l1_loss(occ_prob.reshape(-1, 1), occ_gt.reshape(-1, 1))}
 
     def train_step_rays(self, batch, step):
         """renderer.py:1315-1330 on an explicit ray batch (`mask` = batch['masks'] or ones)."""

@@ -5,8 +5,9 @@ The OptiX / PyMesh-backed `Scene` is replaced by a brute-force scene with the sa
 "vertex_gaussian_curvature" (absent here) by the angle-defect estimate of nu_nerf_amd/lbvh.py -- that input is therefore NOT pinned
 by the reference, everything computed from it is.  Parameters: the stage-1 part from nu_nerf_amd/params.py, every other state-dict
 entry from `nu_nerf_amd.params.params_from_manifest` (names + shapes + seed -> values), so the fixture carries the manifest and
-the product can rebuild the same weights.  Output: tests/golden/stage2_thick_step6000_r24.npz (inputs, per-ray outputs, TIR mask,
-segment geometry, loss terms, gradient norms of every trained parameter).  The product side of this model is not built yet."""
+the product can rebuild the same weights.  Output: tests/golden/stage2_thick_step6000_r24.npz and ..._step25000_r24.npz (the latter
+past `occ_loss_step`, with the inner occlusion loss in the total): inputs, per-ray outputs, TIR mask, segment geometry, loss terms,
+gradient norms of every trained parameter.  The product is nu_nerf_amd/stage2_thick.py (tests/test_stage2_thick_gpu.py)."""
 import os
 import sys
 import tempfile
@@ -19,7 +20,7 @@ sys.path.insert(0, REPO)
 from oracle.gen_golden import install_shims, to_t, OUT   # noqa: E402
 
 
-def main():
+def main(step=6000, loss_names=('eikonal', 'std', 'nerf_render')):
     install_shims()
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -70,7 +71,7 @@ def main():
         yaml.safe_dump(s1cfg, fh)
     cfg = {'name': 'golden_s2t', 'network': 'stage2', 'get_mask': False, 'database_name': 'real/x/raw_1024', 'is_nerf': False,
            'shader_config': {'sphere_direction': True, 'human_light': False, 'light_exp_max': 5.0},
-           'loss': ['eikonal', 'std', 'nerf_render'], 'eikonal_weight': 0.02, 'freeze_inv_s_step': 5000,
+           'loss': list(loss_names), 'eikonal_weight': 0.02, 'freeze_inv_s_step': 5000, 'occ_loss_step': 20000,
            'stage1_ckpt_dir': os.path.join(tmp, 's1.pth'), 'stage1_cfg_dir': os.path.join(tmp, 's1.yaml'),
            'stage1_mesh_dir': 'unused.ply'}
     net = rr.Stage2Renderer(cfg, training=False)
@@ -109,7 +110,7 @@ def main():
     print("own entries", len(own), "missing", missing[:5])
     print("load:", net.load_state_dict(to_t({k: p2[k] for k in keys}), strict=True))
     losses = [name2loss[n](cfg) for n in cfg['loss']]
-    R, step = 24, 6000
+    R = 24
     rays = make_object_rays(R, seed=500)
     o, d, rgbs = (torch.from_numpy(rays[k]) for k in ('rays_o', 'rays_d', 'rgbs'))
     dn = torch.nn.functional.normalize(d, dim=-1)
@@ -154,7 +155,8 @@ def main():
     res['grad_names'] = np.asarray(sorted(gn.keys()))
     res['grad_norms'] = np.asarray([float(gn[k].double().norm()) for k in sorted(gn.keys())])
     os.makedirs(OUT, exist_ok=True)
-    np.savez_compressed(os.path.join(OUT, "stage2_thick_step6000_r24.npz"), **res)
+    res['out_loss_occ'] = outputs['loss_occ'].detach().numpy()
+    np.savez_compressed(os.path.join(OUT, "stage2_thick_step%d_r24.npz" % step), **res)
     print("loss", float(total), {k: float(v) for k, v in res.items() if k.startswith('term_')}, "n grads", len(gn),
           "rgb range", float(outputs['ray_rgb'].min()), float(outputs['ray_rgb'].max()))
     print("params without grad:", sorted(set(n.split('.')[0] for n, p in net.named_parameters() if p.grad is None)))
@@ -162,3 +164,5 @@ def main():
 
 if __name__ == "__main__":
     main()
+    # past occ_loss_step and freeze_inv_s_step: the inner occlusion probe (renderer.py:2247-2255) in the loss, trainable inner variance
+    main(step=25000, loss_names=('eikonal', 'std', 'nerf_render', 'occ'))

@@ -12,7 +12,7 @@ from helpers import golden
 pytestmark = pytest.mark.gpu
 
 
-def build_thick(gpu, g):
+def build_thick(gpu, g, losses=('eikonal', 'std', 'nerf_render')):
     from nu_nerf_amd.stage2_thick import Stage2Renderer
     from nu_nerf_amd.params import init_stage1_params, params_from_manifest, randomize_for_parity
     from nu_nerf_amd.lbvh import icosphere
@@ -21,7 +21,7 @@ def build_thick(gpu, g):
     s1cfg = {'name': 's1', 'network': 'shape', 'get_mask': False, 'database_name': 'real/x/raw_1024', 'is_nerf': False,
              'apply_occ_loss': True, 'occ_loss_step': 15000, 'freeze_inv_s_step': 15000, 'zero_thickness': False, 'shader_config': shader}
     cfg = {'name': 'golden_s2t', 'network': 'stage2', 'get_mask': False, 'database_name': 'real/x/raw_1024', 'is_nerf': False,
-           'shader_config': shader, 'loss': ['eikonal', 'std', 'nerf_render'], 'eikonal_weight': 0.02, 'freeze_inv_s_step': 5000,
+           'shader_config': shader, 'loss': list(losses), 'eikonal_weight': 0.02, 'freeze_inv_s_step': 5000, 'occ_loss_step': 20000,
            'stage1_cfg': s1cfg, 'stage1_mesh_arrays': icosphere(3, 0.5)}
     net = Stage2Renderer(cfg, training=False)
     keys = list(net.state_dict().keys())
@@ -68,7 +68,8 @@ def _check_gradient_norms(net, g, rtol, atol):
             continue
         assert named[n].grad is not None, n
         got = float(named[n].grad.double().norm())
-        worst = max(worst, abs(got - ref_norm) / ref_norm)
+        if ref_norm > 1e-6:
+            worst = max(worst, abs(got - ref_norm) / ref_norm)
         assert abs(got - ref_norm) <= rtol * ref_norm + atol, (n, got, ref_norm)
     names = set(str(n) for n in g['grad_names'])
     for n, p in named.items():
@@ -77,9 +78,13 @@ def _check_gradient_norms(net, g, rtol, atol):
     return worst
 
 
-def test_stage2_thick_train_step_vs_reference_golden(gpu):
-    g = golden("stage2_thick_step6000_r24.npz")
-    net, cfg = build_thick(gpu, g)
+@pytest.mark.parametrize("fixture,losses", [
+    ("stage2_thick_step6000_r24.npz", ('eikonal', 'std', 'nerf_render')),
+    # past occ_loss_step: the inner occlusion probe (renderer.py:2247-2255) is part of the total loss
+    ("stage2_thick_step25000_r24.npz", ('eikonal', 'std', 'nerf_render', 'occ'))])
+def test_stage2_thick_train_step_vs_reference_golden(gpu, fixture, losses):
+    g = golden(fixture)
+    net, cfg = build_thick(gpu, g, losses)
     net.nets()                                                       # builds the engines and the LBVH scene
     np.testing.assert_allclose(net.scene.gaussian_curvatures.cpu().numpy().reshape(-1), g['vertex_gaussian_curvature'].reshape(-1),
                                rtol=1e-4, atol=1e-5)
@@ -99,6 +104,9 @@ def test_stage2_thick_train_step_vs_reference_golden(gpu):
         np.testing.assert_allclose(out['_directions'][i].detach().cpu().numpy(), g['dir%d' % i], rtol=1e-5, atol=2e-6)
     np.testing.assert_allclose(out['ray_rgb'].detach().cpu().numpy(), g['out_ray_rgb'], rtol=1e-4, atol=1e-5)
     np.testing.assert_allclose(float(out['std'].detach()), float(g['out_std']), rtol=1e-5)
+    if 'occ' in losses:
+        assert float(g['out_loss_occ']) > 0.1
+        np.testing.assert_allclose(float(out['loss_occ'].detach()), float(g['out_loss_occ']), rtol=2e-3)
     for k in g:
         if k.startswith('term_'):
             np.testing.assert_allclose(float(torch.mean(log[k[5:]]).detach()), float(g[k]), rtol=5e-4, err_msg=k)
@@ -123,5 +131,5 @@ def test_stage2_thick_train_step_vs_reference_golden(gpu):
         if k.startswith('term_'):
             np.testing.assert_allclose(float(torch.mean(log[k[5:]]).detach()), float(g[k]), rtol=1e-5, err_msg=k)
     np.testing.assert_allclose(float(total.detach()), float(g['total_loss']), rtol=1e-5)
-    worst = _check_gradient_norms(net, g, rtol=1e-3, atol=1e-10)
+    worst = _check_gradient_norms(net, g, rtol=1e-3, atol=2e-9)      # (norms of 2e-8 are sums of cancelling fp32 terms)
     print("worst gradient-norm deviation at the reference's sample placement", worst)
