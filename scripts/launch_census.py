@@ -1,0 +1,85 @@
+"""Which ops the device kernels of one stage-2 step belong to: one step under torch.profiler, kernels attributed to the CPU op
+(aten op or autograd Function) whose time range contains their launch -- library launches through ctypes count towards the
+Function that made them.  (Python stacks are requested but this torch build returns none for these events; the by-site table
+then has one row.)  Usage: python scripts/launch_census.py [thick|zero] [rays]"""
+import collections
+import os
+import re
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+from nu_nerf_amd.params import init_stage1_params, init_stage2_params, init_stage2_thick_own_params  # noqa: E402
+from nu_nerf_amd.lbvh import icosphere  # noqa: E402
+from nu_nerf_amd.synthetic import make_rays  # noqa: E402
+from nu_nerf_amd.loss import name2loss, total_loss  # noqa: E402
+from nu_nerf_amd.train_glue import FusedAdam  # noqa: E402
+
+which = sys.argv[1] if len(sys.argv) > 1 else 'thick'
+R = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+dev = torch.device('cuda:0')
+s1 = init_stage1_params(6033)
+cfg = {'name': 's2', 'network': 'stage2', 'is_nerf': True, 'shader_config': {'sphere_direction': False, 'human_light': False},
+       'eikonal_weight': 0.02, 'freeze_inv_s_step': 5000, 'get_mask': False,
+       'stage1_cfg': {'is_nerf': True, 'apply_occ_loss': True, 'occ_loss_step': 15000, 'freeze_inv_s_step': 15000, 'get_mask': False},
+       'stage1_mesh_arrays': icosphere(5, 0.5)}
+if which == 'thick':
+    from nu_nerf_amd.stage2_thick import Stage2Renderer
+    net = Stage2Renderer(cfg, training=False)
+    net.load_param_dict(init_stage2_thick_own_params(7044, net.color_network_inner.cfg))
+    net.load_param_dict({'stage1_network.' + k: v for k, v in s1.items()})
+else:
+    from nu_nerf_amd.stage2 import Stage2Renderer
+    net = Stage2Renderer(cfg, training=False)
+    p2 = init_stage2_params(6033, 7044, {'sphere_direction': False})
+    for k, v in s1.items():
+        p2['stage1_network.' + k] = v
+        p2['color_network.stage1_network.' + k] = v
+    net.load_param_dict(p2)
+net = net.to(dev)
+losses = [name2loss[n](cfg) for n in ('eikonal', 'std', 'nerf_render')]
+opt = FusedAdam([p for p in net.parameters() if p.requires_grad], lr=1e-3)
+pool = {k: torch.from_numpy(v).to(dev) for k, v in make_rays(R * 4, seed=6033).items() if k in ('rays_o', 'rays_d', 'rgbs')}
+
+
+def step(i):
+    b = {k: v[i * R:(i + 1) * R] for k, v in pool.items()}
+    opt.zero_grad(set_to_none=True)
+    out = net.train_step_rays(b, 6000 + i)
+    total, _ = total_loss(out, losses, 6000 + i)
+    total.backward()
+    opt.step()
+
+
+for i in range(3):
+    step(i)
+torch.cuda.synchronize()
+from torch.profiler import profile, ProfilerActivity  # noqa: E402
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+    step(3)
+    torch.cuda.synchronize()
+by_site, by_op = collections.Counter(), collections.Counter()
+total = 0
+for e in prof.events():
+    nk = len(e.kernels)
+    if nk == 0:
+        continue
+    total += nk
+    site = 'autograd engine / no python frame'
+    for fr in e.stack:
+        m = re.search(r'(nu_nerf_amd/\w+\.py|bench\.py|launch_census\.py)\((\d+)\): (\w+)', fr)
+        if m:
+            site = '%s:%s %s' % m.groups()
+            break
+    by_site[site] += nk
+    by_op[e.name] += nk
+print("torch-launched device kernels in the step:", total)
+print("---- by call site")
+for k, v in by_site.most_common(45):
+    print("%5d  %s" % (v, k))
+print("---- by op")
+for k, v in by_op.most_common(25):
+    print("%5d  %s" % (v, k))
