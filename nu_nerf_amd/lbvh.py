@@ -123,16 +123,20 @@ class Scene:
 
 
 def dintersect_hip(scene, eng, origin, direction, curvature=False):
-    """Scene.Dintersect on the HIP kernels (nu_lbvh_trace + nu_s2_hit_fwd/_bwd): -> dict(n, point, t, faces_ind[, g_k]), hitted
-    mask.  curvature=True adds the interpolated per-vertex Gaussian curvature (DiffRender.py:116, Intersection.g_k)."""
+    """Scene.Dintersect on the HIP kernels (nu_lbvh_trace + nu_s2_hit_fwd/_bwd): -> dict(n, point, t, faces_ind, hit_idx, d
+    [, g_k]), hitted mask.  curvature=True adds the interpolated per-vertex Gaussian curvature (DiffRender.py:116,
+    Intersection.g_k).  ONE device -> host read (the number of hits): the hit rows are gathered by index, `hit_idx` and the
+    gathered directions `d` are handed on so that callers need not ask again."""
     from . import stage2_ops as O
     faces_ind, hitted = scene.intersect(origin, direction)
-    fi = faces_ind[hitted]
+    hit_idx = hitted.nonzero().flatten()
+    fi = faces_ind.index_select(0, hit_idx)
+    o, d = origin.index_select(0, hit_idx), direction.index_select(0, hit_idx)
     if curvature:
-        point, n, t, gk = O.hit(eng, scene, origin[hitted], direction[hitted], fi, curvature=True)
-        return dict(n=n, point=point, t=t, faces_ind=fi, g_k=gk), hitted
-    point, n, t = O.hit(eng, scene, origin[hitted], direction[hitted], fi)
-    return dict(n=n, point=point, t=t, faces_ind=fi), hitted
+        point, n, t, gk = O.hit(eng, scene, o, d, fi, curvature=True)
+        return dict(n=n, point=point, t=t, faces_ind=fi, hit_idx=hit_idx, d=d, g_k=gk), hitted
+    point, n, t = O.hit(eng, scene, o, d, fi)
+    return dict(n=n, point=point, t=t, faces_ind=fi, hit_idx=hit_idx, d=d), hitted
 
 
 def icosphere(subdiv=2, radius=0.5):

@@ -260,19 +260,18 @@ class Stage2Renderer(nn.Module):
             N = start.shape[0]
             S1 = 128 if b == 1 else 256
             inter, hit = dintersect_hip(scene, n1.eng, start, dirs)            # LBVH closest hit + differentiable hit
-            hit_idx = hit.nonzero().flatten()
-            miss_idx = (~hit).nonzero().flatten()
+            hit_idx, d_hit = inter['hit_idx'], inter['d']                      # (one host read for the hit set, shared)
+            miss_idx = (~hit).nonzero().flatten() if (b != 1 and hit_idx.numel() < N) else hit_idx[:0]
             point = inter['point']
             normal = F.normalize(inter['n'], dim=-1)
             if inside:
                 normal = -normal
             ior = torch.sigmoid(n2.ior(G.embed(point, 6)))                     # IoRNetwork on the HIP GEMMs
-            d_hit = dirs.index_select(0, hit_idx)
             refracts, eta, next_dir, next_start = O.refract(n1.eng, d_hit, normal, ior, point, not inside)
             keep = refracts.nonzero().flatten()
             cont_idx = hit_idx.index_select(0, keep)
-            lost = hit_idx.index_select(0, (~refracts).nonzero().flatten())
-            valid[root.index_select(0, lost)] = False
+            root_hit = root.index_select(0, hit_idx)
+            valid[root_hit] = valid.index_select(0, root_hit) & refracts       # (no index list of the lost rays: no host read)
             # ---- sample nodes of this segment: x_j = start + v z_j ----
             v = (start + dirs * 4.5) - start                   # rounded like the reference's `end - start`
             z = torch.linspace(0, 1, S1, device=dev)[None, :].repeat(N, 1)

@@ -141,8 +141,8 @@ class _RefractFn(torch.autograd.Function):
         d, nrm, ior, point = (t.detach().contiguous() for t in (d, nrm, ior, point))
         M = d.shape[0]
         dev = d.device
-        flag = torch.zeros(M, dtype=torch.uint8, device=dev)
-        eta, nd, ns = torch.zeros(M, device=dev), torch.zeros(M, 3, device=dev), torch.zeros(M, 3, device=dev)
+        flag = torch.empty(M, dtype=torch.uint8, device=dev)             # (the kernels write every row of every output)
+        eta, nd, ns = torch.empty(M, device=dev), torch.empty(M, 3, device=dev), torch.empty(M, 3, device=dev)
         L.check(eng.lib.nu_s2_refract_fwd(c_p(addr(d)), c_p(addr(nrm)), c_p(addr(ior)), c_p(addr(point)), M, 1 if outside else 0,
                                           c_p(addr(flag)), c_p(addr(eta)), c_p(addr(nd)), c_p(addr(ns)), eng.stream()), "nu_s2_refract_fwd")
         ctx.eng, ctx.outside = eng, outside
@@ -155,7 +155,7 @@ class _RefractFn(torch.autograd.Function):
     def backward(ctx, _gflag, g_eta, g_nd, g_ns):
         d, nrm, ior = ctx.saved_tensors
         M = d.shape[0]
-        dd, dn, dior, dpoint = torch.zeros_like(d), torch.zeros_like(nrm), torch.zeros_like(ior), torch.zeros_like(d)
+        dd, dn, dior, dpoint = torch.empty_like(d), torch.empty_like(nrm), torch.empty_like(ior), torch.empty_like(d)
         cg = lambda t: t.contiguous() if t is not None else None
         g_eta, g_nd, g_ns = cg(g_eta), cg(g_nd), cg(g_ns)
         L.check(ctx.eng.lib.nu_s2_refract_bwd(c_p(addr(d)), c_p(addr(nrm)), c_p(addr(ior)), M, 1 if ctx.outside else 0, c_p(addr(g_nd)),
@@ -176,9 +176,9 @@ class _ShellFn(torch.autograd.Function):
     def forward(ctx, eng, d, nraw, point, ior_raw, gk, th_raw, inside):
         d, nraw, point, ior_raw, gk, th_raw = (t.detach().contiguous() for t in (d, nraw, point, ior_raw, gk, th_raw))
         M, dev = d.shape[0], d.device
-        refr, ok = torch.zeros(M, dtype=torch.uint8, device=dev), torch.zeros(M, dtype=torch.uint8, device=dev)
-        eta = torch.zeros(M, device=dev)
-        nrm, pend, ns, nd = (torch.zeros(M, 3, device=dev) for _ in range(4))
+        refr, ok = (torch.empty(M, dtype=torch.uint8, device=dev) for _ in range(2))   # (the kernels write every row of every output)
+        eta = torch.empty(M, device=dev)
+        nrm, pend, ns, nd = (torch.empty(M, 3, device=dev) for _ in range(4))
         L.check(eng.lib.nu_s2_shell_fwd(c_p(addr(d)), c_p(addr(nraw)), c_p(addr(point)), c_p(addr(ior_raw)), c_p(addr(gk)), c_p(addr(th_raw)),
                                         M, 1 if inside else 0, c_p(addr(refr)), c_p(addr(ok)), c_p(addr(eta)), c_p(addr(nrm)),
                                         c_p(addr(pend)), c_p(addr(ns)), c_p(addr(nd)), eng.stream()), "nu_s2_shell_fwd")
@@ -192,8 +192,8 @@ class _ShellFn(torch.autograd.Function):
     def backward(ctx, _g0, _g1, _g2, g_nrm, g_pend, g_ns, g_nd):
         d, nraw, point, ior_raw, gk, th_raw = ctx.saved_tensors
         M = d.shape[0]
-        g_d, g_n, g_p = torch.zeros_like(d), torch.zeros_like(d), torch.zeros_like(d)
-        g_i, g_k, g_t = torch.zeros_like(gk), torch.zeros_like(gk), torch.zeros_like(gk)
+        g_d, g_n, g_p = (torch.empty_like(d) for _ in range(3))
+        g_i, g_k, g_t = (torch.empty_like(gk) for _ in range(3))
         cg = lambda t: t.contiguous() if t is not None else None
         g_nrm, g_pend, g_ns, g_nd = cg(g_nrm), cg(g_pend), cg(g_ns), cg(g_nd)
         L.check(ctx.eng.lib.nu_s2_shell_bwd(c_p(addr(d)), c_p(addr(nraw)), c_p(addr(point)), c_p(addr(ior_raw)), c_p(addr(gk)),
@@ -218,7 +218,7 @@ class _HitFn(torch.autograd.Function):
         o, d = o.detach().contiguous(), d.detach().contiguous()
         M = o.shape[0]
         point, nrm, t = torch.empty_like(o), torch.empty_like(o), torch.empty(M, device=o.device)
-        gk = torch.zeros(M, device=o.device)
+        gk = torch.empty(M, device=o.device) if vcurv is not None else torch.zeros(M, device=o.device)
         L.check(eng.lib.nu_s2_hit_fwd(c_p(addr(o)), c_p(addr(d)), c_p(addr(face)), c_p(addr(verts)), c_p(addr(vnrm)), c_p(addr(faces)), M,
                                       c_p(addr(point)), c_p(addr(nrm)), c_p(addr(t)), c_p(addr(vcurv)), c_p(addr(gk)), eng.stream()),
                 "nu_s2_hit_fwd")
@@ -232,7 +232,7 @@ class _HitFn(torch.autograd.Function):
         o, d = ctx.saved_tensors
         face, verts, vnrm, faces, vcurv = ctx.consts
         M = o.shape[0]
-        g_o, g_d = torch.zeros_like(o), torch.zeros_like(d)
+        g_o, g_d = torch.empty_like(o), torch.empty_like(d)
         cg = lambda t: t.contiguous() if t is not None else None
         g_point, g_nrm, g_t, g_gk = cg(g_point), cg(g_nrm), cg(g_t), cg(g_gk)
         L.check(ctx.eng.lib.nu_s2_hit_bwd(c_p(addr(o)), c_p(addr(d)), c_p(addr(face)), c_p(addr(verts)), c_p(addr(vnrm)), c_p(addr(faces)), M,

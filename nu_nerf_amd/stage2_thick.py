@@ -116,41 +116,40 @@ class Stage2Renderer(_ZeroThickStage2):
         for b in range(3):
             inside = b % 2 == 1
             inter, hit = dintersect_hip(scene, n1.eng, start, dirs, curvature=True)
-            if b == 1 and not bool(hit.all()):
+            hit_idx, d_hit = inter['hit_idx'], inter['d']
+            all_hit = hit_idx.numel() == start.shape[0]
+            if b == 1 and not all_hit:
                 # inside the object without an exit (:1660-1670): the ray leaves the paths; its first surface is not shaded either
-                stay = hit.nonzero().flatten()
+                stay = hit_idx
                 prev = segs[0]
                 prev['cont_idx'] = prev['cont_idx'].index_select(0, stay)
                 prev['normal'], prev['eta'] = prev['normal'].index_select(0, stay), prev['eta'].index_select(0, stay)
                 prev['n_cont'] = int(stay.numel())
                 start, dirs, root = start.index_select(0, stay), dirs.index_select(0, stay), root.index_select(0, stay)
                 hit = torch.ones(stay.numel(), dtype=torch.bool, device=dev)
+                hit_idx, all_hit = torch.arange(stay.numel(), device=dev), True
                 if stay.numel() == 0:
                     break
             N = start.shape[0]
-            hit_idx = hit.nonzero().flatten()
-            miss_idx = (~hit).nonzero().flatten()
             point = inter['point']
             pe = G.embed(point, 6)
-            d_hit = dirs.index_select(0, hit_idx)
             refracts, tir_ok, eta, normal, p_end, next_start, next_dir = O.shell_refract(
                 n1.eng, d_hit, inter['n'], point, n2.ior(pe), inter['g_k'], n2.thickness(pe), inside)
             keep = refracts.nonzero().flatten()
             cont_idx = hit_idx.index_select(0, keep)
-            valid[root.index_select(0, hit_idx.index_select(0, (~tir_ok).nonzero().flatten()))] = False
+            root_hit = root.index_select(0, hit_idx)
+            valid[root_hit] = valid.index_select(0, root_hit) & tir_ok      # (no index list of the lost rays: no host read)
             # ---- sample nodes x_j = start + v z_j: 64 (128 inside the object) ----
             S1 = 128 if b == 1 else 64
-            z = torch.linspace(0, 1, S1, device=dev)[None, :].repeat(N, 1)
-            v = dirs * 4.5
-            if hit_idx.numel() > 0:
-                s_hit = start.index_select(0, hit_idx)
-                v = v.index_copy(0, hit_idx, p_end - s_hit)
-                if b == 1:                                     # hierarchical sampling against the inner SDF (:2081-2099)
-                    with torch.no_grad():
-                        z[hit_idx] = self._upsample_inner(n2, s_hit.detach(), d_hit.detach(), p_end.detach())
-            if miss_idx.numel() > 0:                           # rays that leave the scene: fixed inverse-depth nodes (:2101-2119)
-                z[miss_idx] = z_far[None, :]
-                v = v.index_copy(0, miss_idx, dirs.index_select(0, miss_idx))
+            if b == 1:                                         # every ray of the inner segment hit (see above)
+                with torch.no_grad():                          # hierarchical sampling against the inner SDF (:2081-2099)
+                    z = self._upsample_inner(n2, start.detach(), dirs.detach(), p_end.detach())
+                v = p_end - start
+            else:
+                # hits: uniform fractions of (end - start); rays that leave the scene: fixed inverse-depth nodes along the
+                # direction (:2101-2119) -- chosen per row with `where`, no index list of the misses
+                z = torch.where(hit[:, None], torch.linspace(0, 1, S1, device=dev)[None, :], z_far[None, :])
+                v = dirs if hit_idx.numel() == 0 else dirs.index_copy(0, hit_idx, p_end - start.index_select(0, hit_idx))
             segs.append(dict(start=start, dirs=dirs, v=v, z=z, cont_idx=cont_idx, n_cont=int(cont_idx.numel()),
                              normal=normal.index_select(0, keep), eta=eta.index_select(0, keep)[:, None], inside=b != 0))
             if cont_idx.numel() == 0:

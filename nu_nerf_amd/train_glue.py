@@ -69,13 +69,63 @@ class FusedAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
         self._lib = None
-        self._descs = None
+        self._plans = {}          # group index -> launch plan for the current set of parameters with gradients
+        self._steps = None        # one CPU vector holding every parameter's step count; state[p]['step'] is a 0-d view of it
 
     def _library(self):
         if self._lib is None:
             self._lib = L.load()
             assert self._lib.nu_adam_desc_size() == ctypes.sizeof(AdamDesc), "AdamDesc ABI mismatch"
         return self._lib
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._plans.clear()       # new state tensors: pointers and step counts are read again
+        self._steps = None
+
+    def _build_plan(self, gi, ps):
+        """Everything about a group's launch that does not change from step to step: validation, lazily created Adam state,
+        the step counts gathered into ONE CPU vector (state[p]['step'] stays a tensor, as torch.optim.Adam keeps it, but becomes
+        a view of that vector -- one vector add per step instead of one tensor op per parameter), and per distinct step count a
+        descriptor table with the parameter / moment pointers filled in (parameters that start receiving gradients later, e.g.
+        deviation_network.variance at freeze_inv_s_step, or that were restored with their own counts form their own bucket;
+        all counts advance together, so the buckets are static)."""
+        if self._steps is None:
+            cap = sum(len(g['params']) for g in self.param_groups)
+            self._steps = torch.zeros(max(cap, 1))
+            self._slot = {}
+        buckets = {}
+        for p in ps:
+            L.require_cuda(p)
+            if p.dtype != torch.float32 or not p.is_contiguous():
+                raise TypeError("FusedAdam: contiguous fp32 parameters only")
+            st = self.state[p]
+            if len(st) == 0:
+                st['step'] = torch.tensor(0.0)
+                st['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            slot = self._slot.setdefault(p, len(self._slot))
+            if slot >= self._steps.numel():       # add_param_group after the first step
+                grown = torch.zeros(2 * slot + 1)
+                grown[:self._steps.numel()] = self._steps
+                self._steps = grown
+                self._plans.clear()
+                for q, sl in self._slot.items():
+                    if q in self.state and 'step' in self.state[q]:
+                        self.state[q]['step'] = self._steps[sl]
+            view = self._steps[slot]
+            if st['step'] is not view and st['step'].data_ptr() != view.data_ptr():
+                view.copy_(st['step'].to(torch.float32))
+            st['step'] = view
+            buckets.setdefault(int(view), []).append((p, st, slot))
+        plan = []
+        for count, items in buckets.items():
+            descs = (AdamDesc * len(items))()
+            for d, (p, st, _) in zip(descs, items):
+                d.p, d.m, d.v, d.n = p.data_ptr(), st['exp_avg'].data_ptr(), st['exp_avg_sq'].data_ptr(), p.numel()
+            plan.append({'count': count, 'params': [p for p, _, _ in items], 'descs': descs,
+                         'slots': torch.tensor([sl for _, _, sl in items], dtype=torch.long)})
+        return {'sig': tuple(id(p) for p in ps), 'buckets': plan}
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -84,39 +134,27 @@ class FusedAdam(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         lib = self._library()
-        for group in self.param_groups:
+        for gi, group in enumerate(self.param_groups):
             ps = [p for p in group['params'] if p.grad is not None]
             if not ps:
                 continue
-            # Adam's bias correction is per parameter (torch.optim.Adam keeps one step count per tensor): parameters that
-            # start receiving gradients later (deviation_network.variance at freeze_inv_s_step) or that were restored from a
-            # checkpoint with their own counts form their own bucket -- one launch per distinct step count (normally one).
-            buckets = {}
-            keep = []               # contiguous copies of gradients stay alive until every launch is enqueued
-            for p in ps:
-                L.require_cuda(p)
-                if p.dtype != torch.float32 or not p.is_contiguous():
-                    raise TypeError("FusedAdam: contiguous fp32 parameters only")
-                st = self.state[p]
-                if len(st) == 0:
-                    st['step'] = torch.tensor(0.0)
-                    st['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                    st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                st['step'] += 1
-                g = p.grad
-                if not g.is_contiguous():
-                    g = g.contiguous()
-                    keep.append(g)
-                buckets.setdefault(int(st['step']), []).append((p, g, st))
+            plan = self._plans.get(gi)
+            if plan is None or plan['sig'] != tuple(id(p) for p in ps):
+                plan = self._plans[gi] = self._build_plan(gi, ps)
             b1, b2 = group['betas']
-            for step_count, items in buckets.items():
-                if self._descs is None or len(self._descs) < len(items):
-                    self._descs = (AdamDesc * max(len(items), 256))()
-                for i, (p, g, st) in enumerate(items):
-                    d = self._descs[i]
-                    d.p, d.g, d.m, d.v, d.n = p.data_ptr(), g.data_ptr(), st['exp_avg'].data_ptr(), st['exp_avg_sq'].data_ptr(), p.numel()
-                L.check(lib.nu_adam_step(self._descs, len(items), ctypes.c_double(group['lr']), ctypes.c_double(b1),
-                                         ctypes.c_double(b2), ctypes.c_double(group['eps']), step_count, L.stream()), "nu_adam_step")
+            keep = []               # contiguous copies of gradients stay alive until every launch is enqueued
+            for bk in plan['buckets']:
+                descs = bk['descs']
+                for d, p in zip(descs, bk['params']):
+                    g = p.grad
+                    if not g.is_contiguous():
+                        g = g.contiguous()
+                        keep.append(g)
+                    d.g = g.data_ptr()
+                bk['count'] += 1
+                self._steps[bk['slots']] += 1
+                L.check(lib.nu_adam_step(descs, len(descs), ctypes.c_double(group['lr']), ctypes.c_double(b1),
+                                         ctypes.c_double(b2), ctypes.c_double(group['eps']), bk['count'], L.stream()), "nu_adam_step")
             del keep
         return loss
 

@@ -57,6 +57,41 @@ def step(i):
 for i in range(3):
     step(i)
 torch.cuda.synchronize()
+import time  # noqa: E402
+rows = []
+for i in range(8):
+    b = {k: v[(i % 4) * R:((i % 4) + 1) * R] for k, v in pool.items()}
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    opt.zero_grad(set_to_none=True)
+    out = net.train_step_rays(b, 6000 + i)
+    t_f = time.perf_counter()
+    torch.cuda.synchronize()
+    t_fs = time.perf_counter()
+    total, _ = total_loss(out, losses, 6000 + i)
+    total.backward()
+    opt.step()
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    rows.append((1e3 * (t_f - t0), 1e3 * (t_fs - t_f), 1e3 * (t1 - t_fs), 1e3 * (t2 - t1), 1e3 * (t2 - t0)))
+a = np.array(rows[2:])
+print("ms: forward on the host (incl. its device->host reads) | GPU still busy after it | loss + backward + Adam enqueue | GPU still busy "
+      "after it | step (with the extra sync after the forward)")
+print(np.round(a.mean(0), 2))
+if len(sys.argv) > 3 and sys.argv[3] == 'cprofile':        # host time by Python function over 6 steps
+    import cProfile
+    import pstats
+    pr = cProfile.Profile()
+    pr.enable()
+    for i in range(6):
+        step(i % 4)
+    torch.cuda.synchronize()
+    pr.disable()
+    st = pstats.Stats(pr)
+    st.sort_stats('tottime').print_stats(45)
+    st.sort_stats('cumulative').print_stats(60)
+    raise SystemExit(0)
 from torch.profiler import profile, ProfilerActivity  # noqa: E402
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
     step(3)
@@ -76,6 +111,7 @@ for e in prof.events():
             break
     by_site[site] += nk
     by_op[e.name] += nk
+print(prof.key_averages().table(sort_by="self_cpu_time_total", row_limit=40, max_name_column_width=60))
 print("torch-launched device kernels in the step:", total)
 print("---- by call site")
 for k, v in by_site.most_common(45):
