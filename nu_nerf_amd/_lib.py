@@ -46,8 +46,15 @@ def ptr(t):
     return c_p(t.data_ptr())
 
 
-def stream():
-    return c_p(torch.cuda.current_stream().cuda_stream)
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
+def stream(device_index=None):
+    """The current HIP stream of torch as a void* (what every launch of the library takes).  `torch.cuda.current_stream()` builds
+    a Python Stream object per call (~6 us, hundreds of calls per step); the raw getter returns the same handle in ~0.3 us."""
+    if _raw_stream is not None:
+        return c_p(_raw_stream(torch.cuda.current_device() if device_index is None else device_index))
+    return c_p(torch.cuda.current_stream(device_index).cuda_stream)
 
 
 def check(rc, what):

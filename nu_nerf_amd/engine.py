@@ -140,6 +140,7 @@ class Stage1Engine:
         self.dev = torch.device(device)
         if self.dev.type != "cuda":
             raise L.NuNerfLibraryError("Stage1Engine needs a CUDA(HIP) device: there is no CPU fallback")
+        self._dev_index = self.dev.index if self.dev.index is not None else torch.cuda.current_device()
         self.cfg = cfg
         self.p = params  # dict name -> Parameter/Tensor on device
         self.exp_max = float(cfg.get('light_exp_max', 3.0))
@@ -241,7 +242,7 @@ class Stage1Engine:
         return self._ws
 
     def stream(self):
-        return c_p(torch.cuda.current_stream(self.dev).cuda_stream)
+        return L.stream(self._dev_index)
 
     # Small batches leave the chip half empty (a 256 -> 256 layer on 8 192 points is 128 tiles for 256 CUs): the NeRF++ chain of the
     # outer points and the SDF / shading chain of the inner points are independent between the partition and the composite, so
@@ -307,8 +308,11 @@ class Stage1Engine:
             self._goff += n
             return o
 
+        self.grad_numel = {}   # param name -> element count (cached: the per-step slicing of the flat buffer is host-time critical)
+
         def reg(name, off):
             self.grad_views[name] = (off, tuple(p[name].shape))
+            self.grad_numel[name] = int(p[name].numel())
 
         # ---- SDF network ----
         sdf = []

@@ -17,25 +17,36 @@ import torch
 from .engine import addr, rup
 
 
+def _numel(shape):
+    n = 1
+    for d in shape:
+        n *= d
+    return n
+
+
 def _grads_from_flat(eng, flat, names):
-    out = []
-    for n in names:
-        off, shape = eng.grad_views[n]
-        numel = int(np.prod(shape)) if len(shape) else 1
-        out.append(flat[off:off + numel].view(shape))
-    return out
+    cache = eng.__dict__.setdefault('_slice_cache', {})
+    plan = cache.get(id(names))
+    if plan is None or plan[0] is not names:
+        plan = cache[id(names)] = (names, [(eng.grad_views[n][0], _numel(eng.grad_views[n][1]), eng.grad_views[n][1]) for n in names])
+    return [flat[off:off + numel].view(shape) for off, numel, shape in plan[1]]
 
 
 def _own_range(eng, names):
     """[lo, hi) of the flat gradient buffer that the parameters `names` occupy (one network's parameters are contiguous)."""
+    cache = eng.__dict__.setdefault('_range_cache', {})
+    hit = cache.get(id(names))
+    if hit is not None and hit[0] is names:
+        return hit[1]
     lo, hi, tot = None, 0, 0
     for n in names:
         off, shape = eng.grad_views[n]
-        numel = int(np.prod(shape)) if len(shape) else 1
+        numel = _numel(shape)
         lo = off if lo is None else min(lo, off)
         hi = max(hi, off + numel)
         tot += numel
     assert lo is not None and tot == hi - lo, "a network's parameters are expected to be contiguous in the flat gradient buffer"
+    cache[id(names)] = (names, (lo, hi))
     return lo, hi
 
 

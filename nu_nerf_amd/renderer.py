@@ -161,8 +161,7 @@ class _RenderCoreFn(torch.autograd.Function):
             if n == 'deviation_network.variance' and not ctx.train_inv_s:
                 grads.append(None)
                 continue
-            numel = int(np.prod(shape)) if len(shape) else 1
-            grads.append(flat[off:off + numel].view(shape))
+            grads.append(flat[off:off + eng.grad_numel[n]].view(shape))
         ctx.c = None
         return (None,) * 8 + tuple(grads)
 
@@ -191,8 +190,7 @@ class _SdfValueFn(torch.autograd.Function):
         grads = []
         for n in ctx.names:
             off, shape = eng.grad_views[n]
-            numel = int(np.prod(shape)) if len(shape) else 1
-            grads.append(flat[off:off + numel].view(shape))
+            grads.append(flat[off:off + eng.grad_numel[n]].view(shape))
         ctx.a = None
         return (None, None, None) + tuple(grads)
 
