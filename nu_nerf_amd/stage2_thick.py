@@ -123,7 +123,8 @@ class Stage2Renderer(_ZeroThickStage2):
                 stay = hit_idx
                 prev = segs[0]
                 prev['cont_idx'] = prev['cont_idx'].index_select(0, stay)
-                prev['normal'], prev['eta'] = prev['normal'].index_select(0, stay), prev['eta'].index_select(0, stay)
+                prev['normal'] = prev['normal'].index_select(0, stay)      # (`ior_ratios[0]` keeps its rows in the reference;
+                #                                                              the shader ignores that argument, field.py:909)
                 prev['n_cont'] = int(stay.numel())
                 start, dirs, root = start.index_select(0, stay), dirs.index_select(0, stay), root.index_select(0, stay)
                 hit = torch.ones(stay.numel(), dtype=torch.bool, device=dev)

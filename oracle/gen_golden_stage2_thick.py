@@ -20,7 +20,7 @@ sys.path.insert(0, REPO)
 from oracle.gen_golden import install_shims, to_t, OUT   # noqa: E402
 
 
-def main(step=6000, loss_names=('eikonal', 'std', 'nerf_render')):
+def main(step=6000, loss_names=('eikonal', 'std', 'nerf_render'), open_mesh=False):
     install_shims()
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -32,6 +32,10 @@ def main(step=6000, loss_names=('eikonal', 'std', 'nerf_render')):
     from nu_nerf_amd.lbvh import icosphere, corner_angles_and_face_normals
 
     V, F = icosphere(3, 0.5)
+    if open_mesh:
+        # an OPEN surface (the cap z > 0.2 removed, unused vertices kept): rays that enter through the shell can find no exit,
+        # which is the ragged branch of ray_trace (renderer.py:1660-1670); rays through the opening meet the back of the far side
+        F = np.ascontiguousarray(F[V[F].mean(1)[:, 2] <= 0.2])
 
     class FakeScene:
         def __init__(self, mesh_path):
@@ -156,7 +160,8 @@ def main(step=6000, loss_names=('eikonal', 'std', 'nerf_render')):
     res['grad_norms'] = np.asarray([float(gn[k].double().norm()) for k in sorted(gn.keys())])
     os.makedirs(OUT, exist_ok=True)
     res['out_loss_occ'] = outputs['loss_occ'].detach().numpy()
-    np.savez_compressed(os.path.join(OUT, "stage2_thick_step%d_r24.npz" % step), **res)
+    res['mesh_faces'] = F.astype(np.int32)
+    np.savez_compressed(os.path.join(OUT, "stage2_thick_step%d_r24%s.npz" % (step, "_open" if open_mesh else "")), **res)
     print("loss", float(total), {k: float(v) for k, v in res.items() if k.startswith('term_')}, "n grads", len(gn),
           "rgb range", float(outputs['ray_rgb'].min()), float(outputs['ray_rgb'].max()))
     print("params without grad:", sorted(set(n.split('.')[0] for n, p in net.named_parameters() if p.grad is None)))
@@ -166,3 +171,4 @@ if __name__ == "__main__":
     main()
     # past occ_loss_step and freeze_inv_s_step: the inner occlusion probe (renderer.py:2247-2255) in the loss, trainable inner variance
     main(step=25000, loss_names=('eikonal', 'std', 'nerf_render', 'occ'))
+    main(step=6000, open_mesh=True)

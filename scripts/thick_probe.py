@@ -9,7 +9,7 @@ from test_stage2_thick_gpu import build_thick
 from nu_nerf_amd.loss import name2loss, total_loss
 
 gpu = torch.device('cuda:0')
-g = golden("stage2_thick_step6000_r24.npz")
+g = golden(os.environ.get("NU_THICK_FIXTURE", "stage2_thick_step6000_r24.npz"))
 net, cfg = build_thick(gpu, g)
 step = int(g['step'])
 batch = {k: torch.from_numpy(g[k]).to(gpu) for k in ('rays_o', 'rays_d', 'rgbs')}

@@ -23,6 +23,8 @@ def build_thick(gpu, g, losses=('eikonal', 'std', 'nerf_render')):
     cfg = {'name': 'golden_s2t', 'network': 'stage2', 'get_mask': False, 'database_name': 'real/x/raw_1024', 'is_nerf': False,
            'shader_config': shader, 'loss': list(losses), 'eikonal_weight': 0.02, 'freeze_inv_s_step': 5000, 'occ_loss_step': 20000,
            'stage1_cfg': s1cfg, 'stage1_mesh_arrays': icosphere(3, 0.5)}
+    if 'mesh_faces' in g:                                    # the open-surface fixture carries its face list
+        cfg['stage1_mesh_arrays'] = (cfg['stage1_mesh_arrays'][0], g['mesh_faces'])
     net = Stage2Renderer(cfg, training=False)
     keys = list(net.state_dict().keys())
     assert keys == [str(k) for k in g['state_dict_keys']]
@@ -81,7 +83,10 @@ def _check_gradient_norms(net, g, rtol, atol):
 @pytest.mark.parametrize("fixture,losses", [
     ("stage2_thick_step6000_r24.npz", ('eikonal', 'std', 'nerf_render')),
     # past occ_loss_step: the inner occlusion probe (renderer.py:2247-2255) is part of the total loss
-    ("stage2_thick_step25000_r24.npz", ('eikonal', 'std', 'nerf_render', 'occ'))])
+    ("stage2_thick_step25000_r24.npz", ('eikonal', 'std', 'nerf_render', 'occ')),
+    # an OPEN surface (cap removed): 8 of the 15 first hits are back faces seen through the opening, and rays that entered through
+    # the shell find no exit -- the ragged branch of ray_trace (renderer.py:1660-1670)
+    ("stage2_thick_step6000_r24_open.npz", ('eikonal', 'std', 'nerf_render'))])
 def test_stage2_thick_train_step_vs_reference_golden(gpu, fixture, losses):
     g = golden(fixture)
     net, cfg = build_thick(gpu, g, losses)
