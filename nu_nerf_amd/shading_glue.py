@@ -117,6 +117,11 @@ def shade(nets, scfg, lut, points, normals, view_dirs, feats, s2=False, is_inter
         color = base + (fres * light0) * trans
         if is_internal:
             color = color * 0
+        if inter_results:      # the validation images of the first surface (field.py:984-1003)
+            c01 = lambda x: torch.clamp(x, 0.0, 1.0)
+            inter = {'specular_ref': c01(spec_ref), 'specular_light': c01(G.linear_to_srgb(light0)),
+                     'specular_color': c01(G.linear_to_srgb(spec_color) * (1 - trans) + fres * light0 * trans)}
+            return G.linear_to_srgb(color), (1 - fres) * trans, inter
         return G.linear_to_srgb(color), (1 - fres) * trans
     rf = scfg.get('refrac_freq', 6)
     refrac = torch.exp(torch.clamp(nets.predictor('refrac_light', torch.cat([G.embed(points, rf), G.embed(v, rf)], -1)),

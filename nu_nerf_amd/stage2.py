@@ -117,7 +117,11 @@ class Stage2Renderer(nn.Module):
         self.scene = None
         self._nets = None
         if training:
-            raise NotImplementedError("image databases are out of scope: construct with training=False and feed ray batches")
+            self._init_dataset()
+
+    # ---- data: the ray-pool store of the stage-1 module (`database_name: synthetic/<n_rays>`; image databases are out of scope) ----
+    _init_dataset = NeROShapeRenderer._init_dataset
+    _shuffle_train_batch = NeROShapeRenderer._shuffle_train_batch
 
     # ---- construction helpers ---------------------------------------------------------------------
     def _load_stage1_cfg(self):
@@ -202,8 +206,9 @@ class Stage2Renderer(nn.Module):
         alpha = 1.0 - torch.exp(-F.softplus(sig) * dists)
         return alpha, G.linear_to_srgb(torch.exp(torch.clamp(rgb, max=5.0)))
 
-    def _shading(self, nets, scfg, lut, points, normals, view_dirs, feats, s2=False, is_internal=False, aux=None):
-        return shade(nets, scfg, lut, points, normals, view_dirs, feats, s2=s2, is_internal=is_internal, aux=aux)
+    def _shading(self, nets, scfg, lut, points, normals, view_dirs, feats, s2=False, is_internal=False, aux=None, inter_results=False):
+        return shade(nets, scfg, lut, points, normals, view_dirs, feats, s2=s2, is_internal=is_internal, aux=aux,
+                     inter_results=inter_results)
 
     def _inner_occ_loss(self, n2, x, sdf, grads, dirs, aux, step):
         """Hook for the inner segment's occlusion loss: the zero-thickness model has none (renderer_zerothick.py:1890-1915)."""
@@ -299,7 +304,7 @@ class Stage2Renderer(nn.Module):
         return seg['start'][:, None, :] + seg['v'][:, None, :] * seg['z'][..., None]
 
     # ---- render_core ------------------------------------------------------------------------------
-    def render_segments(self, segs, cos_anneal_ratio=0.0, step=None):
+    def render_segments(self, segs, cos_anneal_ratio=0.0, step=None, is_train=True):
         """Front-to-back over the segments in linear RGB with a running transmittance (renderer_zerothick.py:1835-2011, training).
         The outer (|x| > 1) samples of ALL segments go through the NeRF++ in one pass of HIP kernels (stage2_ops.outer_segments);
         each segment's composite is one kernel pair; surface and inner-segment shading are the HIP network ops + one BRDF-mix
@@ -348,8 +353,18 @@ class Stage2Renderer(nn.Module):
             # the surface the continuing rays cross: stage-1 materials at the hit point, AppShadingNetwork_S2
             hit_pt = sg['start'].index_select(0, cont) + sg['v'].index_select(0, cont) * sg['z'].index_select(0, cont)[:, -1:]
             y, _ = n1.sdf(hit_pt)
-            surf, through = self._shading(n1, s1c.cfg, s1c.FG_LUT, hit_pt, sg['normal'], -sg['dirs'].index_select(0, cont), y[:, 1:],
-                                          s2=True, is_internal=sg['inside'])
+            if b == 0 and not is_train:
+                # validation images of the first surface (renderer_zerothick.py:1952-1962 / renderer.py:2274-2289): shading normal
+                # mapped to [0,1], specular terms of AppShadingNetwork_S2's intermediate results, scattered to the camera rays
+                surf, through, inter = self._shading(n1, s1c.cfg, s1c.FG_LUT, hit_pt, sg['normal'], -sg['dirs'].index_select(0, cont),
+                                                     y[:, 1:], s2=True, is_internal=sg['inside'], inter_results=True)
+                zero = torch.zeros(N0, 3, device=dev)
+                out['normal'] = zero.index_copy(0, cont, (F.normalize(sg['normal'], dim=-1) + 1.0) * 0.5)
+                for k in ('specular_color', 'specular_light', 'specular_ref'):
+                    out[k] = zero.index_copy(0, cont, inter[k].expand(-1, 3))
+            else:
+                surf, through = self._shading(n1, s1c.cfg, s1c.FG_LUT, hit_pt, sg['normal'], -sg['dirs'].index_select(0, cont),
+                                              y[:, 1:], s2=True, is_internal=sg['inside'])
             T_c = T.index_select(0, cont)
             colors.append(light.index_add(0, cont, G.srgb_to_linear(surf) * T_c))
             T = T_c * through
@@ -357,14 +372,17 @@ class Stage2Renderer(nn.Module):
             colors[b - 1] = colors[b - 1].index_add(0, segs[b - 1]['cont_idx'], colors[b])
         out['ray_rgb'] = torch.clamp(G.linear_to_srgb(colors[0]), min=0.0, max=1.0)
         out['acc'] = torch.ones(N0, device=dev)
+        if not is_train:
+            for k in ('normal', 'specular_color', 'specular_light', 'specular_ref'):
+                out.setdefault(k, torch.zeros(N0, 3, device=dev))
         return out
 
     # the reference's method names (renderer_zerothick.py:1571, :1835), kept for callers that use them
     def ray_trace(self, rays_o, rays_d):
         return self.trace_segments(rays_o, rays_d)
 
-    def render_core(self, segs, cos_anneal_ratio=0.0, step=None, **_):
-        return self.render_segments(segs, cos_anneal_ratio=cos_anneal_ratio, step=step)
+    def render_core(self, segs, cos_anneal_ratio=0.0, step=None, is_train=True, **_):
+        return self.render_segments(segs, cos_anneal_ratio=cos_anneal_ratio, step=step, is_train=is_train)
 
     def render(self, rays_o, rays_d, near=None, far=None, human_poses=None, perturb_overwrite=-1, cos_anneal_ratio=0.0,
                is_train=True, step=None, is_nerf=False):
@@ -375,7 +393,7 @@ class Stage2Renderer(nn.Module):
         n1.begin_pass()
         n2.begin_pass()
         segs, valid = self.trace_segments(rays_o, rays_d)
-        ret = self.render_segments(segs, cos_anneal_ratio=cos_anneal_ratio, step=step)
+        ret = self.render_segments(segs, cos_anneal_ratio=cos_anneal_ratio, step=step, is_train=is_train)
         ret['tir_mask'] = valid
         with torch.no_grad():
             ret['_paths'] = [self.path_points(sg) for sg in segs]       # materialised for inspection only
@@ -393,8 +411,69 @@ class Stage2Renderer(nn.Module):
         out['loss_rgb'] = self.compute_rgb_loss(out['ray_rgb'] * tm, batch['rgbs'] * tm)
         return out
 
+    def train_step(self, step):
+        """renderer_zerothick.py:1259-1275 on the module's device-resident ray store."""
+        rn = self.cfg['train_ray_num']
+        dev = self.IORs.device
+        if not hasattr(self, 'train_batch'):
+            raise RuntimeError("train_step needs the module's ray store: construct with training=True")
+        if self._batch_dev != dev:
+            self.train_batch = {k: v.to(dev) for k, v in self.train_batch.items()}
+            self._batch_dev = dev
+            self._shuffle_train_batch()
+        batch = {k: v[self.train_batch_i:self.train_batch_i + rn] for k, v in self.train_batch.items()}
+        self.train_batch_i += rn
+        if self.train_batch_i + rn >= self.tbn:
+            self._shuffle_train_batch()
+        return self.train_step_rays(batch, step)
+
+    _EVAL_KEYS = ('ray_rgb', 'gradient_error', 'normal', 'tir_mask', 'specular_light', 'specular_color', 'specular_ref')
+
+    def render_eval(self, batch, step, chunk=None):
+        """test_step's ray loop (renderer_zerothick.py:1226-1241) over an explicit ray batch: chunks of cfg['test_ray_num'] rays,
+        cos_anneal 0, is_train=False; ray_rgb / gt masked by the TIR mask as the reference does."""
+        trn = int(chunk or self.cfg['test_ray_num'])
+        outs = {k: [] for k in self._EVAL_KEYS}
+        n = batch['rays_o'].shape[0]
+        for ri in range(0, n, trn):
+            rays_d = F.normalize(batch['rays_d'][ri:ri + trn], dim=-1)
+            o = self.render(batch['rays_o'][ri:ri + trn], rays_d, None, None, None, 0, 0, is_train=False, step=step, is_nerf=self.is_nerf)
+            for k in self._EVAL_KEYS:
+                outs[k].append(o[k].detach())
+        outs = {k: torch.cat(v, 0) for k, v in outs.items()}
+        tm = outs['tir_mask'].float()
+        if 'rgbs' in batch:
+            outs['loss_rgb'] = self.compute_rgb_loss(outs['ray_rgb'] * tm, batch['rgbs'] * tm)
+        return outs
+
+    def test_step(self, index, step):
+        """Full-image validation render of camera `index` (renderer_zerothick.py:1209-1257) for the ray-pool datasets of this
+        build (every pixel of the down-sampled synthetic camera; gt_depth / gt_mask are the empty scene's zeros)."""
+        from . import synthetic
+        hw = int(self.cfg.get('synthetic_hw', 800))
+        ratio = float(self.cfg['downsample_ratio']) if self.cfg['test_downsample_ratio'] else 1.0
+        rays, h, w = synthetic.make_image_rays(index, hw=hw, seed=int(self.cfg.get('ray_seed', 6033)), downsample=ratio)
+        dev = self.IORs.device
+        batch = {k: torch.from_numpy(v).to(dev) for k, v in rays.items()}
+        with torch.no_grad():
+            outputs = self.render_eval(batch, step)
+        tm = outputs['tir_mask'].float()
+        outputs['gt_rgb'] = (batch['rgbs'] * tm).reshape(h, w, 3)
+        outputs['ray_rgb'] = (outputs['ray_rgb'] * tm).reshape(h, w, 3)
+        outputs['gt_depth'] = torch.zeros(h, w, 1)
+        outputs['gt_mask'] = torch.zeros(h, w, 1, dtype=torch.int32)
+        self.zero_grad()
+        return outputs
+
     def forward(self, data):
-        raise NotImplementedError("stage-2 forward(data) needs an image database: use train_step_rays / render")
+        """trainer protocol (renderer_zerothick.py:2013-2035): {'step'} -> train_step; {'index','eval','step'} (the
+        ValidationEvaluator's call, train/train_valid.py:25-29) -> test_step."""
+        step = data['step']
+        if 'eval' in data:
+            index = data['index']
+            index = int(index.reshape(-1)[0]) if torch.is_tensor(index) else int(np.asarray(index).reshape(-1)[0])
+            return self.test_step(index, step)
+        return self.train_step(step)
 
 
 from .renderer import name2renderer  # noqa: E402

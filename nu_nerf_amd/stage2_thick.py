@@ -66,7 +66,7 @@ class Stage2Renderer(_ZeroThickStage2):
         self.scene = None
         self._nets = None
         if training:
-            raise NotImplementedError("image databases are out of scope: construct with training=False and feed ray batches")
+            self._init_dataset()
 
     def _init_own_parameters(self):
         from .params import init_stage2_thick_own_params
@@ -159,8 +159,8 @@ class Stage2Renderer(_ZeroThickStage2):
             root = root.index_select(0, cont_idx)
         return segs, valid[:, None]
 
-    def render_segments(self, segs, cos_anneal_ratio=0.0, step=None):
-        out = super().render_segments(segs, cos_anneal_ratio=cos_anneal_ratio, step=step)
+    def render_segments(self, segs, cos_anneal_ratio=0.0, step=None, is_train=True):
+        out = super().render_segments(segs, cos_anneal_ratio=cos_anneal_ratio, step=step, is_train=is_train)
         out.setdefault('loss_occ', torch.zeros(1, device=segs[0]['start'].device))
         return out
 

@@ -121,6 +121,11 @@ def main():
         if k in gn:
             res['grad__' + k] = gn[k].numpy().copy()
     res['state_dict_keys'] = np.asarray(keys)
+    # the validation render of the same rays (test_step's call, renderer_zerothick.py:1238-1240: perturb 0, cos_anneal 0, is_train=False)
+    with torch.no_grad():
+        ev = net.render(o, dn, None, None, None, 0, 0, is_train=False, step=step, is_nerf=True)
+    for k in ('ray_rgb', 'normal', 'specular_color', 'specular_light', 'specular_ref', 'tir_mask'):
+        res['eval_' + k] = ev[k].detach().numpy()
     np.savez_compressed(os.path.join(OUT, "stage2_step6000_r24.npz"), **res)
     print("stage2 loss", float(total), {k: float(v) for k, v in res.items() if k.startswith('term_')},
           "tir", outputs['tir_mask'].flatten().tolist()[:8], "n grads", len(gn))

@@ -161,6 +161,11 @@ def main(step=6000, loss_names=('eikonal', 'std', 'nerf_render'), open_mesh=Fals
     os.makedirs(OUT, exist_ok=True)
     res['out_loss_occ'] = outputs['loss_occ'].detach().numpy()
     res['mesh_faces'] = F.astype(np.int32)
+    # the validation render of the same rays (test_step's call, renderer.py:1297-1300: perturb 0, cos_anneal 0, is_train=False)
+    with torch.no_grad():
+        ev = net.render(o, dn, mask, None, None, None, 0, 0, is_train=False, step=step, is_nerf=False)
+    for k in ('ray_rgb', 'normal', 'specular_color', 'specular_light', 'specular_ref', 'tir_mask'):
+        res['eval_' + k] = ev[k].detach().numpy()
     np.savez_compressed(os.path.join(OUT, "stage2_thick_step%d_r24%s.npz" % (step, "_open" if open_mesh else "")), **res)
     print("loss", float(total), {k: float(v) for k, v in res.items() if k.startswith('term_')}, "n grads", len(gn),
           "rgb range", float(outputs['ray_rgb'].min()), float(outputs['ray_rgb'].max()))

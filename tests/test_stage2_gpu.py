@@ -61,3 +61,27 @@ def test_stage2_train_step_vs_reference_golden(gpu):
     for k in g:
         if k.startswith('grad__'):
             assert rel_err(named[k[6:]].grad.cpu(), g[k]) < 2e-2, k
+
+
+def test_stage2_validation_render_vs_reference_golden(gpu):
+    """render(..., is_train=False) -- test_step's per-chunk call (renderer_zerothick.py:1238-1240) -- against the reference's
+    outputs on the fixture's rays: RGB, TIR mask and the validation images of the first surface; then the trainer protocol
+    (forward({'step'}) / forward({'index','eval','step'})) on the module's own ray store."""
+    g = golden("stage2_step6000_r24.npz")
+    net, cfg = build(gpu)
+    batch = {k: torch.from_numpy(g[k]).to(gpu) for k in ('rays_o', 'rays_d', 'rgbs')}
+    with torch.no_grad():
+        whole = net.render_eval(batch, int(g['step']))
+        parts = net.render_eval(batch, int(g['step']), chunk=10)
+    assert np.array_equal(whole['tir_mask'].cpu().numpy(), g['eval_tir_mask'])
+    for k in ('ray_rgb', 'normal', 'specular_color', 'specular_light', 'specular_ref'):
+        np.testing.assert_allclose(whole[k].cpu().numpy(), g['eval_' + k], rtol=1e-4, atol=2e-6, err_msg=k)
+        np.testing.assert_allclose(parts[k].cpu().numpy(), whole[k].cpu().numpy(), rtol=1e-5, atol=1e-6, err_msg=k)
+    from nu_nerf_amd.stage2 import name2renderer
+    cfg2 = dict(cfg, database_name='synthetic/8192', train_ray_num=256, test_ray_num=512, synthetic_hw=48, downsample_ratio=0.5)
+    net2 = name2renderer['stage2'](cfg2, training=True).to(gpu)
+    out = net2({'step': 6000})
+    assert out['ray_rgb'].shape == (256, 3) and out['loss_rgb'].requires_grad
+    with torch.no_grad():
+        ev = net2({'index': 1, 'eval': True, 'step': 0})
+    assert ev['ray_rgb'].shape == (24, 24, 3) and ev['normal'].shape == (576, 3) and torch.isfinite(ev['ray_rgb']).all()

@@ -138,3 +138,43 @@ def test_stage2_thick_train_step_vs_reference_golden(gpu, fixture, losses):
     np.testing.assert_allclose(float(total.detach()), float(g['total_loss']), rtol=1e-5)
     worst = _check_gradient_norms(net, g, rtol=1e-3, atol=2e-9)      # (norms of 2e-8 are sums of cancelling fp32 terms)
     print("worst gradient-norm deviation at the reference's sample placement", worst)
+
+
+def test_stage2_thick_validation_render_vs_reference_golden(gpu):
+    """render(..., is_train=False) -- test_step's per-chunk call (renderer.py:1297-1300) -- against the reference's outputs on
+    the fixture's rays: RGB, TIR mask and the validation images of the first surface (shading normal, specular terms)."""
+    g = golden("stage2_thick_step6000_r24.npz")
+    net, cfg = build_thick(gpu, g)
+    batch = {k: torch.from_numpy(g[k]).to(gpu) for k in ('rays_o', 'rays_d', 'rgbs')}
+    with torch.no_grad():
+        whole = net.render_eval(batch, int(g['step']))
+        parts = net.render_eval(batch, int(g['step']), chunk=10)               # 10 + 10 + 4: ragged last chunk
+    assert np.array_equal(whole['tir_mask'].cpu().numpy(), g['eval_tir_mask'])
+    for k in ('ray_rgb', 'normal', 'specular_color', 'specular_light', 'specular_ref'):
+        np.testing.assert_allclose(whole[k].cpu().numpy(), g['eval_' + k], rtol=1e-4, atol=2e-6, err_msg=k)
+        np.testing.assert_allclose(parts[k].cpu().numpy(), whole[k].cpu().numpy(), rtol=1e-5, atol=1e-6, err_msg=k)
+    assert float(np.abs(g['eval_normal']).sum()) > 1.0 and float(g['eval_specular_light'].max()) > 0.01
+
+
+def test_stage2_thick_trainer_protocol(gpu):
+    """name2renderer['stage2'](cfg) -> forward({'step'}) / forward({'index','eval','step'}) on the module's own ray store, as
+    train/trainer.py:97-161 and train/train_valid.py:25-29 drive it."""
+    from nu_nerf_amd.stage2_thick import name2renderer
+    from nu_nerf_amd.lbvh import icosphere
+    shader = {'sphere_direction': True, 'human_light': False, 'light_exp_max': 5.0}
+    cfg = {'name': 's2t', 'network': 'stage2', 'get_mask': False, 'database_name': 'synthetic/8192', 'is_nerf': False,
+           'shader_config': shader, 'train_ray_num': 256, 'test_ray_num': 512, 'synthetic_hw': 48, 'downsample_ratio': 0.5,
+           'stage1_cfg': {'name': 's1', 'network': 'shape', 'get_mask': False, 'is_nerf': False, 'shader_config': shader},
+           'stage1_mesh_arrays': icosphere(3, 0.5)}
+    net = name2renderer['stage2'](cfg, training=True).to(gpu)
+    out = net({'step': 6000})
+    assert out['ray_rgb'].shape == (256, 3) and out['loss_rgb'].requires_grad and out['tir_mask'].shape == (256, 1)
+    out['loss_rgb'].mean().backward()
+    assert any(p.grad is not None for p in net.IORs_pred.parameters())
+    with torch.no_grad():
+        ev = net({'index': torch.tensor([3]), 'eval': True, 'step': 0})
+    for k in ('ray_rgb', 'gt_rgb'):
+        assert ev[k].shape == (24, 24, 3)
+    for k in ('normal', 'specular_color', 'specular_light', 'specular_ref'):
+        assert ev[k].shape == (576, 3)
+    assert ev['gt_depth'].shape == (24, 24, 1) and torch.isfinite(ev['ray_rgb']).all()
