@@ -425,6 +425,20 @@ int nu_s2_refract_fwd(const float* d, const float* nrm, const float* ior, const 
                       float* eta, float* nd, float* ns, hipStream_t stream);
 int nu_s2_refract_bwd(const float* d, const float* nrm, const float* ior, int M, int outside, const float* g_nd, const float* g_ns,
                       const float* g_eta, float* dd, float* dn, float* dior, float* dpoint, hipStream_t stream);
+/*   nu_s2_shade_encode_fwd / _bwd       inputs of the shading stacks for explicit points / normals / view directions [P,3] (stage 2:
+ *                                       AppShadingNetwork, _S2, _SpecInner; field.py:636-682, :828-907, :1399-1445): n^, v^, NoV,
+ *                                       r = 2 NoV n^ - v^, rho = sigmoid(Mraw[:,1]);  OLin [3P, ld_ol] IDE rows (+ sphere points when
+ *                                       `sphere`), ILin [2P,128] = [pe(x) | IDE], IWin [P,96] = [pe(x) | embed(r,6)], RLin [P, ld_rl]
+ *                                       = [embed(x, rf) | embed(v^, rf)] (refrac_freq < 0: none), SD [P,12] = n^, NoV, 1/|n|, rho,
+ *                                       1/|v|, 0, r, 0; pe(x) has pos_freq frequencies (6 or 8).  _bwd: cotangents of OLin / ILin /
+ *                                       RLin / NoV (each may be NULL) -> d x, d n, d v [P,3] and d Mraw[:,1] [P] -- the stage-1 pair
+ *                                       nu_shade_encode_* returns d n and d rho only. */
+int nu_s2_shade_encode_fwd(const float* x, const float* nrm, const float* view, const float* Mraw, int ldm, int P, int sphere, int pos_freq,
+                           int ld_ol, int refrac_freq, int ld_rl, float* OLin, float* ILin, float* IWin, float* RLin, float* SD,
+                           hipStream_t stream);
+int nu_s2_shade_encode_bwd(const float* x, const float* nrm, const float* view, const float* SD, int P, int sphere, int pos_freq, int ld_ol,
+                           int refrac_freq, int ld_rl, const float* dOLin, const float* dILin, const float* dRLin, const float* dNoV,
+                           float* dx, float* dn, float* dv, float* drho_raw, hipStream_t stream);
 /*   nu_s2_shell_fwd / _bwd              thin-shell refraction of the NON-zero-thickness stage-2 model (network/renderer.py:1692-2032,
  *                                       Stage2Renderer.ray_trace): per hit ray the two refractions through a shell of learned thickness
  *                                       whose faces are concentric spheres of the local curvature radius.  In: d, raw interpolated

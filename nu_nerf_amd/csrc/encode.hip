@@ -730,3 +730,247 @@ extern "C" int nu_embed_n_bwd(const float* x, const float* g, int ldg, int P, in
     hipLaunchKernelGGL(embed_n_bwd_kernel, dim3(nu_cdiv(P, 256)), dim3(256), 0, stream, x, g, ldg, P, n_freq, dx);
     return nu_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------
+// Stage-2 form of the shading-stack inputs: explicit points / normals / view directions [P,3] (no point records), position code of
+// `pos_freq` frequencies computed here (6: AppShadingNetwork / _S2, 8: AppShadingNetwork_SpecInner, field.py:1351), refraction
+// codes of `rdim = 3 + 6 refrac_freq` columns (0: no refraction stack, AppShadingNetwork_S2) -- and a backward that returns the
+// gradients w.r.t. ALL inputs: stage 2 differentiates positions, normals and view directions (every one of them depends on the
+// learned index of refraction), stage 1 only the normal and the roughness.
+//   n^ = n / max(|n|, 1e-12), v^ likewise;  NoV = n^ . v^;  r = 2 NoV n^ - v^;  rho = sigmoid(Mraw[:, 1])
+//   OLin [3P, ld_ol]: IDE(n^,1) | IDE(r,rho) | IDE(r,0)   (+ IDE of the sphere points of x along n^ / r, kappa 1 / rho / rho)
+//   ILin [2P, 128]  : [pe(x), IDE(r,rho)] | [pe(x), IDE(r,0)]
+//   IWin [P, 96]    : [pe(x), embed(r,6)]          (inputs of the occlusion head: no gradient, field.py:649)
+//   RLin [P, ld_rl] : [embed(x,rf), embed(v^,rf)]
+//   SD   [P, 12]    : n^(3), NoV, 1/|n|, rho, 1/|v|, 0, r(3), 0
+// (field.py:636-682, :828-907, :1399-1445; one wave per point, lanes over encoding columns)
+// ------------------------------------------------------------------------------------------------
+static __device__ inline void nu_s2_dirs(const float* n, const float* v, float* nh, float* vh, float* r, float& nov, float& inorm,
+                                         float& ivn) {
+    inorm = 1.0f / fmaxf(sqrtf(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]), 1e-12f);
+    ivn = 1.0f / fmaxf(sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]), 1e-12f);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { nh[c] = n[c] * inorm; vh[c] = v[c] * ivn; }
+    nov = nh[0] * vh[0] + nh[1] * vh[1] + nh[2] * vh[2];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) r[c] = nov * nh[c] * 2.0f - vh[c];
+}
+// cotangent of the unit sphere point -> cotangents of dir AND of the offset origin p'
+static __device__ inline void nu_sph_point_bwd2(const NuSph& o, const float* dir, const float* ds_unit, float* ddir, float* dpp) {
+    const float dotp = ds_unit[0] * o.s[0] + ds_unit[1] * o.s[1] + ds_unit[2] * o.s[2];
+    float ds[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) ds[c] = (ds_unit[c] - o.s[c] * dotp) / o.snorm;
+    const float b = o.pp[0] * dir[0] + o.pp[1] * dir[1] + o.pp[2] * dir[2];
+    const float dt_db = -1.0f + b / o.root;
+    const float dt = ds[0] * dir[0] + ds[1] * dir[1] + ds[2] * dir[2];    // d L / d t
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        ddir[c] += o.t * ds[c] + dt * dt_db * o.pp[c];
+        dpp[c] += ds[c] + dt * (dt_db * dir[c] - o.pp[c] / o.root);        // t = -b + sqrt(b^2 - p'.p' + 1 + 1e-6)
+    }
+}
+// per-lane share of J^T g for one embedding column `col` of argument a[3]: adds to the coordinate the column depends on
+static __device__ inline void nu_embed_col_grad(const float* a, int col, float g, float& gx, float& gy, float& gz) {
+    int c;
+    float d;
+    if (col < 3) { c = col; d = 1.0f; }
+    else {
+        const int q = col - 3, k = q / 6, rr = q - k * 6;
+        c = rr >= 3 ? rr - 3 : rr;
+        const float f = (float)(1 << k), arg = a[c] * f;
+        d = rr >= 3 ? -sinf(arg) * f : cosf(arg) * f;
+    }
+    const float v = g * d;
+    gx += c == 0 ? v : 0.f; gy += c == 1 ? v : 0.f; gz += c == 2 ? v : 0.f;
+}
+
+__global__ __launch_bounds__(256) void s2_shade_encode_fwd_kernel(const float* __restrict__ xs, const float* __restrict__ nrm,
+                                                                  const float* __restrict__ view, const float* __restrict__ Mraw,
+                                                                  int ldm, int P, int sphere, int pe, int ld_ol, int rdim, int ld_rl,
+                                                                  float* __restrict__ OLin, float* __restrict__ ILin,
+                                                                  float* __restrict__ IWin, float* __restrict__ RLin,
+                                                                  float* __restrict__ SD) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwave = (gridDim.x * blockDim.x) >> 6;
+    const NuIdeLane IL = nu_ide_lane(lane);
+    for (int p = wave; p < P; p += nwave) {
+        float n[3], v[3], x[3], nh[3], vh[3], r[3], nov, inorm, ivn;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { n[c] = nrm[p * 3LL + c]; v[c] = view[p * 3LL + c]; x[c] = xs[p * 3LL + c]; }
+        nu_s2_dirs(n, v, nh, vh, r, nov, inorm, ivn);
+        const float rho = nu_sigmoid(Mraw[(long long)p * ldm + 1]);
+        const float e = lane < pe ? nu_embed_col(x, 3, lane) : 0.f;
+        float* ol0 = OLin + (long long)p * ld_ol;
+        float* ol1 = OLin + (long long)(P + p) * ld_ol;
+        float* ol2 = OLin + (long long)(2LL * P + p) * ld_ol;
+        const NuIdeDir tn = nu_ide_dir(IL, nh[0], nh[1], nh[2]);
+        const NuIdeDir tr = nu_ide_dir(IL, r[0], r[1], r[2]);
+        const float att_rho = nu_ide_att(IL, rho);
+        if (sphere) {
+            const NuSph sn = nu_sph_point(x, nh), sr = nu_sph_point(x, r);
+            const NuIdeDir tsn = nu_ide_dir(IL, sn.s[0], sn.s[1], sn.s[2]);
+            const NuIdeDir tsr = nu_ide_dir(IL, sr.s[0], sr.s[1], sr.s[2]);
+            nu_ide_store(ol0, lane, IL, tn, IL.att1, 72);
+            nu_ide_store(ol0 + 72, lane, IL, tsn, IL.att1, ld_ol - 72);
+            nu_ide_store(ol1, lane, IL, tr, att_rho, 72);
+            nu_ide_store(ol1 + 72, lane, IL, tsr, att_rho, ld_ol - 72);
+            nu_ide_store(ol2, lane, IL, tr, 1.0f, 72);
+            nu_ide_store(ol2 + 72, lane, IL, tsr, att_rho, ld_ol - 72);
+        } else {
+            nu_ide_store(ol0, lane, IL, tn, IL.att1, ld_ol);
+            nu_ide_store(ol1, lane, IL, tr, att_rho, ld_ol);
+            nu_ide_store(ol2, lane, IL, tr, 1.0f, ld_ol);
+        }
+        float* il0 = ILin + (long long)p * 128;
+        float* il1 = ILin + (long long)(P + p) * 128;
+        if (lane < pe) { il0[lane] = e; il1[lane] = e; }
+        nu_ide_store(il0 + pe, lane, IL, tr, att_rho, 128 - pe);
+        nu_ide_store(il1 + pe, lane, IL, tr, 1.0f, 128 - pe);
+        float* iw = IWin + (long long)p * 96;
+        if (lane < pe) iw[lane] = e;
+        if (lane < 39) iw[pe + lane] = nu_embed_col(r, 3, lane);
+        for (int c = pe + 39 + lane; c < 96; c += 64) iw[c] = 0.f;
+        if (rdim > 0) {
+            float* rl = RLin + (long long)p * ld_rl;
+            if (lane < rdim) {
+                rl[lane] = e;                               // the rf-frequency code is a prefix of the pos_freq one (rf <= pos_freq)
+                rl[rdim + lane] = nu_embed_col(vh, 3, lane);
+            }
+            for (int c = 2 * rdim + lane; c < ld_rl; c += 64) rl[c] = 0.f;
+        }
+        if (lane < 12) {
+            float o = 0.f;
+            if (lane < 3) o = nh[lane];
+            else if (lane == 3) o = nov;
+            else if (lane == 4) o = inorm;
+            else if (lane == 5) o = rho;
+            else if (lane == 6) o = ivn;
+            else if (lane >= 8 && lane < 11) o = r[lane - 8];
+            SD[(long long)p * 12 + lane] = o;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void s2_shade_encode_bwd_kernel(const float* __restrict__ xs, const float* __restrict__ nrm,
+                                                                  const float* __restrict__ view, const float* __restrict__ SD,
+                                                                  int P, int sphere, int pe, int ld_ol, int rdim, int ld_rl,
+                                                                  const float* __restrict__ dOLin, const float* __restrict__ dILin,
+                                                                  const float* __restrict__ dRLin, const float* __restrict__ dNoV,
+                                                                  float* __restrict__ dx, float* __restrict__ dn,
+                                                                  float* __restrict__ dv, float* __restrict__ drho_raw) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwave = (gridDim.x * blockDim.x) >> 6;
+    const NuIdeLane IL = nu_ide_lane(lane);
+    const bool lv = IL.live;
+    for (int p = wave; p < P; p += nwave) {
+        float n[3], v[3], x[3], nh[3], vh[3], r[3], nov, inorm, ivn;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { n[c] = nrm[p * 3LL + c]; v[c] = view[p * 3LL + c]; x[c] = xs[p * 3LL + c]; }
+        nu_s2_dirs(n, v, nh, vh, r, nov, inorm, ivn);
+        const float rho = SD[(long long)p * 12 + 5];
+        const float att_rho = nu_ide_att(IL, rho);
+        const float* g0 = dOLin ? dOLin + (long long)p * ld_ol : nullptr;
+        const float* g1 = dOLin ? dOLin + (long long)(P + p) * ld_ol : nullptr;
+        const float* g2 = dOLin ? dOLin + (long long)(2LL * P + p) * ld_ol : nullptr;
+        const float* i0 = dILin ? dILin + (long long)p * 128 : nullptr;
+        const float* i1 = dILin ? dILin + (long long)(P + p) * 128 : nullptr;
+        const float* rl = (dRLin && rdim > 0) ? dRLin + (long long)p * ld_rl : nullptr;
+        auto G = [&](const float* row, int col) -> float { return (row && lv) ? row[col] : 0.f; };
+        float dnh[3], dr[3], drho, dpp[3] = {0.f, 0.f, 0.f};
+        float ax, ay, az;
+        {   // IDE(n^, 1)
+            const NuIdeDir tn = nu_ide_dir(IL, nh[0], nh[1], nh[2]);
+            nu_ide_dir_grad(IL, tn, G(g0, lane) * IL.att1, G(g0, 36 + lane) * IL.att1, ax, ay, az);
+            dnh[0] = nu_wave_sum(ax); dnh[1] = nu_wave_sum(ay); dnh[2] = nu_wave_sum(az);
+        }
+        {   // IDE(r, rho): outer row 1 + inner row 0;  IDE(r, 0): outer row 2 + inner row 1
+            const NuIdeDir tr = nu_ide_dir(IL, r[0], r[1], r[2]);
+            const float are_k = G(g1, lane) + G(i0, pe + lane), aim_k = G(g1, 36 + lane) + G(i0, pe + 36 + lane);
+            const float are_0 = G(g2, lane) + G(i1, pe + lane), aim_0 = G(g2, 36 + lane) + G(i1, pe + 36 + lane);
+            nu_ide_dir_grad(IL, tr, are_k * att_rho + are_0, aim_k * att_rho + aim_0, ax, ay, az);
+            dr[0] = nu_wave_sum(ax); dr[1] = nu_wave_sum(ay); dr[2] = nu_wave_sum(az);
+            drho = nu_wave_sum(-IL.sigma * att_rho * tr.poly * (are_k * tr.are + aim_k * tr.aim));
+        }
+        if (sphere) {
+            const NuSph sn = nu_sph_point(x, nh), sr = nu_sph_point(x, r);
+            float ds[3];
+            const NuIdeDir tsn = nu_ide_dir(IL, sn.s[0], sn.s[1], sn.s[2]);
+            nu_ide_dir_grad(IL, tsn, G(g0, 72 + lane) * IL.att1, G(g0, 108 + lane) * IL.att1, ax, ay, az);
+            ds[0] = nu_wave_sum(ax); ds[1] = nu_wave_sum(ay); ds[2] = nu_wave_sum(az);
+            nu_sph_point_bwd2(sn, nh, ds, dnh, dpp);
+            const NuIdeDir tsr = nu_ide_dir(IL, sr.s[0], sr.s[1], sr.s[2]);
+            const float sre = G(g1, 72 + lane) + G(g2, 72 + lane), sim = G(g1, 108 + lane) + G(g2, 108 + lane);
+            nu_ide_dir_grad(IL, tsr, sre * att_rho, sim * att_rho, ax, ay, az);
+            ds[0] = nu_wave_sum(ax); ds[1] = nu_wave_sum(ay); ds[2] = nu_wave_sum(az);
+            drho += nu_wave_sum(-IL.sigma * att_rho * tsr.poly * (sre * tsr.are + sim * tsr.aim));
+            nu_sph_point_bwd2(sr, r, ds, dr, dpp);
+        }
+        // position codes (both inner_light rows, the refraction stack's first half) and the view code (its second half)
+        float ex = 0.f, ey = 0.f, ez = 0.f, wx = 0.f, wy = 0.f, wz = 0.f;
+        if (lane < pe) {
+            float g = (i0 ? i0[lane] + i1[lane] : 0.f) + ((rl && lane < rdim) ? rl[lane] : 0.f);
+            nu_embed_col_grad(x, lane, g, ex, ey, ez);
+        }
+        if (rl && lane < rdim) nu_embed_col_grad(vh, lane, rl[rdim + lane], wx, wy, wz);
+        ex = nu_wave_sum(ex); ey = nu_wave_sum(ey); ez = nu_wave_sum(ez);
+        wx = nu_wave_sum(wx); wy = nu_wave_sum(wy); wz = nu_wave_sum(wz);
+        if (lane == 0) {
+            // r = 2 NoV n^ - v^ ; NoV = n^ . v^
+            const float dnov = (dNoV ? dNoV[p] : 0.f) + 2.0f * (dr[0] * nh[0] + dr[1] * nh[1] + dr[2] * nh[2]);
+            const float dve[3] = {wx, wy, wz};
+            float tn_[3], tv_[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                tn_[c] = dnh[c] + 2.0f * nov * dr[c] + dnov * vh[c];
+                tv_[c] = -dr[c] + dnov * nh[c] + dve[c];
+            }
+            const float dn_ = tn_[0] * nh[0] + tn_[1] * nh[1] + tn_[2] * nh[2];
+            const float dv_ = tv_[0] * vh[0] + tv_[1] * vh[1] + tv_[2] * vh[2];
+            // p' = x inside radius 0.999, else 0.999 x / |x|
+            const float xn = sqrtf(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+            float dxs[3] = {dpp[0], dpp[1], dpp[2]};
+            if (xn > 0.999f) {
+                const float xd = (dpp[0] * x[0] + dpp[1] * x[1] + dpp[2] * x[2]) / (xn * xn);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) dxs[c] = 0.999f / xn * (dpp[c] - x[c] * xd);
+            }
+            const float dem[3] = {ex, ey, ez};
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                dn[p * 3LL + c] = (tn_[c] - nh[c] * dn_) * inorm;
+                dv[p * 3LL + c] = (tv_[c] - vh[c] * dv_) * ivn;
+                dx[p * 3LL + c] = dem[c] + dxs[c];
+            }
+            drho_raw[p] = drho * rho * (1.0f - rho);
+        }
+    }
+}
+
+extern "C" int nu_s2_shade_encode_fwd(const float* x, const float* nrm, const float* view, const float* Mraw, int ldm, int P, int sphere,
+                                      int pos_freq, int ld_ol, int refrac_freq, int ld_rl, float* OLin, float* ILin, float* IWin,
+                                      float* RLin, float* SD, hipStream_t stream) {
+    if (P <= 0) return NU_OK;
+    const int pe = 3 + 6 * pos_freq, rdim = refrac_freq >= 0 ? 3 + 6 * refrac_freq : 0;
+    if (pos_freq < 0 || pe + 72 > 128 || pe + 39 > 96 || ld_ol < (sphere ? 144 : 72) || rdim > pe || (rdim > 0 && (ld_rl < 2 * rdim || !RLin)))
+        return NU_ERR_ARG;
+    int blocks = nu_cdiv(P, 4);
+    blocks = blocks < 8192 ? blocks : 8192;
+    hipLaunchKernelGGL(s2_shade_encode_fwd_kernel, dim3(blocks), dim3(256), 0, stream, x, nrm, view, Mraw, ldm, P, sphere, pe, ld_ol, rdim,
+                       ld_rl, OLin, ILin, IWin, RLin, SD);
+    return nu_launch_status();
+}
+extern "C" int nu_s2_shade_encode_bwd(const float* x, const float* nrm, const float* view, const float* SD, int P, int sphere, int pos_freq,
+                                      int ld_ol, int refrac_freq, int ld_rl, const float* dOLin, const float* dILin, const float* dRLin,
+                                      const float* dNoV, float* dx, float* dn, float* dv, float* drho_raw, hipStream_t stream) {
+    if (P <= 0) return NU_OK;
+    const int pe = 3 + 6 * pos_freq, rdim = refrac_freq >= 0 ? 3 + 6 * refrac_freq : 0;
+    if (pos_freq < 0 || pe + 72 > 128 || rdim > pe) return NU_ERR_ARG;
+    int blocks = nu_cdiv(P, 4);
+    blocks = blocks < 8192 ? blocks : 8192;
+    hipLaunchKernelGGL(s2_shade_encode_bwd_kernel, dim3(blocks), dim3(256), 0, stream, x, nrm, view, SD, P, sphere, pe, ld_ol, rdim, ld_rl,
+                       dOLin, dILin, dRLin, dNoV, dx, dn, dv, drho_raw);
+    return nu_launch_status();
+}

@@ -142,8 +142,11 @@ class StackFn(torch.autograd.Function):
     def forward(ctx, eng, layers, X, names, token):
         rows, K = X.shape
         Kp = layers[0].Kp
-        Xp = eng.zeros(rows, Kp)
-        Xp[:, :K] = X.detach()
+        if K == Kp:                 # rows already in the stack's padded layout (stage2_ops.shade_encode): no copy
+            Xp = X.detach().contiguous()
+        else:
+            Xp = eng.zeros(rows, Kp)
+            Xp[:, :K] = X.detach()
         Hs = eng.relu_stack_fwd(layers, Xp, Kp, rows)
         head = layers[3]
         no = head.N

@@ -11,6 +11,7 @@ from . import torch_glue as G
 
 
 FUSED_COMBINE = True     # False: the eager formulation everywhere (the parity tests' checker)
+FUSED_ENCODE = True      # False: the stacks' inputs from separate encoding ops + torch glue (checker of nu_s2_shade_encode_*)
 
 
 def offset_points_to_sphere(points):
@@ -86,6 +87,23 @@ def shade(nets, scfg, lut, points, normals, view_dirs, feats, s2=False, is_inter
     n, v = F.normalize(normals, dim=-1), F.normalize(view_dirs, dim=-1)
     nov = torch.sum(n * v, -1, keepdim=True)
     refl = nov * n * 2 - v
+    if FUSED_COMBINE and FUSED_ENCODE and not inter_results and points.is_cuda and points.shape[0] > 0:
+        # materials -> ONE kernel for every stack's padded input rows (n^, v^, NoV, r, IDE / position / refraction codes, sphere
+        # points) with gradients to points, normals, view directions and the roughness logit -> the four stacks -> BRDF mix
+        from . import stage2_ops as O
+        m_raw = nets.materials(feats, points)
+        rf = -1 if s2 else int(scfg.get('refrac_freq', 6))
+        OL, IL, IW, RL, nov1, SD = O.shade_encode(nets.eng, points, normals, view_dirs, m_raw, sphere, pos_freq, rf)
+        ol, il, iw = nets.predictor('outer_light', OL), nets.predictor('inner_light', IL), nets.predictor('inner_weight', IW)
+        rl = None
+        if not s2:
+            rl = nets.predictor('refrac_light', RL)
+            if rl_max < exp_max:
+                rl = torch.clamp(rl, max=rl_max)
+        if aux is not None:
+            aux.update(occ_raw=iw, reflective=SD[:, 8:11])
+        color, rc = O.shade_combine(nets.eng, m_raw, ol, il, iw, rl, nov1[:, None], lut, exp_max, s2=s2, internal=is_internal)
+        return color, (rc if s2 else None)
     if FUSED_COMBINE and not inter_results and points.is_cuda and points.shape[0] > 0:
         from . import stage2_ops as O
         m_raw = nets.materials(feats, points)

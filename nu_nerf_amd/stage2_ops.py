@@ -270,6 +270,56 @@ def far_importance_nodes(eng, start, dirs):
     return zout
 
 
+class _ShadeEncodeFn(torch.autograd.Function):
+    """Inputs of the shading stacks from explicit points / normals / view directions (nu_s2_shade_encode_*), with gradients
+    w.r.t. all of them and the roughness logit."""
+
+    @staticmethod
+    def forward(ctx, eng, x, nrm, view, m_raw, sphere, pos_freq, refrac_freq, ld_ol, ld_rl):
+        x, nrm, view, m = (t.detach().contiguous() for t in (x, nrm, view, m_raw))
+        P, dev = x.shape[0], x.device
+        OL, IL, IW = torch.empty(3 * P, ld_ol, device=dev), torch.empty(2 * P, 128, device=dev), torch.empty(P, 96, device=dev)
+        RL = torch.empty(P, ld_rl, device=dev) if refrac_freq >= 0 else None
+        SD = torch.empty(P, 12, device=dev)
+        L.check(eng.lib.nu_s2_shade_encode_fwd(c_p(addr(x)), c_p(addr(nrm)), c_p(addr(view)), c_p(addr(m)), m.shape[1], P, 1 if sphere else 0,
+                                               pos_freq, ld_ol, refrac_freq, ld_rl, c_p(addr(OL)), c_p(addr(IL)), c_p(addr(IW)), c_p(addr(RL)),
+                                               c_p(addr(SD)), eng.stream()), "nu_s2_shade_encode_fwd")
+        ctx.eng, ctx.k = eng, (sphere, pos_freq, refrac_freq, ld_ol, ld_rl, m.shape[1])
+        ctx.save_for_backward(x, nrm, view, SD)
+        ctx.mark_non_differentiable(IW, SD)
+        ctx.set_materialize_grads(False)
+        if RL is None:
+            RL = torch.empty(0, device=dev)
+            ctx.mark_non_differentiable(RL)
+        return OL, IL, IW, RL, SD[:, 3].clone(), SD
+
+    @staticmethod
+    def backward(ctx, dOL, dIL, _dIW, dRL, dnov, _dSD):
+        x, nrm, view, SD = ctx.saved_tensors
+        sphere, pos_freq, refrac_freq, ld_ol, ld_rl, mcols = ctx.k
+        P = x.shape[0]
+        dx, dn, dv = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+        dm = torch.zeros(P, mcols, device=x.device)
+        drho = torch.empty(P, device=x.device)
+        cg = lambda t: t.contiguous() if t is not None else None
+        dOL, dIL, dnov = cg(dOL), cg(dIL), cg(dnov)
+        dRL = cg(dRL) if refrac_freq >= 0 else None
+        L.check(ctx.eng.lib.nu_s2_shade_encode_bwd(c_p(addr(x)), c_p(addr(nrm)), c_p(addr(view)), c_p(addr(SD)), P, 1 if sphere else 0,
+                                                   pos_freq, ld_ol, refrac_freq, ld_rl, c_p(addr(dOL)), c_p(addr(dIL)), c_p(addr(dRL)),
+                                                   c_p(addr(dnov)), c_p(addr(dx)), c_p(addr(dn)), c_p(addr(dv)), c_p(addr(drho)),
+                                                   ctx.eng.stream()), "nu_s2_shade_encode_bwd")
+        dm[:, 1] = drho
+        return None, dx, dn, dv, dm, None, None, None, None, None
+
+
+def shade_encode(eng, x, nrm, view, m_raw, sphere, pos_freq, refrac_freq):
+    """-> (OLin [3P, ld_ol], ILin [2P,128], IWin [P,96] (no gradient), RLin [P, ld_rl] or None, NoV [P], SD [P,12]): the padded input
+    rows of the outer_light / inner_light / inner_weight / refrac_light stacks of `eng` (include/nu_nerf.h nu_s2_shade_encode_*)."""
+    OL, IL, IW, RL, nov, SD = _ShadeEncodeFn.apply(eng, x, nrm, view, m_raw, bool(sphere), int(pos_freq), int(refrac_freq), eng.ld_ol,
+                                                   eng.ld_rl)
+    return OL, IL, IW, (RL if refrac_freq >= 0 else None), nov, SD
+
+
 class _ShadeCombineFn(torch.autograd.Function):
     """The BRDF mix on raw head outputs (nu_shade_combine_* for AppShadingNetwork.forward, nu_s2_shade_combine_* for
     AppShadingNetwork_S2.forward): sigmoids of the material heads, exp(min(., exp_max)) of the light heads, occlusion mix, Schlick

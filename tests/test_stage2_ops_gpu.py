@@ -200,6 +200,7 @@ def test_fused_brdf_mix_matches_the_eager_shading(gpu, s2, internal):
     res = {}
     for fused in (True, False):
         SG.FUSED_COMBINE = fused
+        SG.FUSED_ENCODE = False       # the stacks' inputs from the same separate ops on both sides: this test is about the mix
         try:
             n1.begin_pass()
             ins = [t.clone().requires_grad_(True) for t in base]
@@ -209,6 +210,7 @@ def test_fused_brdf_mix_matches_the_eager_shading(gpu, s2, internal):
             res[fused] = (color.detach(), rc.detach() if s2 else None, grads)
         finally:
             SG.FUSED_COMBINE = True
+            SG.FUSED_ENCODE = True
     torch.testing.assert_close(res[True][0], res[False][0], rtol=1e-5, atol=1e-6)
     if s2:
         torch.testing.assert_close(res[True][1], res[False][1], rtol=1e-5, atol=1e-6)
@@ -360,3 +362,150 @@ def test_generic_embedding_matches_the_eager_formula(gpu, n_freq):
     (gx,) = torch.autograd.grad((out * gcot).sum(), x)
     (rx,) = torch.autograd.grad((ref * gcot.double()).sum(), xr)
     assert float((gx.double() - rx).abs().max()) <= 2e-5 * float(rx.abs().max())
+
+
+@pytest.mark.parametrize("which", ["surface_s2_sphere", "inner_specinner_sphere", "inner_plain"])
+def test_fused_shade_encode_matches_the_separate_encoding_ops(gpu, which):
+    """nu_s2_shade_encode_* (one kernel for every stack's input rows, gradients w.r.t. points / normals / view directions /
+    roughness) against the separate encoding ops + torch glue it replaces, through shade(): colour, (1 - F) T and the gradients
+    w.r.t. every input and parameter.  Cases: the surface shader with sphere directions, AppShadingNetwork_SpecInner (8 position /
+    2 refraction frequencies, sphere directions), the plain inner shader (6 / 6, no sphere directions); points inside and outside
+    radius 0.999 (the sphere-point offset branch), normals and view directions of arbitrary length."""
+    from nu_nerf_amd import shading_glue as SG
+    if which == "inner_plain":
+        net, _ = _eng(gpu)
+        nets, ccfg, lut, s2 = net.nets()[1], net.color_network_inner.cfg, net.color_network_inner.FG_LUT, False
+        params = [p for p in net.color_network_inner.parameters() if p.requires_grad]
+    else:
+        from helpers import golden
+        from test_stage2_thick_gpu import build_thick
+        net, _ = build_thick(gpu, golden("stage2_thick_step6000_r24.npz"))
+        n1, n2 = net.nets()
+        if which == "surface_s2_sphere":
+            s1c = net.stage1_network.color_network
+            nets, ccfg, lut, s2 = n1, s1c.cfg, s1c.FG_LUT, True
+            params = [p for p in s1c.parameters() if p.requires_grad]
+        else:
+            nets, ccfg, lut, s2 = n2, net.color_network_inner.cfg, net.color_network_inner.FG_LUT, False
+            params = [p for p in net.color_network_inner.parameters() if p.requires_grad]
+    nets.eng.pack()
+    torch.manual_seed(77)
+    P = 301
+    x = F.normalize(torch.randn(P, 3, device=gpu), dim=-1) * (0.2 + 1.0 * torch.rand(P, 1, device=gpu))     # |x| from 0.2 to 1.2
+    base = [x, torch.randn(P, 3, device=gpu) * 1.7, torch.randn(P, 3, device=gpu) * 0.6, 0.3 * torch.randn(P, 256, device=gpu)]
+    gcol, grc = torch.randn(P, 3, device=gpu), torch.randn(P, 1, device=gpu)
+    res = {}
+    for fused in (True, False):
+        SG.FUSED_ENCODE = fused
+        try:
+            nets.begin_pass()
+            ins = [t.clone().requires_grad_(True) for t in base]
+            aux = {}
+            color, rc = SG.shade(nets, ccfg, lut, ins[0], ins[1], ins[2], ins[3], s2=s2, aux=aux)
+            loss = (color * gcol).sum() + ((rc * grc).sum() if s2 else 0.0) + (aux['occ_raw'] * grc).sum()
+            grads = torch.autograd.grad(loss, ins + params, allow_unused=True)
+            res[fused] = (color.detach(), rc.detach() if s2 else None, aux['reflective'].detach(), grads)
+        finally:
+            SG.FUSED_ENCODE = True
+    # Integration-level tolerances: the two paths round the reflected direction differently (kernel FMA vs torch ops, 1e-7), and
+    # the degree-16 terms of the directional encoding amplify that by ~1e4 in fp32 on either side (their Legendre coefficients
+    # reach 1e5); the tight checks of the kernel pair itself are in test_shade_encode_kernels_vs_float64.
+    torch.testing.assert_close(res[True][0], res[False][0], rtol=5e-4, atol=2e-4)
+    torch.testing.assert_close(res[True][2], res[False][2], rtol=1e-5, atol=1e-6)
+    if s2:
+        torch.testing.assert_close(res[True][1], res[False][1], rtol=1e-5, atol=1e-6)
+    n_checked = 0
+    for i, (a, b) in enumerate(zip(res[True][3], res[False][3])):
+        if b is None or float(b.abs().max()) == 0.0:
+            assert a is None or float(a.abs().max()) <= 1e-12, i
+            continue
+        scale = float(b.abs().max())
+        assert float((a - b).abs().max()) <= 1e-1 * scale + 1e-7, (i, float((a - b).abs().max()), scale)       # wiring errors are O(1)
+        assert float((a - b).norm()) <= 2e-2 * float(b.norm()) + 1e-7, (i, float((a - b).norm()), float(b.norm()))
+        n_checked += 1
+    assert n_checked >= 10
+
+
+@pytest.mark.parametrize("sphere,pos_freq,rf", [(False, 6, 6), (True, 6, -1), (True, 8, 2)])
+def test_shade_encode_kernels_vs_float64(gpu, sphere, pos_freq, rf):
+    """nu_s2_shade_encode_fwd / _bwd against the same formulas in float64 torch on the CPU (field.py:636-682, :828-907): every
+    stack's input rows, NoV, the reflected direction, and the gradients w.r.t. points, normals, view directions and the roughness
+    logit for random cotangents.  Points on both sides of radius 0.999 (the sphere-point offset)."""
+    import types
+    from nu_nerf_amd import stage2_ops as O
+    from nu_nerf_amd import shading_glue as SG
+    from nu_nerf_amd import torch_glue as G
+    net, n1 = _eng(gpu)
+    eng = types.SimpleNamespace(lib=n1.eng.lib, stream=n1.eng.stream, ld_ol=160 if sphere else 96, ld_rl=max(32, -(-2 * (3 + 6 * max(rf, 0)) // 32) * 32))
+    torch.manual_seed(3 + pos_freq)
+    P = 211
+    x = F.normalize(torch.randn(P, 3), dim=-1) * (0.2 + 1.0 * torch.rand(P, 1))
+    nrm, view, m_raw = torch.randn(P, 3) * 1.7, torch.randn(P, 3) * 0.6, torch.randn(P, 6)
+    ins = [t.to(gpu).requires_grad_(True) for t in (x, nrm, view, m_raw)]
+    OL, IL, IW, RL, nov, SD = O.shade_encode(eng, *ins, sphere, pos_freq, rf)
+    # ---- float64 reference ----
+    xd, nd, vd, md = (t.double().requires_grad_(True) for t in (x, nrm, view, m_raw))
+    mt, lt, mat = G._ide_tables(torch.device('cpu'))
+
+    def ide64(d, kinv):
+        xx, yy, zz = d[..., 0:1], d[..., 1:2], d[..., 2:3]
+        zp = torch.cat([torch.ones_like(zz)] + [zz ** i for i in range(1, 17)], -1)
+        re, im = [torch.ones_like(xx)], [torch.zeros_like(xx)]
+        for _ in range(16):
+            re.append(re[-1] * xx - im[-1] * yy)
+            im.append(re[-2] * yy + im[-1] * xx)
+        re, im = torch.cat(re, -1)[..., mt], torch.cat(im, -1)[..., mt]
+        att = torch.exp(-0.5 * lt.double() * (lt.double() + 1) * kinv)
+        poly = zp @ mat.double()
+        return torch.cat([re * poly * att, im * poly * att], -1)
+    n, v = F.normalize(nd, dim=-1), F.normalize(vd, dim=-1)
+    nov_r = torch.sum(n * v, -1, keepdim=True)
+    refl = nov_r * n * 2 - v
+    rho = torch.sigmoid(md[:, 1:2])
+    one, zero = torch.ones_like(rho), torch.zeros_like(rho)
+    enc = [ide64(n, one), ide64(refl, rho), ide64(refl, zero)]
+    if sphere:
+        sn, sr = SG.sphere_point(xd, n), SG.sphere_point(xd, refl)
+        enc = [torch.cat([enc[0], ide64(sn, one)], -1), torch.cat([enc[1], ide64(sr, rho)], -1), torch.cat([enc[2], ide64(sr, rho)], -1)]
+    OL_r = torch.cat(enc, 0)
+    pe = G.embed(xd, pos_freq)
+    IL_r = torch.cat([torch.cat([pe, ide64(refl, rho)], -1), torch.cat([pe, ide64(refl, zero)], -1)], 0)
+    IW_r = torch.cat([pe, G.embed(refl, 6)], -1)
+    RL_r = torch.cat([G.embed(xd, rf), G.embed(v, rf)], -1) if rf >= 0 else None
+    # fp32 Horner evaluation of a term's polynomial in z carries eps * sum_k |c_k| of absolute error: the degree-16 terms have
+    # coefficient sums up to 1e5, so their columns are compared (and, below, differentiated) with that conditioning in mind
+    kappa = mat.double().abs().sum(0)                                       # [36] per term
+    kap72 = torch.cat([kappa, kappa])
+    well = kap72 < 300.0                                                    # terms up to degree 8
+    tol72 = 2e-5 + 4e-7 * kap72
+
+    def col_tol(ncols, ide_starts):
+        t = torch.full((ncols,), 2e-5, dtype=torch.float64)
+        for s0 in ide_starts:
+            t[s0:s0 + 72] = tol72
+        return t
+    pe_dim = 3 + 6 * pos_freq
+    pairs = [(OL, OL_r, col_tol(OL_r.shape[1], [0, 72] if sphere else [0])), (IL, IL_r, col_tol(IL_r.shape[1], [pe_dim])),
+             (IW, IW_r, col_tol(IW_r.shape[1], []))] + ([(RL, RL_r, col_tol(RL_r.shape[1], []))] if rf >= 0 else [])
+    for got, ref, tol in pairs:
+        k = ref.shape[1]
+        err = (got.detach().cpu()[:, :k].double() - ref.detach()).abs()
+        assert bool((err <= tol[None, :] + 1e-4 * ref.detach().abs()).all()), float((err / tol[None, :]).max())
+        assert float(got.detach()[:, k:].abs().max() if got.shape[1] > k else 0.0) == 0.0           # zero padding
+    torch.testing.assert_close(nov.detach().cpu().double(), nov_r.detach()[:, 0], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(SD.cpu()[:, 8:11].double(), refl.detach(), rtol=1e-5, atol=1e-6)
+    # ---- gradients for random cotangents (IWin carries none) ----
+    # (cotangents only on the well-conditioned encoding columns: the degree-16 terms run through the same code with other table rows)
+    c_ol, c_il = torch.randn(OL_r.shape), torch.randn(IL_r.shape)
+    for s0 in ([0, 72] if sphere else [0]):
+        c_ol[:, s0:s0 + 72] *= well
+    c_il[:, pe_dim:pe_dim + 72] *= well
+    cots = [c_ol, c_il, torch.randn(P)] + ([torch.randn(RL_r.shape)] if rf >= 0 else [])
+    outs = [OL, IL, nov] + ([RL] if rf >= 0 else [])
+    refs = [OL_r, IL_r, nov_r[:, 0]] + ([RL_r] if rf >= 0 else [])
+    loss = sum((o[..., :c.shape[-1]] * c.to(gpu)).sum() if o.dim() == 2 else (o * c.to(gpu)).sum() for o, c in zip(outs, cots))
+    got = torch.autograd.grad(loss, ins)
+    want = torch.autograd.grad(sum((r * c.double()).sum() for r, c in zip(refs, cots)), (xd, nd, vd, md))
+    for a, b, name in zip(got, want, ('x', 'normal', 'view', 'm_raw')):
+        err, scale = float((a.cpu().double() - b).abs().max()), float(b.abs().max())
+        assert err <= 2e-4 * scale + 1e-6, (name, err, scale)
