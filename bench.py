@@ -149,7 +149,10 @@ def main_stage2(args):
         net.load_param_dict(p2)
     net = net.to(dev)
     losses = [name2loss[n](cfg) for n in ('eikonal', 'std', 'nerf_render')]
-    opt = FusedAdam([p for p in net.parameters() if p.requires_grad], lr=1e-3)
+    # lr 1e-5: the full optimizer step runs, but the light paths (which rays refract, how many samples fall inside the object) stay
+    # what the initial weights give for the whole run -- with untrained networks and lr 1e-3 the IoR network drifts within a few
+    # steps towards invalidating rays (masked out of the loss), and the work per step with it (scripts/stage2_thick_trajectory.py)
+    opt = FusedAdam([p for p in net.parameters() if p.requires_grad], lr=1e-5)
     R, n = args.rays, args.steps + args.warmup
     pool = (make_object_rays if args.object_rays else make_rays)(R * n, seed=6033)
     pool = {k: torch.from_numpy(v).to(dev) for k, v in pool.items() if k in ('rays_o', 'rays_d', 'rgbs')}

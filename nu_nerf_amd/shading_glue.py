@@ -4,6 +4,8 @@ Used where the fused stage-1 shading kernels do not apply: stage 2 (input gradie
 sets) and validation rendering (intermediate images wanted).  Every MLP GEMM still runs in libnunerf.so.
 Reference: AppShadingNetwork.forward / predict_specular_lights / predict_diffuse_lights (network/field.py:636-777),
 AppShadingNetwork_S2.forward (field.py:909-1010)."""
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -11,7 +13,8 @@ from . import torch_glue as G
 
 
 FUSED_COMBINE = True     # False: the eager formulation everywhere (the parity tests' checker)
-FUSED_ENCODE = True      # False: the stacks' inputs from separate encoding ops + torch glue (checker of nu_s2_shade_encode_*)
+# False (or NU_FUSED_ENCODE=0): the stacks' inputs from separate encoding ops + torch glue (checker of nu_s2_shade_encode_*)
+FUSED_ENCODE = os.environ.get('NU_FUSED_ENCODE', '1') != '0'
 
 
 def offset_points_to_sphere(points):
