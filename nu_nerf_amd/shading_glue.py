@@ -1,4 +1,5 @@
-"""Surface shading assembled from the HIP network ops (nets.Stage1Nets) with torch glue for the BRDF algebra.
+"""Surface shading assembled from the HIP network ops (nets.Stage1Nets): stack inputs (nu_s2_shade_encode_*), the predictor /
+material stacks, the BRDF mix (nu_(s2_)shade_combine_*); the eager torch formulation below serves validation images and the tests.
 
 Used where the fused stage-1 shading kernels do not apply: stage 2 (input gradients needed, ragged per-bounce point
 sets) and validation rendering (intermediate images wanted).  Every MLP GEMM still runs in libnunerf.so.

@@ -10,7 +10,8 @@ the learned index of refraction:
   * refraction / total internal reflection: nu_s2_refract_*;
   * sample placement: the stage-1 sampler kernels for the inner-SDF up-sampling, nu_s2_far_* for the NeRF++ importance pass;
   * the outer samples of all segments: nu_s2_seg_* + ONE NeRF++ pass; inner segment: nu_s2_neus_alpha_*;
-  * shading: encodings (nu_ide, nu_embed) + predictor stacks + one BRDF-mix kernel pair (nu_s2_shade_combine_*, shading_glue.py);
+  * shading: one kernel pair for the stacks' inputs (nu_s2_shade_encode_*) + predictor stacks + one BRDF-mix kernel pair
+    (nu_s2_shade_combine_*, shading_glue.py);
   * per-segment composite in linear RGB with the running transmittance: nu_s2_composite_*.
 torch is left with index bookkeeping (one nonzero per mask, index_select / index_add) and O(rays) glue.
 state_dict() names/order equal the reference's (574 entries incl. the `color_network.stage1_network.*` aliases).
