@@ -145,6 +145,9 @@ typedef struct NuPackDesc {
 int nu_pack_desc_size(void);
 int nu_pack_layers(const void* descs_dev, int ndesc, int total_rows, hipStream_t stream);
 int nu_unpack_grads(const void* descs_dev, int ndesc, int total_rows, float* flat_grads, hipStream_t stream);
+/* The same for the rows [row0, row0 + nrows) of the table only (rows are numbered through all layers in descriptor order): what one
+ * network-level op of stage 2 owns -- its weight-norm gradients land in `flat_grads`, every other slot stays untouched. */
+int nu_unpack_grads_range(const void* descs, int ndesc, int row0, int nrows, float* flat_grads, hipStream_t stream);
 
 /* 1..6-wide output heads (field.py:393 final Linear of make_predictor; :260-261 alpha_linear / rgb_linear) */
 int nu_skinny_fwd(const float* H, int ldh, int P, int K, const float* Ws, int ldw, const float* b, int NO, float* out,

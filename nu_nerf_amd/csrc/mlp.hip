@@ -45,8 +45,8 @@ __global__ __launch_bounds__(64) void pack_kernel(const NuPackDesc* __restrict__
 }
 
 __global__ __launch_bounds__(64) void unpack_kernel(const NuPackDesc* __restrict__ descs, int nd,
-                                                    float* __restrict__ flat) {
-    const int row = blockIdx.x;
+                                                    float* __restrict__ flat, int row0) {
+    const int row = blockIdx.x + row0;
     const int lane = threadIdx.x;
     const NuPackDesc d = descs[nu_find_desc(descs, nd, row)];
     const int n = row - d.row_begin;
@@ -86,7 +86,13 @@ extern "C" int nu_pack_layers(const void* descs, int ndesc, int total_rows, hipS
 }
 extern "C" int nu_unpack_grads(const void* descs, int ndesc, int total_rows, float* flat_grads, hipStream_t stream) {
     if (total_rows <= 0) return NU_OK;
-    hipLaunchKernelGGL(unpack_kernel, dim3(total_rows), dim3(64), 0, stream, (const NuPackDesc*)descs, ndesc, flat_grads);
+    hipLaunchKernelGGL(unpack_kernel, dim3(total_rows), dim3(64), 0, stream, (const NuPackDesc*)descs, ndesc, flat_grads, 0);
+    return nu_launch_status();
+}
+extern "C" int nu_unpack_grads_range(const void* descs, int ndesc, int row0, int nrows, float* flat_grads, hipStream_t stream) {
+    if (nrows <= 0) return NU_OK;
+    if (row0 < 0) return NU_ERR_ARG;
+    hipLaunchKernelGGL(unpack_kernel, dim3(nrows), dim3(64), 0, stream, (const NuPackDesc*)descs, ndesc, flat_grads, row0);
     return nu_launch_status();
 }
 extern "C" int nu_pack_desc_size() { return (int)sizeof(NuPackDesc); }

@@ -358,7 +358,8 @@ class Stage1Engine:
         self.nerf_alpha = plain('outer_nerf.alpha_linear', 256)
         self.nerf_view = plain('outer_nerf.views_linears.0', 288)
         self.nerf_rgb = plain('outer_nerf.rgb_linear', 128)
-        layers += nerf + [self.nerf_feat, self.nerf_alpha, self.nerf_view, self.nerf_rgb]
+        self.nerf_all = nerf + [self.nerf_feat, self.nerf_alpha, self.nerf_view, self.nerf_rgb]     # consecutive in the table
+        layers += self.nerf_all
 
         # ---- shading: material predictors (batched) ----
         mats = ['metallic_predictor', 'roughness_predictor', 'albedo_predictor', 'transmisstion_weight']
@@ -485,6 +486,7 @@ class Stage1Engine:
             d.bias = addr(l.b) if (l.bias_p is not None) else 0
             d.bias_p = addr(*l.bias_p) if l.bias_p is not None else 0
             d.scale, d.N, d.K, d.Kp, d.ldT, d.ldd, d.row_begin, d.col_off = l.scale, l.N, l.K, l.Kp, l.ldT, l.ldd, row, l.col_off
+            l.row_begin = row
             row += l.N
         self.total_rows = row
         raw = bytes(descs)
@@ -544,10 +546,25 @@ class Stage1Engine:
         L.check(self.lib.nu_pack_layers(c_p(self._desc_dev.data_ptr()), len(self.layers), self.total_rows, self.stream()),
                 "nu_pack_layers")
 
-    def unpack_grads(self, flat):
+    def unpack_grads(self, flat, layers=None):
+        """Weight-norm / plain weight gradients from the packed dW tables into `flat`.  layers: only these (consecutive entries of
+        self.layers -- one network of a stage-2 op): every other slot of `flat` stays untouched."""
         self.flush_reductions()
-        L.check(self.lib.nu_unpack_grads(c_p(self._desc_dev.data_ptr()), len(self.layers), self.total_rows,
-                                         c_p(flat.data_ptr()), self.stream()), "nu_unpack_grads")
+        if layers is None:
+            L.check(self.lib.nu_unpack_grads(c_p(self._desc_dev.data_ptr()), len(self.layers), self.total_rows,
+                                             c_p(flat.data_ptr()), self.stream()), "nu_unpack_grads")
+            return
+        key = id(layers)
+        rng = self.__dict__.setdefault('_unpack_ranges', {}).get(key)
+        if rng is None or rng[0] is not layers:
+            row0, rows = layers[0].row_begin, 0
+            for l in layers:
+                if l.row_begin != row0 + rows:
+                    raise ValueError("unpack_grads(layers=...): the layers are not consecutive in the descriptor table")
+                rows += l.N
+            rng = self._unpack_ranges[key] = (layers, row0, rows)
+        L.check(self.lib.nu_unpack_grads_range(c_p(self._desc_dev.data_ptr()), len(self.layers), rng[1], rng[2], c_p(flat.data_ptr()),
+                                               self.stream()), "nu_unpack_grads_range")
 
     # ------------------------------------------------------------------ raw launches
     def nt(self, A, lda, B, ldb, M, N, K, C, ldc, epi, *, C2=0, ldc2=0, bias=0, H=0, ldh=0, D=0, ldd=0, Cadd=0,

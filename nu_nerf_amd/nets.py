@@ -33,7 +33,8 @@ def _grads_from_flat(eng, flat, names):
 
 
 def _own_range(eng, names):
-    """[lo, hi) of the flat gradient buffer that the parameters `names` occupy (one network's parameters are contiguous)."""
+    """[lo, hi) of the flat gradient buffer that the parameters `names` occupy (one network's parameters are contiguous: each
+    op's backward writes exactly this range of its zero-filled buffer)."""
     cache = eng.__dict__.setdefault('_range_cache', {})
     hit = cache.get(id(names))
     if hit is not None and hit[0] is names:
@@ -51,13 +52,10 @@ def _own_range(eng, names):
 
 
 def _token_grad(eng, flat, names):
-    """This op's share of the flat gradient buffer: its own parameters' range, zero elsewhere (unpack_grads rewrites every
-    layer's slots from the packed tables, which may hold another op's values)."""
-    lo, hi = _own_range(eng, names)
-    g = torch.zeros_like(flat)
-    g[lo:hi] = flat[lo:hi]
+    """This op's share of the flat gradient buffer: `flat` itself -- it was zero-filled, the op's kernels wrote its bias gradients
+    and unpack_grads(flat, layers=<the op's network>) its weight gradients, nothing else."""
     eng._hub_touched.update(names)           # parameters no op touched keep grad None (optimizer state is created lazily)
-    return g
+    return flat
 
 
 class ParamHubFn(torch.autograd.Function):
@@ -102,7 +100,7 @@ class SdfFn(torch.autograd.Function):
         nbar = dn.contiguous() if dn is not None else None
         dx = eng.empty(P, 3)
         eng.sdf_backward(a, dYX, nbar, flat, dx=dx)
-        eng.unpack_grads(flat)
+        eng.unpack_grads(flat, eng.sdf)
         ctx.a = None
         return None, dx, None, _token_grad(eng, flat, ctx.names)
 
@@ -130,7 +128,7 @@ class NerfFn(torch.autograd.Function):
             dr[:, :3] = drgb
         dx, dd = eng.empty(P, 3), eng.empty(P, 3)
         eng.nerf_backward(b, pt, None, None, None, flat, dsig=ds, drgb=dr, dx=dx, ddir=dd)
-        eng.unpack_grads(flat)
+        eng.unpack_grads(flat, eng.nerf_all)
         ctx.b = None
         return None, dx, dd, None, _token_grad(eng, flat, ctx.names)
 
@@ -170,7 +168,7 @@ class StackFn(torch.autograd.Function):
                        addr(*head.dWp), head.ldd, addr(flat, head.db_off))
         dX = eng.empty(rows, Kp)
         eng.relu_stack_bwd(layers, Xp, Kp, rows, Hs, dH3, flat, dX, Kp, Kp)
-        eng.unpack_grads(flat)
+        eng.unpack_grads(flat, layers)
         ctx.Hs = ctx.Xp = None
         return None, None, dX[:, :ctx.K], None, _token_grad(eng, flat, ctx.names)
 
@@ -223,7 +221,7 @@ class MaterialsFn(torch.autograd.Function):
         eng.wgrad(addr(dA), 1024, addr(s['YX']), 288, P, 1024, 288, addr(eng.dWpM0), 288, addr(flat, db0))
         dYX = e(P, 288)
         eng.nt(addr(dA), 1024, addr(eng.WpTM0), 1024, P, 288, 1024, addr(dYX), 288, EPI_PLAIN)
-        eng.unpack_grads(flat)
+        eng.unpack_grads(flat, eng.mat_layers)
         ctx.s = None
         return None, dYX[:, 1:257], dYX[:, 257:260], None, _token_grad(eng, flat, ctx.names)
 
@@ -268,7 +266,7 @@ class IorFn(torch.autograd.Function):
         eng.wgrad(addr(d0), 256, addr(Xp), 64, rows, 256, 64, addr(*ls[0].dWp), ls[0].ldd, addr(flat, ls[0].db_off))
         dX = eng.empty(rows, 64)
         eng.nt(addr(d0), 256, addr(*ls[0].WpT), ls[0].ldT, rows, 64, 256, addr(dX), 64, EPI_PLAIN)
-        eng.unpack_grads(flat)
+        eng.unpack_grads(flat, ls)
         ctx.H = ctx.Xp = None
         return None, None, dX[:, :ctx.K], None, _token_grad(eng, flat, ctx.names)
 
@@ -298,6 +296,9 @@ class Stage1Nets:
         self.ior_names, _ = sel(lambda n: n.startswith('ior_network.'))
         self.thick_names, _ = sel(lambda n: n.startswith('thickness_network.'))
         self.all_names = [n for n in g if n in named and isinstance(named[n], torch.nn.Parameter)]
+        for names in [self.sdf_names, self.nerf_names, self.mat_names, self.ior_names, self.thick_names] + [v[1] for v in self.stack.values()]:
+            if names:
+                _own_range(eng, names)       # every op's parameters form ONE range of the flat buffer (asserted once, here)
         self._token = None
 
     def begin_pass(self):

@@ -75,7 +75,7 @@ class _OuterSegmentsFn(torch.autograd.Function):
             L.check(lib.nu_s2_ddist(c_p(addr(ctx.b['sig'])), c_p(addr(pt)), c_p(addr(idx)), P, c_p(addr(da)), c_p(addr(ddist)), S_),
                     "nu_s2_ddist")
             eng.nerf_backward(ctx.b, pt[:P], idx, da, dc, flat, dx=dx, ddir=dd)
-            eng.unpack_grads(flat)
+            eng.unpack_grads(flat, eng.nerf_all)
         for i, ((st, v, z, d), (n, s1)) in enumerate(zip(segs, dims)):
             gs, gv, gd = torch.zeros_like(st), torch.zeros_like(v), torch.zeros_like(d)
             if n > 0 and P > 0:

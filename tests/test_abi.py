@@ -34,7 +34,7 @@ def test_header_declares_the_expected_surface():
                  "nu_s2_seg_count", "nu_s2_seg_write", "nu_s2_ddist", "nu_s2_seg_bwd", "nu_s2_composite_fwd", "nu_s2_composite_bwd",
                  "nu_s2_refract_fwd", "nu_s2_refract_bwd", "nu_s2_hit_fwd", "nu_s2_hit_bwd", "nu_s2_far_points", "nu_s2_far_resample",
                  "nu_s2_shade_combine_fwd", "nu_s2_shade_combine_bwd", "nu_s2_neus_alpha_fwd", "nu_s2_neus_alpha_bwd",
-                 "nu_skinny_fwd_h16", "nu_skinny_bwd_enqueue_h16", "nu_s2_shell_fwd", "nu_s2_shell_bwd", "nu_embed_n_fwd", "nu_embed_n_bwd", "nu_s2_shade_encode_fwd", "nu_s2_shade_encode_bwd"):
+                 "nu_skinny_fwd_h16", "nu_skinny_bwd_enqueue_h16", "nu_s2_shell_fwd", "nu_s2_shell_bwd", "nu_embed_n_fwd", "nu_embed_n_bwd", "nu_s2_shade_encode_fwd", "nu_s2_shade_encode_bwd", "nu_unpack_grads_range"):
         assert must in names
     assert len(names) >= 50
 

@@ -278,7 +278,8 @@ def test_stage2_parameter_hub_hands_each_parameter_its_slice_once_cpu_side():
         N._own_range(eng, ['a.w', 'b.w'])                      # not contiguous: the op would leak another op's slots
 
     class Op(torch.autograd.Function):
-        """A stand-in network op: its backward fills the WHOLE flat buffer (as unpack_grads does) and returns its own share."""
+        """A stand-in network op: its backward writes its own slots of a zero-filled flat buffer (as the ops' kernels and
+        unpack_grads(flat, layers=...) do) and returns it."""
         @staticmethod
         def forward(ctx, x, own, fill, token):
             ctx.own, ctx.fill = own, fill
@@ -286,7 +287,9 @@ def test_stage2_parameter_hub_hands_each_parameter_its_slice_once_cpu_side():
 
         @staticmethod
         def backward(ctx, g):
-            flat = torch.full((eng.n_grad,), ctx.fill)
+            flat = torch.zeros(eng.n_grad)
+            lo, hi = N._own_range(eng, ctx.own)
+            flat[lo:hi] = ctx.fill
             return g * 2.0, None, None, N._token_grad(eng, flat, ctx.own)
 
     token = N.ParamHubFn.apply(eng, names, *[params[n] for n in names])
