@@ -48,7 +48,7 @@ class Stage2Renderer(_ZeroThickStage2):
         nn.Module.__init__(self)
         self.cfg = {**self.default_cfg, **cfg}
         self.is_nerf = self.cfg['is_nerf']
-        self.get_mask = self.cfg['get_mask']                           # renderer.py:962 (a missing key is an error there too)
+        self.get_mask = self.cfg['get_mask']                           # renderer.py:962 (default False here; the reference has no default)
         self.IORs = nn.Parameter(torch.zeros(10))
         self.nerf_network = NeRFNetwork()
         self.stage1_network = NeROShapeRenderer(self._load_stage1_cfg(), training=False)

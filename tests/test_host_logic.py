@@ -330,3 +330,33 @@ def test_stage2_thick_fixture_is_reproducible_from_its_manifest():
     # what the reference run produced with those inputs (the numbers the product will have to match)
     assert g['out_ray_rgb'].shape == (24, 3) and int(g['out_tir_mask'].sum()) == 23 and len(g['grad_names']) == 295
     assert [g['path%d' % i].shape[:2] for i in range(3)] == [(24, 64), (15, 128), (15, 64)]
+
+
+def test_stage2_thick_module_has_the_reference_state_dict_and_registry_entry():
+    """The non-zero-thickness Stage2Renderer (network/renderer.py:907-1024) as a module, on the CPU: `name2renderer['stage2']` of the
+    `zero_thickness: False` registry, the reference's 565 state_dict() keys in the reference's order (from the fixture the
+    reference itself wrote), parameter shapes of the manifest, and the initial values a from-scratch run starts with (inner SDF:
+    geometric init; last biases of the light stacks; refraction-light cap)."""
+    from helpers import golden
+    from nu_nerf_amd.stage2_thick import name2renderer, Stage2Renderer, AppShadingNetworkSpecInner
+    from nu_nerf_amd.renderer_std import NeROShapeRenderer as StdStage1
+    from nu_nerf_amd.lbvh import icosphere
+    g = golden("stage2_thick_step6000_r24.npz")
+    assert name2renderer['stage2'] is Stage2Renderer and name2renderer['shape'] is StdStage1
+    shader = {'sphere_direction': True, 'human_light': False, 'light_exp_max': 5.0}
+    cfg = {'name': 's2t', 'network': 'stage2', 'get_mask': False, 'is_nerf': False, 'shader_config': shader,
+           'stage1_cfg': {'name': 's1', 'network': 'shape', 'get_mask': False, 'is_nerf': False, 'shader_config': shader},
+           'stage1_mesh_arrays': icosphere(2, 0.5)}
+    net = Stage2Renderer(cfg, training=False)
+    sd = net.state_dict()
+    assert list(sd.keys()) == [str(k) for k in g['state_dict_keys']] and len(sd) == 565
+    for n, shp in zip(g['manifest_names'], g['manifest_shapes']):
+        assert tuple(sd[str(n)].shape) == tuple(int(x) for x in str(shp).split(',') if x), n
+    assert sd['infinity_far_bkgr.module0.0.weight_v'].data_ptr() == sd['stage1_network.infinity_far_bkgr.module0.0.weight_v'].data_ptr()
+    inner = net.color_network_inner
+    assert isinstance(inner, AppShadingNetworkSpecInner) and inner.cfg['light_pos_freq'] == 8 and inner.cfg['refrac_freq'] == 2
+    assert inner.cfg['refrac_exp_max'] == -0.2
+    assert tuple(sd['color_network_inner.inner_light.0.weight_v'].shape) == (256, 51 + 72)
+    assert tuple(sd['color_network_inner.refrac_light.0.weight_v'].shape) == (256, 30)
+    np.testing.assert_allclose(sd['color_network_inner.outer_light.6.bias'].numpy(), np.log(0.5), rtol=1e-6)
+    np.testing.assert_allclose(sd['sdf_network_inner.lin8.bias'].numpy(), -0.5, rtol=1e-6)          # geometric init, bias 0.5
