@@ -151,6 +151,7 @@ class FusedAdam(torch.optim.Optimizer):
                         g = g.contiguous()
                         keep.append(g)
                     d.g = g.data_ptr()
+                    d.p = p.data_ptr()        # (re-read every step: `module.to(...)` gives a Parameter new storage)
                 bk['count'] += 1
                 self._steps[bk['slots']] += 1
                 L.check(lib.nu_adam_step(descs, len(descs), ctypes.c_double(group['lr']), ctypes.c_double(b1),
