@@ -12,7 +12,7 @@ from helpers import golden
 pytestmark = pytest.mark.gpu
 
 
-def build_thick(gpu, g, losses=('eikonal', 'std', 'nerf_render')):
+def build_thick(gpu, g, losses=('eikonal', 'std', 'nerf_render'), mlp_dtype=None):
     from nu_nerf_amd.stage2_thick import Stage2Renderer
     from nu_nerf_amd.params import init_stage1_params, params_from_manifest, randomize_for_parity
     from nu_nerf_amd.lbvh import icosphere
@@ -23,6 +23,9 @@ def build_thick(gpu, g, losses=('eikonal', 'std', 'nerf_render')):
     cfg = {'name': 'golden_s2t', 'network': 'stage2', 'get_mask': False, 'database_name': 'real/x/raw_1024', 'is_nerf': False,
            'shader_config': shader, 'loss': list(losses), 'eikonal_weight': 0.02, 'freeze_inv_s_step': 5000, 'occ_loss_step': 20000,
            'stage1_cfg': s1cfg, 'stage1_mesh_arrays': icosphere(3, 0.5)}
+    if mlp_dtype is not None:                                # MLP arithmetic mode of both engines (fp32 default)
+        cfg['mlp_dtype'] = mlp_dtype
+        cfg['stage1_cfg'] = dict(s1cfg, mlp_dtype=mlp_dtype)
     if 'mesh_faces' in g:                                    # the open-surface fixture carries its face list
         cfg['stage1_mesh_arrays'] = (cfg['stage1_mesh_arrays'][0], g['mesh_faces'])
     net = Stage2Renderer(cfg, training=False)
@@ -178,3 +181,16 @@ def test_stage2_thick_trainer_protocol(gpu):
     for k in ('normal', 'specular_color', 'specular_light', 'specular_ref'):
         assert ev[k].shape == (576, 3)
     assert ev['gt_depth'].shape == (24, 24, 1) and torch.isfinite(ev['ray_rgb']).all()
+
+
+def test_stage2_thick_train_step_in_the_split_bf16_mode(gpu):
+    """`mlp_dtype: bf16x6` (fp32-equivalent products on the bf16 matrix pipe) on both engines of the stage-2 model:
+    the reference golden step at the fp32 tolerances."""
+    g = golden("stage2_thick_step6000_r24.npz")
+    net, cfg = build_thick(gpu, g, mlp_dtype='bf16x6')
+    assert net.nets()[0].eng.bf16 == 2 and net.nets()[1].eng.bf16 == 2
+    out, total, log = _step(net, cfg, g, gpu)
+    assert np.array_equal(out['tir_mask'].cpu().numpy(), g['out_tir_mask'])
+    np.testing.assert_allclose(out['ray_rgb'].detach().cpu().numpy(), g['out_ray_rgb'], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(float(total.detach()), float(g['total_loss']), rtol=5e-5)
+    _check_gradient_norms(net, g, rtol=5e-3, atol=2e-8)
