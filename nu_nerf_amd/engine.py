@@ -259,6 +259,26 @@ class Stage1Engine:
     def _join(self):
         torch.cuda.current_stream(self.dev).wait_stream(self._side)
 
+    # Stage 2 runs the ops of ONE engine on two streams (the inner segment on the side stream, the IoR / thickness networks on the
+    # caller's): they share this engine's reduction arena and descriptor list, which a flush resets.  The host issues the ops one
+    # after the other, so a total order across the streams is enough: every op that may push reductions waits for the previous such
+    # op of the engine when that ran on another stream (an event, not a stream-wide wait: the other engine's work on that stream
+    # keeps overlapping).
+    def op_begin(self):
+        ev = getattr(self, '_op_ev', None)
+        if ev is not None:
+            cur = torch.cuda.current_stream(self.dev)
+            if cur.cuda_stream != self._op_stream:
+                cur.wait_event(ev)
+
+    def op_end(self):
+        if getattr(self, '_side', None) is None:
+            return                                    # this engine never left its caller's stream
+        cur = torch.cuda.current_stream(self.dev)
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        self._op_ev, self._op_stream = ev, cur.cuda_stream
+
     def relu_mask(self, act, rows, ncols):
         """Sign-bit buffer for a [rows, ncols] ReLU activation (2 KB per 128x128 tile): written by the BIAS_RELU GEMM that
         produces `act`, read by the backward GEMMs instead of `act` itself.  Rides on the activation tensor so that it lives

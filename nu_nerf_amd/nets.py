@@ -92,6 +92,7 @@ class SdfFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, dn):
         eng, a = ctx.eng, ctx.a
+        eng.op_begin()
         P = a['P']
         flat = eng.zeros(eng.n_grad)
         dYX = eng.zeros(P, 288)
@@ -101,6 +102,7 @@ class SdfFn(torch.autograd.Function):
         dx = eng.empty(P, 3)
         eng.sdf_backward(a, dYX, nbar, flat, dx=dx)
         eng.unpack_grads(flat, eng.sdf)
+        eng.op_end()
         ctx.a = None
         return None, dx, None, _token_grad(eng, flat, ctx.names)
 
@@ -120,6 +122,7 @@ class NerfFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dsig, drgb):
         eng, b, pt = ctx.eng, ctx.b, ctx.pt
+        eng.op_begin()
         P = b['P']
         flat = eng.zeros(eng.n_grad)
         ds = dsig.contiguous() if dsig is not None else eng.zeros(P)
@@ -129,6 +132,7 @@ class NerfFn(torch.autograd.Function):
         dx, dd = eng.empty(P, 3), eng.empty(P, 3)
         eng.nerf_backward(b, pt, None, None, None, flat, dsig=ds, drgb=dr, dx=dx, ddir=dd)
         eng.unpack_grads(flat, eng.nerf_all)
+        eng.op_end()
         ctx.b = None
         return None, dx, dd, None, _token_grad(eng, flat, ctx.names)
 
@@ -157,6 +161,7 @@ class StackFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         eng, layers, Xp, Hs = ctx.eng, ctx.layers, ctx.Xp, ctx.Hs
+        eng.op_begin()
         rows, Kp = Xp.shape
         flat = eng.zeros(eng.n_grad)
         dy = eng.zeros(rows, 4)
@@ -169,6 +174,7 @@ class StackFn(torch.autograd.Function):
         dX = eng.empty(rows, Kp)
         eng.relu_stack_bwd(layers, Xp, Kp, rows, Hs, dH3, flat, dX, Kp, Kp)
         eng.unpack_grads(flat, layers)
+        eng.op_end()
         ctx.Hs = ctx.Xp = None
         return None, None, dX[:, :ctx.K], None, _token_grad(eng, flat, ctx.names)
 
@@ -200,6 +206,7 @@ class MaterialsFn(torch.autograd.Function):
     def backward(ctx, dM):
         from .engine import EPI_MUL_DRELU, EPI_PLAIN
         eng, s = ctx.eng, ctx.s
+        eng.op_begin()
         P = s['YX'].shape[0]
         e = eng.empty
         flat = eng.zeros(eng.n_grad)
@@ -222,6 +229,7 @@ class MaterialsFn(torch.autograd.Function):
         dYX = e(P, 288)
         eng.nt(addr(dA), 1024, addr(eng.WpTM0), 1024, P, 288, 1024, addr(dYX), 288, EPI_PLAIN)
         eng.unpack_grads(flat, eng.mat_layers)
+        eng.op_end()
         ctx.s = None
         return None, dYX[:, 1:257], dYX[:, 257:260], None, _token_grad(eng, flat, ctx.names)
 
@@ -251,6 +259,7 @@ class IorFn(torch.autograd.Function):
     def backward(ctx, dout):
         from .engine import EPI_MUL_DRELU, EPI_PLAIN
         eng, ls, Xp, H = ctx.eng, ctx.ls, ctx.Xp, ctx.H
+        eng.op_begin()
         rows = Xp.shape[0]
         flat = eng.zeros(eng.n_grad)
         dy = (dout.contiguous() if dout is not None else eng.zeros(rows)).reshape(rows, 1).contiguous()
@@ -267,6 +276,7 @@ class IorFn(torch.autograd.Function):
         dX = eng.empty(rows, 64)
         eng.nt(addr(d0), 256, addr(*ls[0].WpT), ls[0].ldT, rows, 64, 256, addr(dX), 64, EPI_PLAIN)
         eng.unpack_grads(flat, ls)
+        eng.op_end()
         ctx.H = ctx.Xp = None
         return None, None, dX[:, :ctx.K], None, _token_grad(eng, flat, ctx.names)
 

@@ -300,6 +300,35 @@ class Stage2Renderer(nn.Module):
             root = root.index_select(0, cont_idx)
         return segs, valid[:, None]
 
+    _TWO_STREAM_RAYS = int(os.environ.get('NU_S2_TWO_STREAM_RAYS', 2048))
+
+    def _inner_segment(self, n2, sg, cos_anneal_ratio, step, s):
+        """The samples of the inner segment that lie inside the unit sphere (renderer_zerothick.py:1886-1915): inner SDF + normal,
+        NeuS alpha, inner shading.  -> None without such samples, else (ray, sample) indices, alpha, sRGB colour (4 channels) and
+        the eikonal / std / occlusion terms."""
+        N = sg['start'].shape[0]
+        nodes = self.path_points(sg)[:, :-1, :]
+        inner = torch.norm(nodes, dim=-1) <= 1.0
+        where = inner.nonzero()
+        if where.shape[0] == 0:
+            return None
+        r_i, s_i = where[:, 0], where[:, 1]
+        seglen = torch.linalg.norm(nodes[:, 1:] - nodes[:, :-1], dim=-1)
+        seglen = torch.cat([seglen, seglen[..., -1:]], -1)
+        # (directions through an expanded view, not index_select(0, r_i): its backward would add the many samples of a ray with
+        # float atomics; this way the per-sample cotangents land at unique (ray, sample) slots and the sum over a ray's samples is
+        # an ordinary reduction -- bitwise reproducible)
+        d_in = sg['dirs'][:, None, :].expand(N, nodes.shape[1], 3)[r_i, s_i]
+        x_in, len_in = nodes[r_i, s_i], seglen[r_i, s_i]
+        y, grads = n2.sdf(x_in)
+        a = O.neus_alpha(n2.eng, y[:, 0], grads, d_in, len_in, s, cos_anneal_ratio)
+        aux = {}
+        c, _ = self._shading(n2, self.color_network_inner.cfg, self.color_network_inner.FG_LUT, x_in, grads, -d_in, y[:, 1:], aux=aux)
+        res = dict(r_i=r_i, s_i=s_i, alpha=a, color4=torch.cat([c, torch.zeros_like(c[:, :1])], -1), std=torch.mean(1 / s),
+                   gradient_error=(torch.linalg.norm(grads, dim=-1) - 1.0) ** 2)
+        res.update(self._inner_occ_loss(n2, x_in, y[:, 0], grads, d_in, aux, step))
+        return res
+
     @staticmethod
     def path_points(seg):
         return seg['start'][:, None, :] + seg['v'][:, None, :] * seg['z'][..., None]
@@ -317,36 +346,40 @@ class Stage2Renderer(nn.Module):
         colors = []
         out = {'gradient_error': torch.zeros(1, device=dev), 'std': torch.zeros(1, device=dev)}
         s1c = self.stage1_network.color_network
+        # The inner segment (inner engine: SDF, NeuS alpha, inner shading) and the outer samples of all segments (stage-1 engine:
+        # NeRF++) do not depend on each other.  Small batches leave the chip half empty, so below `_TWO_STREAM_RAYS` camera rays the
+        # inner segment is enqueued on the inner engine's side stream first and the NeRF++ pass on the current stream beside it; the
+        # autograd engine runs each node's backward on its forward stream, so the backward passes overlap the same way.  The two
+        # engines have separate reduction arenas and descriptor tables; tensors that cross the fork / join are recorded on the
+        # stream that reads them.
+        inner_res, side = None, None
+        # inv_s of the inner surface (read on the caller's stream: the parameter's gradient accumulates there)
+        inv_s = torch.exp(self.deviation_network_inner.variance * 10.0).clip(1e-6, 1e6)
+        if self.cfg['freeze_inv_s_step'] is not None and step is not None and step < self.cfg['freeze_inv_s_step']:
+            inv_s = inv_s.detach()
+        if len(segs) > 1 and segs[1]['start'].shape[0] > 0 and N0 <= self._TWO_STREAM_RAYS and dev.type == 'cuda':
+            main = torch.cuda.current_stream(dev)
+            side = n2.eng._fork()
+            for t in [segs[1][k] for k in ('start', 'v', 'z', 'dirs')] + [inv_s]:
+                t.record_stream(side)
+            with torch.cuda.stream(side):
+                inner_res = self._inner_segment(n2, segs[1], cos_anneal_ratio, step, inv_s)
+                for t in (inner_res or {}).values():
+                    if torch.is_tensor(t):
+                        t.record_stream(main)
         outer = O.outer_segments(n1, [(sg['start'], sg['v'], sg['z'], sg['dirs']) for sg in segs])
         for b, sg in enumerate(segs):
             N, cont = sg['start'].shape[0], sg['cont_idx']
             alpha, col = outer[b]
             if b == 1 and N > 0:                               # inside the object: the inner SDF surface (NeuS alpha + shading)
-                nodes = self.path_points(sg)[:, :-1, :]
-                inner = torch.norm(nodes, dim=-1) <= 1.0
-                where = inner.nonzero()
-                if where.shape[0] > 0:
-                    r_i, s_i = where[:, 0], where[:, 1]
-                    seglen = torch.linalg.norm(nodes[:, 1:] - nodes[:, :-1], dim=-1)
-                    seglen = torch.cat([seglen, seglen[..., -1:]], -1)
-                    # (directions through an expanded view, not index_select(0, r_i): its backward would add the many samples of
-                    # a ray with float atomics; this way the per-sample cotangents land at unique (ray, sample) slots and the sum
-                    # over a ray's samples is an ordinary reduction -- bitwise reproducible)
-                    d_in = sg['dirs'][:, None, :].expand(N, nodes.shape[1], 3)[r_i, s_i]
-                    x_in, len_in = nodes[r_i, s_i], seglen[r_i, s_i]
-                    y, grads = n2.sdf(x_in)
-                    s = torch.exp(self.deviation_network_inner.variance * 10.0).clip(1e-6, 1e6)
-                    if self.cfg['freeze_inv_s_step'] is not None and step < self.cfg['freeze_inv_s_step']:
-                        s = s.detach()
-                    a = O.neus_alpha(n2.eng, y[:, 0], grads, d_in, len_in, s, cos_anneal_ratio)
-                    aux = {}
-                    c, _ = self._shading(n2, self.color_network_inner.cfg, self.color_network_inner.FG_LUT, x_in, grads, -d_in, y[:, 1:],
-                                         aux=aux)
-                    out.update(self._inner_occ_loss(n2, x_in, y[:, 0], grads, d_in, aux, step))
-                    alpha = alpha.index_put((r_i, s_i), a)
-                    col = col.index_put((r_i, s_i), torch.cat([c, torch.zeros_like(c[:, :1])], -1))
-                    out['std'] = torch.mean(1 / s)
-                    out['gradient_error'] = (torch.linalg.norm(grads, dim=-1) - 1.0) ** 2
+                if side is not None:
+                    n2.eng._join()
+                else:
+                    inner_res = self._inner_segment(n2, sg, cos_anneal_ratio, step, inv_s)
+                if inner_res is not None:
+                    alpha = alpha.index_put((inner_res['r_i'], inner_res['s_i']), inner_res['alpha'])
+                    col = col.index_put((inner_res['r_i'], inner_res['s_i']), inner_res['color4'])
+                    out.update({k: inner_res[k] for k in ('std', 'gradient_error', 'loss_occ') if k in inner_res})
             light, T = O.segment_composite(n1.eng, alpha, col, T)
             if sg['n_cont'] == 0:
                 colors.append(light)
