@@ -134,6 +134,11 @@ def main_stage2(args):
            'eikonal_weight': 0.02, 'freeze_inv_s_step': 5000,
            'stage1_cfg': {'is_nerf': True, 'apply_occ_loss': True, 'occ_loss_step': 15000, 'freeze_inv_s_step': 15000},
            'stage1_mesh_arrays': icosphere(5, 0.5)}
+    if args.mlp_dtype != 'fp32':
+        if args.mlp_dtype != 'bf16x6':
+            raise SystemExit("--workload stage2 runs the fp32 and bf16x6 MLP modes (bf16 storage is a stage-1 mode)")
+        cfg['mlp_dtype'] = args.mlp_dtype
+        cfg['stage1_cfg'] = dict(cfg['stage1_cfg'], mlp_dtype=args.mlp_dtype)
     if args.thick:
         # the non-zero-thickness model (network/renderer.py:907-2398; every configs/stage2/real/*.yaml): shell refraction with
         # curvature radius + thickness network, segment samples 64/128/64, SpecInner inner shading
@@ -195,7 +200,7 @@ def main_stage2(args):
         "metric": "train rays/sec", "value": R / dt, "unit": "rays/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt, "median_ms_per_step": float(np.median(step_ms)), "p10_ms_per_step": float(np.percentile(step_ms, 10)),
         "p90_ms_per_step": float(np.percentile(step_ms, 90)), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32" if args.mlp_dtype == 'fp32' else "bf16x6 (exact 3-way split, fp32-equivalent)", "data": "synthetic",
         "config": {"workload": ("stage-2 train step, NON-zero-thickness model, %d rays, icosphere 20480 faces (HIP LBVH), 3 shell crossings, "
                                 "segment samples 64/128/64, fp32" % R) if args.thick else
                                ("stage-2 train step, %d rays, icosphere 20480 faces (HIP LBVH), 3 bounces, segment samples "
@@ -203,7 +208,7 @@ def main_stage2(args):
                    "rays": "object-aimed" if args.object_rays else "Spherepot-shaped cameras",
                    "frac_rays_entering_object": float(np.mean(entered)), "final_loss": float(last.detach()),
                    "max_mem_GB": torch.cuda.max_memory_allocated() / 2 ** 30}}
-    if not args.no_kernel_timing:
+    if not args.no_kernel_timing and args.mlp_dtype == 'fp32':
         fl = sum(k['flops'] for k in kts); sec = sum(k['seconds'] for k in kts); ln = sum(k['launches'] for k in kts)
         tf = fl / max(sec, 1e-12) / 1e12
         res["roofline"] = {"bound": "mfma", "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_FP32_MFMA_TFLOPS,
