@@ -11,10 +11,9 @@ per-bounce bookkeeping of stage 2 can stay in torch while every GEMM runs in the
   StackFn     X[rows, K]            -> raw[rows, n_out]   one make_predictor stack          (field.py:371-408)
   MaterialsFn feat[P,256], x[P,3]   -> raw[P,6] (metallic, roughness, albedo(3), transmission; pre-sigmoid)
 """
-import numpy as np
 import torch
 
-from .engine import addr, rup
+from .engine import addr
 
 
 def _numel(shape):
