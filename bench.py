@@ -8,6 +8,10 @@ parameter gradients.
 
 A step = ray fetch (device-resident pool) -> sampler -> render_core forward -> loss -> backward -> [all-reduce]
 -> Adam.  Rank 0 prints ONE JSON line.  Extra objects:
+  extra_workloads : (default N = 1 run only) short legs of the other BASELINE.json configs, timed AFTER the headline's timed
+                 region in the same process, each {workload, dtype, ms_per_step, rays_per_s, roofline{...}}: config 3 (stage 2,
+                 4096 rays, and the non-zero-thickness model at its real batch of 1024), config 4 (real-capture path, 8192
+                 rays, bf16 storage) and the reference's default stage-1 batch of 512 rays.  The headline fields never change.
   roofline     : the fp32-MFMA GEMM kernels (gemm_nt_kernel*, the dominant kernel): algorithmic FLOPs of every
                  launch / summed launch durations (HIP events on the launch stream, on one step in the middle of
                  the timed region by default: the ~330 event pairs cost that step a few ms) vs the 157.3 TFLOP/s fp32-MFMA peak
@@ -114,10 +118,22 @@ def spawn_ranks_or_die(args):
     raise SystemExit(subprocess.call(cmd))
 
 
-def main_stage2(args):
+class SumRuleError(RuntimeError):
+    """The per-launch GEMM times of a bracketed step add up to more than that step's wall time: the launches overlapped
+    (two streams) or the event pairing broke -- the roofline of such a step is not evidence."""
+
+
+def check_sum_rule(what, gemm_s, step_ms):
+    if gemm_s * 1e3 > step_ms * 1.001:
+        raise SumRuleError(f"{what}: NT + TN launch time {gemm_s * 1e3:.2f} ms exceeds the bracketed step's wall time {step_ms:.2f} ms")
+    return {"gemm_ms_in_bracketed_step": gemm_s * 1e3, "bracketed_step_ms": step_ms, "ok": True}
+
+
+def stage2_leg(args):
     """BASELINE.json configs[2]: stage-2 training step (refraction through the stage-1 mesh, learned IoR, 3 bounces) on ONE
     GPU: 4096 rays, icosphere(r=0.5) with 20480 faces standing in for the stage-1 mesh, segment samples 256/128/256.  A parity
-    case of the build, not its headline: printed in the same JSON format on request (--workload stage2)."""
+    case of the build, not its headline: printed in the same JSON format on request (--workload stage2) and attached to the
+    default run's line as an extra workload."""
     from nu_nerf_amd.stage2 import Stage2Renderer
     from nu_nerf_amd.params import init_stage1_params, init_stage2_params
     from nu_nerf_amd.lbvh import icosphere
@@ -157,7 +173,8 @@ def main_stage2(args):
     # lr 1e-5: the full optimizer step runs, but the light paths (which rays refract, how many samples fall inside the object) stay
     # what the initial weights give for the whole run -- with untrained networks and lr 1e-3 the IoR network drifts within a few
     # steps towards invalidating rays (masked out of the loss), and the work per step with it (scripts/stage2_thick_trajectory.py)
-    opt = FusedAdam([p for p in net.parameters() if p.requires_grad], lr=1e-5)
+    S2_LR = 1e-5
+    opt = FusedAdam([p for p in net.parameters() if p.requires_grad], lr=S2_LR)
     R, n = args.rays, args.steps + args.warmup
     pool = (make_object_rays if args.object_rays else make_rays)(R * n, seed=6033)
     pool = {k: torch.from_numpy(v).to(dev) for k, v in pool.items() if k in ('rays_o', 'rays_d', 'rgbs')}
@@ -185,12 +202,21 @@ def main_stage2(args):
     t0 = time.perf_counter()
     step_ev[0].record()
     for i in range(args.warmup, n):
-        if i == mid and not args.no_kernel_timing:      # one bracketed step: per-launch HIP events on the GEMMs of both engines
+        if i == mid and not args.no_kernel_timing:
+            # one bracketed step: per-launch HIP events on the GEMMs of both engines.  That step runs on ONE stream (the
+            # two-stream modes of the renderer and of the engines are switched off for it): events of launches that overlap on
+            # two streams would each include the other stream's work and their sum would exceed the step (check_sum_rule)
+            saved = (net._TWO_STREAM_RAYS, [e._TWO_STREAM_SAMPLES for e in engines])
+            net._TWO_STREAM_RAYS = 0
             for e in engines:
-                e.begin_kernel_timing(reserve=1200)
+                e._TWO_STREAM_SAMPLES = 0
+                e.begin_kernel_timing(reserve=2400)
         last = step(i)
         if i == mid and not args.no_kernel_timing:
             kts = [e.end_kernel_timing() for e in engines]
+            net._TWO_STREAM_RAYS = saved[0]
+            for e, v in zip(engines, saved[1]):
+                e._TWO_STREAM_SAMPLES = v
         step_ev[i - args.warmup + 1].record()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
@@ -205,17 +231,22 @@ def main_stage2(args):
                                 "segment samples 64/128/64, fp32" % R) if args.thick else
                                ("stage-2 train step, %d rays, icosphere 20480 faces (HIP LBVH), 3 bounces, segment samples "
                                 "256/128/256, fp32 (BASELINE.json configs[2])" % R),
-                   "rays": "object-aimed" if args.object_rays else "Spherepot-shaped cameras",
+                   "rays": "object-aimed" if args.object_rays else "Spherepot-shaped cameras", "adam_lr": S2_LR,
+                   "adam_lr_note": "fixed small lr: the light paths (and with them the work per step) stay those of the initial "
+                                   "weights for the whole run -- a fixed-path measurement, not a training trajectory",
                    "frac_rays_entering_object": float(np.mean(entered)), "final_loss": float(last.detach()),
                    "max_mem_GB": torch.cuda.max_memory_allocated() / 2 ** 30}}
     if not args.no_kernel_timing and args.mlp_dtype == 'fp32':
         fl = sum(k['flops'] for k in kts); sec = sum(k['seconds'] for k in kts); ln = sum(k['launches'] for k in kts)
         tf = fl / max(sec, 1e-12) / 1e12
+        tn_sec = sum(k['tn_seconds'] for k in kts)
         res["roofline"] = {"bound": "mfma", "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_FP32_MFMA_TFLOPS,
-                           "traffic": None, "kernel": "gemm_nt2_kernel<*> (all NT launches of the bracketed step, both engines)",
+                           "traffic": None, "kernel": "gemm_nt2_kernel<*> (all NT launches of the bracketed step, both engines, one stream)",
                            "launches": ln, "avg_launch_us": 1e6 * sec / max(ln, 1),
                            "algorithmic_flops_per_launch": fl / max(ln, 1),
-                           "wgrad": {"achieved": sum(k['tn_flops'] for k in kts) / max(sum(k['tn_seconds'] for k in kts), 1e-12) / 1e12,
+                           "event_pool_exhausted": any(k['event_capacity_reached'] or k['python_event_pool_exhausted'] for k in kts),
+                           "sum_rule": check_sum_rule("stage 2", sec + tn_sec, float(step_ms[mid - args.warmup])),
+                           "wgrad": {"achieved": sum(k['tn_flops'] for k in kts) / max(tn_sec, 1e-12) / 1e12,
                                      "launches": sum(k['tn_launches'] for k in kts)}}
     # mesh tracing of this step's shape: the first-bounce rays of one batch against the scene's LBVH (latency-bound kernel;
     # algorithmic bytes = 24 B in + 8 B out per ray)
@@ -233,64 +264,53 @@ def main_stage2(args):
                          "algorithmic_GBps": R * 32 / us / 1e3, "hit_fraction": float(hit.mean()),
                          "note": "at 4096 rays the launch is latency-bound (one wave per 64 rays on 256 CUs); scripts/bench_lbvh.py "
                                  "reports 1.8-4.2 G rays/s at 2^20 rays"}
-    print(json.dumps(res), flush=True)
+    return res
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--workload', default='stage1', choices=['stage1', 'stage2'],
-                    help="'stage1' = the headline (BASELINE configs[1]); 'stage2' = configs[2] on one GPU (a parity case, see DESIGN 9)")
-    ap.add_argument('--thick', action='store_true', help="with --workload stage2: the non-zero-thickness model (nu_nerf_amd/stage2_thick.py)")
-    ap.add_argument('--object-rays', action='store_true',
-                    help='aim every ray at the object: stage 1 -> inner-point share ~0.5 (the shading stack dominates); stage 2 -> all three bounces')
-    ap.add_argument('--steps', type=int, default=50)
-    ap.add_argument('--warmup', type=int, default=10)
-    ap.add_argument('--rays', type=int, default=4096, help='rays per GPU per step')
-    ap.add_argument('--start-step', type=int, default=20000, help='training-step index of the first iteration')
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--mlp-dtype', default='fp32', choices=['fp32', 'bf16', 'bf16x6'],
-                    help="'bf16' = BASELINE config 4's MLP arithmetic (not the headline: the reference computes in fp32)")
-    ap.add_argument('--real-capture', action='store_true',
-                    help='real-capture code path (is_nerf False, sphere_direction True): BASELINE config 4 with --rays 8192 --mlp-dtype bf16')
-    ap.add_argument('--no-kernel-timing', action='store_true')
-    ap.add_argument('--unfused-loss', action='store_true', help='assemble the loss with the eager torch registry (development A/B)')
-    ap.add_argument('--time-every', type=int, default=0,
-                    help='bracket the GEMM launches with HIP events on every Nth step of the timed region; 0 (default): on ONE '
-                         'step in the middle of it (the ~330 event pairs cost that step 2-4 ms)')
-    args = ap.parse_args()
-    if args.workload == 'stage2':
-        if int(os.environ.get('WORLD_SIZE', 1)) != 1 or args.gpus != 1:
-            raise SystemExit("--workload stage2 runs on one GPU")
-        return main_stage2(args)
+def find_traffic_profile(R, world, real_capture, mlp_dtype, object_rays, h16, p_in, p_out):
+    """HBM traffic per launch of the dominant kernel from a committed rocprofv3 PMC pass (FETCH_SIZE / WRITE_SIZE in separate
+    --pmc runs, gfx950 corrections applied by scripts/summarize_pmc.py) -- but only when that pass was collected on THIS
+    workload: same configuration and mean inner / outer point counts within 5 % of this run's; otherwise (None, None, None):
+    a constant from another run is not a measurement of this one."""
+    if world != 1 or object_rays:
+        return None, None, None
+    prof = os.path.join(ROOT, 'profiles')
+    cands = []
+    for rnd in sorted(os.listdir(prof), reverse=True) if os.path.isdir(prof) else []:
+        for name in ('traffic_pmc.json', 'traffic_pmc_config4.json'):
+            f = os.path.join(prof, rnd, name)
+            if os.path.exists(f):
+                cands.append(f)
+    for f in cands:
+        try:
+            d = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        w = d.get('workload')
+        if not w:                                   # files without the workload record (round 2) cannot be matched
+            continue
+        if (w.get('rays') != R or bool(w.get('real_capture')) != bool(real_capture) or w.get('mlp_dtype') != mlp_dtype
+                or bool(w.get('bf16_storage', False)) != bool(h16)):
+            continue
+        pi, po = w.get('mean_inner_points', 0), w.get('mean_outer_points', 0)
+        if pi <= 0 or po <= 0 or abs(pi - p_in) > 0.05 * pi or abs(po - p_out) > 0.05 * po:
+            continue
+        return (d.get('gemm_nt_kernel', {}).get('hbm_bytes_per_launch'), d.get('gemm_tn_kernel', {}).get('hbm_bytes_per_launch'),
+                os.path.relpath(f, ROOT))
+    return None, None, None
 
-    spawn_ranks_or_die(args)        # --gpus N without a launcher: start the N ranks ourselves (never returns in the parent)
-    rank = int(os.environ.get('RANK', 0))
-    local_rank = int(os.environ.get('LOCAL_RANK', 0))
-    world = int(os.environ.get('WORLD_SIZE', 1))
+
+def stage1_leg(args, dist_ctx):
+    """One timed run of the stage-1 training step with the configuration in `args` (rays, code path, MLP arithmetic).
+    dist_ctx = (rank, world, dev, rccl_ranks, coll_backend).  Returns the result dict on rank 0, None elsewhere."""
     import torch.distributed as dist
-    # NU_BENCH_DEVICE / NU_BENCH_BACKEND exist only to rehearse the multi-process path on a one-GPU box (gloo, all ranks on
-    # cuda:0); the driver's runs use one GPU per rank and RCCL ("nccl").
-    dev_index = int(os.environ.get('NU_BENCH_DEVICE', local_rank))
-    torch.cuda.set_device(dev_index)
-    dev = torch.device('cuda', dev_index)
-    if world > 1:
-        backend = os.environ.get('NU_BENCH_BACKEND', 'nccl')
-        if backend == 'nccl':
-            dist.init_process_group('nccl', device_id=dev)
-        else:
-            dist.init_process_group(backend)
-    rccl_ranks = dist.get_world_size() if world > 1 else 1
-    if rccl_ranks != args.gpus:
-        raise SystemExit(f"bench.py: process group has {rccl_ranks} rank(s), --gpus {args.gpus}")
-    coll_backend = dist.get_backend() if world > 1 else None
-
     from nu_nerf_amd.renderer import NeROShapeRenderer
     from nu_nerf_amd.params import init_stage1_params
     from nu_nerf_amd.synthetic import make_rays, make_object_rays
     from nu_nerf_amd.loss import name2loss, SPHEREPOT_LOSSES, total_loss, fused_stage1_loss
     from nu_nerf_amd.parallel import GradAllReducer
     from nu_nerf_amd.train_glue import FusedAdam
+    rank, world, dev, rccl_ranks, coll_backend = dist_ctx
 
     R = args.rays
     cfg = build_cfg(R, args.real_capture, args.mlp_dtype)
@@ -323,8 +343,10 @@ def main():
         for g in opt.param_groups:
             g['lr'] = lr
         opt.zero_grad(set_to_none=True)
-        if reducer is None and not args.unfused_loss:
-            total, _, _ = fused_stage1_loss(net, batch_for(it), step, losses)        # loss assembly on the HIP loss kernels
+        if not args.unfused_loss:
+            # loss assembly on the HIP loss kernels; with a reducer the eikonal mean takes this rank's point weight (count ratio
+            # n_local * world / sum n, a device scalar) INSIDE those kernels: the N > 1 step is the N = 1 step + one all-reduce
+            total, _, _ = fused_stage1_loss(net, batch_for(it), step, losses, reducer=reducer)
         else:
             out = net.train_step_rays(batch_for(it), step)
             if reducer is not None:     # eikonal mean over the union of all ranks' inner points (exact data parallelism)
@@ -345,6 +367,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     stats['P_in'] = stats['P_out'] = 0
+    bracketed = []
     if not args.no_kernel_timing:
         bracketed = [args.steps // 2] if args.time_every <= 0 else [i for i in range(args.steps) if i % args.time_every == 0]
         eng.begin_kernel_timing(reserve=2 * 200 * len(bracketed))
@@ -356,12 +379,17 @@ def main():
     step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     step_ev[0].record()
     seg_count = [torch.cuda.memory_stats(dev).get('segment.all.allocated', 0)]
+    two_stream_default = eng._TWO_STREAM_SAMPLES
     for it in range(args.warmup, args.warmup + args.steps):
         eng.ktime_on = (not args.no_kernel_timing) and (it - args.warmup) in bracketed
+        # a bracketed step runs on ONE stream: per-launch events of launches that overlap on two streams (the small-batch mode,
+        # engine._TWO_STREAM_SAMPLES) would each include the other stream's work (check_sum_rule)
+        eng._TWO_STREAM_SAMPLES = 0 if eng.ktime_on else two_stream_default
         timed_steps += int(eng.ktime_on)
         last = one_step(it)
         step_ev[it - args.warmup + 1].record()
         seg_count.append(torch.cuda.memory_stats(dev).get('segment.all.allocated', 0))
+    eng._TWO_STREAM_SAMPLES = two_stream_default
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -373,85 +401,193 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ktime = eng.end_kernel_timing() if not args.no_kernel_timing else None
+    if rank != 0:
+        return None
 
-    if rank == 0:
-        ms = 1e3 * elapsed / args.steps
-        value = R * world * args.steps / elapsed
-        step_ms = np.array([step_ev[i].elapsed_time(step_ev[i + 1]) for i in range(args.steps)])   # rank 0's stream
-        if args.real_capture or args.mlp_dtype != 'fp32':
-            workload = ("stage-1 train step, %s code path, %d rays/GPU x (64 + 64 + 32) samples, %s MLP GEMMs (fp32 accumulate), "
-                        "synthetic cameras (BASELINE.json configs[3] when --real-capture --rays 8192 --mlp-dtype bf16)"
-                        % ("real-capture (is_nerf False, sphere_direction True)" if args.real_capture else "Spherepot", R,
-                           args.mlp_dtype))
+    ms = 1e3 * elapsed / args.steps
+    value = R * world * args.steps / elapsed
+    step_ms = np.array([step_ev[i].elapsed_time(step_ev[i + 1]) for i in range(args.steps)])   # rank 0's stream
+    if args.real_capture or args.mlp_dtype != 'fp32':
+        workload = ("stage-1 train step, %s code path, %d rays/GPU x (64 + 64 + 32) samples, %s MLP GEMMs (fp32 accumulate), "
+                    "synthetic cameras (BASELINE.json configs[3] when --real-capture --rays 8192 --mlp-dtype bf16)"
+                    % ("real-capture (is_nerf False, sphere_direction True)" if args.real_capture else "Spherepot", R,
+                       args.mlp_dtype))
+    else:
+        workload = ("Spherepot-shaped stage-1 train step, %d rays/GPU x (64 coarse + 64 importance + 32 bg) "
+                    "samples, fp32, synthetic cameras (BASELINE.json configs[1])" % R)
+    p_in, p_out = stats['P_in'] / args.steps, stats['P_out'] / args.steps
+    res = {
+        "metric": "train rays/sec", "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": ms, "median_ms_per_step": float(np.median(step_ms)),
+        "p10_ms_per_step": float(np.percentile(step_ms, 10)), "p90_ms_per_step": float(np.percentile(step_ms, 90)),
+        "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": {"fp32": "f32", "bf16": "bf16", "bf16x6": "bf16x6 (exact 3-way split, fp32-equivalent)"}[args.mlp_dtype],
+        "data": "synthetic",
+        "config": {"workload": workload,
+                   "rays_per_gpu": R, "global_rays": R * world, "samples_per_ray": 160, "start_step": args.start_step,
+                   "parallelism": "dp%d" % world, "rccl_ranks": rccl_ranks, "collective_backend": coll_backend,
+                   "rays": "object-aimed (make_object_rays)" if args.object_rays else "Spherepot-shaped camera frusta",
+                   "loss_assembly": "eager torch registry (--unfused-loss)" if args.unfused_loss else
+                   "HIP loss kernels (fused_stage1_loss%s)" % ("; eikonal point weight as a device scalar" if reducer is not None else ""),
+                   "grad_all_reduce": None if reducer is None else
+                   ("in place on the flat gradient buffer" if reducer.gathered_calls == 0 else
+                    "gathered (%d of %d steps)" % (reducer.gathered_calls, reducer.gathered_calls + reducer.in_place_calls)),
+                   "mean_inner_points": p_in, "mean_outer_points": p_out,
+                   "final_loss": float(last.detach()),
+                   "step_ms": [round(float(v), 2) for v in step_ms],
+                   "new_device_segments_per_step": [seg_count[i + 1] - seg_count[i] for i in range(args.steps)]},
+    }
+    if ktime is not None:
+        tf = ktime['flops'] / max(ktime['seconds'], 1e-12) / 1e12
+        traffic, traffic_tn, traffic_src = find_traffic_profile(R, world, args.real_capture, args.mlp_dtype, args.object_rays,
+                                                                eng.h16, p_in, p_out)
+        br_ms = float(np.sum(step_ms[bracketed]))
+        common = {"algorithmic_bytes_per_launch": ktime['bytes'] / max(ktime['launches'], 1),
+                  "algorithmic_flops_per_launch": ktime['flops'] / max(ktime['launches'], 1),
+                  "launches": ktime['launches'], "avg_launch_us": 1e6 * ktime['seconds'] / max(ktime['launches'], 1),
+                  "event_timed_steps": timed_steps,
+                  "event_pool_exhausted": bool(ktime['event_capacity_reached'] or ktime['python_event_pool_exhausted']),
+                  "gemm_time_share": ktime['seconds'] / (elapsed * timed_steps / args.steps),
+                  "traffic_source": traffic_src if traffic is not None else
+                  "null: no committed PMC pass matches this run's configuration and mean point counts within 5 %",
+                  "wgrad": {"achieved": ktime['tn_flops'] / max(ktime['tn_seconds'], 1e-12) / 1e12,
+                            "launches": ktime['tn_launches'],
+                            "algorithmic_bytes_per_launch": ktime['tn_bytes'] / max(ktime['tn_launches'], 1),
+                            "avg_launch_us": 1e6 * ktime['tn_seconds'] / max(ktime['tn_launches'], 1),
+                            "traffic": traffic_tn,
+                            "time_share": ktime['tn_seconds'] / (elapsed * timed_steps / args.steps)}}
+        try:
+            common["sum_rule"] = check_sum_rule("stage 1", ktime['seconds'] + ktime['tn_seconds'], br_ms)
+        except SumRuleError as e:
+            res["roofline"] = None
+            res["roofline_error"] = str(e)
+            return res
+        if args.mlp_dtype == 'bf16x6':
+            # six bf16 MFMAs per 16-deep k-step: price the achieved rate against the bf16 pipe doing 6x the arithmetic
+            res["roofline"] = {"bound": "mfma", "achieved": 6 * tf, "peak": 2516.6, "unit": "TFLOP/s (bf16 MFMA issued)",
+                               "frac": 6 * tf / 2516.6, "traffic": None, "fp32_equivalent_tflops": tf,
+                               "kernel": "gemm_nt_kernel<*, split> (6 x v_mfma_f32_32x32x16_bf16 per k-step)", **common}
+        elif args.mlp_dtype != 'fp32':
+            # bf16 build: 16x the fp32 MFMA rate, so the GEMMs are bound by streaming their operands; the algorithmic bytes
+            # count each matrix at the width it is stored in (bf16 weight tables and hidden activations, fp32 elsewhere)
+            gbs = ktime['bytes'] / max(ktime['seconds'], 1e-12) / 1e9
+            stored = eng.h16
+            res["roofline"] = {"bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0,
+                               "traffic": traffic, "mfma_tflops": tf,
+                               "traffic_unit": "HBM bytes per launch (rocprofv3 PMC passes, gfx950 corrections applied)",
+                               "kernel": ("gemm_nt16_kernel<*> (v_mfma_f32_32x32x16_bf16, bf16 weights and hidden activations in HBM)"
+                                          if stored else "gemm_nt_kernel<*, bf16> (v_mfma_f32_32x32x16_bf16, fp32 operands in HBM)"),
+                               **common}
         else:
-            workload = ("Spherepot-shaped stage-1 train step, %d rays/GPU x (64 coarse + 64 importance + 32 bg) "
-                        "samples, fp32, synthetic cameras (BASELINE.json configs[1])" % R)
-        res = {
-            "metric": "train rays/sec", "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": ms, "median_ms_per_step": float(np.median(step_ms)),
-            "p10_ms_per_step": float(np.percentile(step_ms, 10)), "p90_ms_per_step": float(np.percentile(step_ms, 90)),
-            "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": {"fp32": "f32", "bf16": "bf16", "bf16x6": "bf16x6 (exact 3-way split, fp32-equivalent)"}[args.mlp_dtype],
-            "data": "synthetic",
-            "config": {"workload": workload,
-                       "rays_per_gpu": R, "global_rays": R * world, "samples_per_ray": 160, "start_step": args.start_step,
-                       "parallelism": "dp%d" % world, "rccl_ranks": rccl_ranks, "collective_backend": coll_backend,
-                       "rays": "object-aimed (make_object_rays)" if args.object_rays else "Spherepot-shaped camera frusta",
-                       "grad_all_reduce": None if reducer is None else
-                       ("in place on the flat gradient buffer" if reducer.gathered_calls == 0 else
-                        "gathered (%d of %d steps)" % (reducer.gathered_calls, reducer.gathered_calls + reducer.in_place_calls)),
-                       "mean_inner_points": stats['P_in'] / args.steps, "mean_outer_points": stats['P_out'] / args.steps,
-                       "final_loss": float(last.detach()),
-                       "step_ms": [round(float(v), 2) for v in step_ms],
-                       "new_device_segments_per_step": [seg_count[i + 1] - seg_count[i] for i in range(args.steps)]},
-        }
-        if ktime is not None:
-            tf = ktime['flops'] / max(ktime['seconds'], 1e-12) / 1e12
-            # HBM traffic per launch comes from the committed rocprofv3 PMC passes of this same workload (FETCH_SIZE / WRITE_SIZE
-            # in separate --pmc runs, gfx950 corrections applied by scripts/summarize_pmc.py); null if absent or other workload
-            traffic = traffic_tn = None
-            tj = os.path.join(ROOT, 'profiles', 'r02', 'traffic_pmc.json')
-            if os.path.exists(tj) and R == 4096 and world == 1 and not args.real_capture and args.mlp_dtype == 'fp32' and not args.object_rays:
-                tjd = json.load(open(tj))
-                traffic = tjd.get('gemm_nt_kernel', {}).get('hbm_bytes_per_launch')
-                traffic_tn = tjd.get('gemm_tn_kernel', {}).get('hbm_bytes_per_launch')
-            tj4 = os.path.join(ROOT, 'profiles', 'r02', 'traffic_pmc_config4.json')
-            if os.path.exists(tj4) and R == 8192 and world == 1 and args.real_capture and args.mlp_dtype == 'bf16' and eng.h16:
-                tjd = json.load(open(tj4))
-                traffic = tjd.get('gemm_nt_kernel', {}).get('hbm_bytes_per_launch')
-                traffic_tn = tjd.get('gemm_tn_kernel', {}).get('hbm_bytes_per_launch')
-            common = {"algorithmic_bytes_per_launch": ktime['bytes'] / max(ktime['launches'], 1),
-                      "algorithmic_flops_per_launch": ktime['flops'] / max(ktime['launches'], 1),
-                      "launches": ktime['launches'], "avg_launch_us": 1e6 * ktime['seconds'] / max(ktime['launches'], 1),
-                      "event_timed_steps": timed_steps,
-                      "gemm_time_share": ktime['seconds'] / (elapsed * timed_steps / args.steps),
-                      "wgrad": {"achieved": ktime['tn_flops'] / max(ktime['tn_seconds'], 1e-12) / 1e12,
-                                "launches": ktime['tn_launches'],
-                                "algorithmic_bytes_per_launch": ktime['tn_bytes'] / max(ktime['tn_launches'], 1),
-                                "avg_launch_us": 1e6 * ktime['tn_seconds'] / max(ktime['tn_launches'], 1),
-                                "traffic": traffic_tn,
-                                "time_share": ktime['tn_seconds'] / (elapsed * timed_steps / args.steps)}}
-            if args.mlp_dtype == 'bf16x6':
-                # six bf16 MFMAs per 16-deep k-step: price the achieved rate against the bf16 pipe doing 6x the arithmetic
-                res["roofline"] = {"bound": "mfma", "achieved": 6 * tf, "peak": 2516.6, "unit": "TFLOP/s (bf16 MFMA issued)",
-                                   "frac": 6 * tf / 2516.6, "traffic": None, "fp32_equivalent_tflops": tf,
-                                   "kernel": "gemm_nt_kernel<*, split> (6 x v_mfma_f32_32x32x16_bf16 per k-step)", **common}
-            elif args.mlp_dtype != 'fp32':
-                # bf16 build: 16x the fp32 MFMA rate, so the GEMMs are bound by streaming their operands; the algorithmic bytes
-                # count each matrix at the width it is stored in (bf16 weight tables and hidden activations, fp32 elsewhere)
-                gbs = ktime['bytes'] / max(ktime['seconds'], 1e-12) / 1e9
-                stored = eng.h16
-                res["roofline"] = {"bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0,
-                                   "traffic": traffic, "mfma_tflops": tf,
-                                   "traffic_unit": "HBM bytes per launch (rocprofv3 PMC of this workload and these kernels, profiles/r02/traffic_pmc_config4.json)",
-                                   "kernel": ("gemm_nt16_kernel<*> (v_mfma_f32_32x32x16_bf16, bf16 weights and hidden activations in HBM)"
-                                              if stored else "gemm_nt_kernel<*, bf16> (v_mfma_f32_32x32x16_bf16, fp32 operands in HBM)"),
-                                   **common}
-            else:
-                res["roofline"] = {"bound": "mfma", "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                   "frac": tf / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
-                                   "traffic_unit": "HBM bytes per launch (rocprofv3 PMC of this workload and these kernels, profiles/r02/traffic_pmc.json; re-collect when a GEMM kernel changes)",
-                                   "kernel": "gemm_nt2_kernel<*> (fp32 v_mfma_f32_32x32x2_f32, software-pipelined, 2 LDS stages)", **common}
+            res["roofline"] = {"bound": "mfma", "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                               "frac": tf / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
+                               "traffic_unit": "HBM bytes per launch (rocprofv3 PMC passes, gfx950 corrections applied)",
+                               "kernel": "gemm_nt2_kernel<*> (fp32 v_mfma_f32_32x32x2_f32, software-pipelined, 2 LDS stages)", **common}
+    res["_pool"] = pool
+    return res
+
+
+EXTRA_LEGS = (
+    # (tag, workload function, overrides of the command-line namespace)
+    ("config3_stage2", 'stage2', dict(rays=4096, steps=10, warmup=4, thick=False)),
+    ("stage2_thick_1024", 'stage2', dict(rays=1024, steps=20, warmup=5, thick=True)),
+    ("config4_bf16", 'stage1', dict(rays=8192, steps=10, warmup=4, real_capture=True, mlp_dtype='bf16')),
+    ("stage1_512rays", 'stage1', dict(rays=512, steps=30, warmup=6)),
+)
+
+
+def run_extra_legs(args, dist_ctx):
+    """Short legs of the non-headline configs, each >= 10 steps after >= 4 warm-ups, run after the headline's timed region."""
+    out = []
+    for tag, kind, over in EXTRA_LEGS:
+        a = argparse.Namespace(**vars(args))
+        a.object_rays, a.real_capture, a.mlp_dtype, a.thick, a.unfused_loss, a.time_every, a.no_kernel_timing = False, False, 'fp32', False, False, 0, False
+        a.start_step = 20000
+        for k, v in over.items():
+            setattr(a, k, v)
+        t0 = time.perf_counter()
+        try:
+            r = stage2_leg(a) if kind == 'stage2' else stage1_leg(a, dist_ctx)
+            r.pop('_pool', None)
+            leg = {"tag": tag, "workload": r['config']['workload'], "dtype": r['dtype'], "steps": a.steps, "warmup": a.warmup,
+                   "ms_per_step": r['ms_per_step'], "median_ms_per_step": r['median_ms_per_step'], "rays_per_s": r['value'],
+                   "roofline": r.get('roofline'), "leg_wall_s": None}
+            for k in ('frac_rays_entering_object', 'adam_lr', 'mean_inner_points', 'mean_outer_points', 'final_loss'):
+                if k in r['config']:
+                    leg[k] = r['config'][k]
+            if 'roofline_error' in r:
+                leg['roofline_error'] = r['roofline_error']
+            if 'lbvh_trace' in r:
+                leg['lbvh_trace'] = r['lbvh_trace']
+        except Exception as e:          # a failing leg must not cost the headline its line: it is reported as failed
+            leg = {"tag": tag, "error": "%s: %s" % (type(e).__name__, e)}
+        leg["leg_wall_s"] = time.perf_counter() - t0
+        out.append(leg)
+        gc.collect()
+        torch.cuda.empty_cache()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--workload', default='stage1', choices=['stage1', 'stage2'],
+                    help="'stage1' = the headline (BASELINE configs[1]); 'stage2' = configs[2] on one GPU (a parity case, see DESIGN 9)")
+    ap.add_argument('--thick', action='store_true', help="with --workload stage2: the non-zero-thickness model (nu_nerf_amd/stage2_thick.py)")
+    ap.add_argument('--object-rays', action='store_true',
+                    help='aim every ray at the object: stage 1 -> inner-point share ~0.5 (the shading stack dominates); stage 2 -> all three bounces')
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--rays', type=int, default=4096, help='rays per GPU per step')
+    ap.add_argument('--start-step', type=int, default=20000, help='training-step index of the first iteration')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extra', action='store_true',
+                    help="headline line only: skip the extra_workloads legs (configs 3 / 4 and the 512-ray batch) of the default N = 1 run")
+    ap.add_argument('--mlp-dtype', default='fp32', choices=['fp32', 'bf16', 'bf16x6'],
+                    help="'bf16' = BASELINE config 4's MLP arithmetic (not the headline: the reference computes in fp32)")
+    ap.add_argument('--real-capture', action='store_true',
+                    help='real-capture code path (is_nerf False, sphere_direction True): BASELINE config 4 with --rays 8192 --mlp-dtype bf16')
+    ap.add_argument('--no-kernel-timing', action='store_true')
+    ap.add_argument('--unfused-loss', action='store_true', help='assemble the loss with the eager torch registry (development A/B)')
+    ap.add_argument('--time-every', type=int, default=0,
+                    help='bracket the GEMM launches with HIP events on every Nth step of the timed region; 0 (default): on ONE '
+                         'step in the middle of it (the ~330 event pairs cost that step 2-4 ms)')
+    args = ap.parse_args()
+    if args.workload == 'stage2':
+        if int(os.environ.get('WORLD_SIZE', 1)) != 1 or args.gpus != 1:
+            raise SystemExit("--workload stage2 runs on one GPU")
+        print(json.dumps(stage2_leg(args)), flush=True)
+        return
+
+    spawn_ranks_or_die(args)        # --gpus N without a launcher: start the N ranks ourselves (never returns in the parent)
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    import torch.distributed as dist
+    # NU_BENCH_DEVICE / NU_BENCH_BACKEND exist only to rehearse the multi-process path on a one-GPU box (gloo, all ranks on
+    # cuda:0); the driver's runs use one GPU per rank and RCCL ("nccl").
+    dev_index = int(os.environ.get('NU_BENCH_DEVICE', local_rank))
+    torch.cuda.set_device(dev_index)
+    dev = torch.device('cuda', dev_index)
+    if world > 1:
+        backend = os.environ.get('NU_BENCH_BACKEND', 'nccl')
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
+    rccl_ranks = dist.get_world_size() if world > 1 else 1
+    if rccl_ranks != args.gpus:
+        raise SystemExit(f"bench.py: process group has {rccl_ranks} rank(s), --gpus {args.gpus}")
+    coll_backend = dist.get_backend() if world > 1 else None
+    dist_ctx = (rank, world, dev, rccl_ranks, coll_backend)
+
+    res = stage1_leg(args, dist_ctx)
+    if rank == 0:
+        pool = res.pop('_pool')
+        headline = (args.rays == 4096 and args.mlp_dtype == 'fp32' and not args.real_capture and not args.object_rays
+                    and not args.unfused_loss)
+        if world == 1 and headline and not args.no_extra:
+            res["extra_workloads"] = run_extra_legs(args, dist_ctx)
         if world == 1 and not args.no_cpu_baseline and not args.real_capture and args.mlp_dtype == 'fp32':
             res["cpu_baseline"] = cpu_baseline(pool, args.start_step)
         print(json.dumps(res), flush=True)

@@ -315,6 +315,9 @@ typedef struct NuOpCtx {
     float* arena; long long arena_floats; long long arena_off;
     NuReduceDesc* descs; int ndesc, cap;  /* HOST array of deferred reductions */
     void** ev; double* ev_meta; int nev, ev_cap;      /* HOST arrays: hipEvent_t handles, 3 doubles per launch */
+    int forked, pad_;                     /* != 0 while ops of this context are in flight on MORE THAN ONE stream: a forced
+                                             mid-step flush would reduce slabs another stream still writes and hand their space
+                                             out again, so the entries return NU_ERR_WORKSPACE instead (fail closed) */
 } NuOpCtx;
 int nu_op_ctx_size(void);
 int nu_ctx_flush(NuOpCtx* ctx, hipStream_t stream);
@@ -391,16 +394,19 @@ int nu_shading_stack_bwd(NuOpCtx* ctx, const NuShadeNet* net, NuShadeBufs* bufs,
  *   rays that take part in the outer regulariser.  Weights of inactive terms are passed as 0.
  *   terms[6] = {loss_rgb, loss_eikonal, loss_outer_reg, loss_normal, their sum, candidate count}; per-ray outputs
  *   ray_rgb / color_spec [R,3], loss_rgb [R].  nu_loss_bwd reads the upstream gradient from device memory.
+ *   point_weight (optional device scalar, NULL = 1): factor on the eikonal mean and its gradient -- under data parallelism
+ *   this rank's share n_local * world / sum_r n_r of the mean over all ranks' inner points, so the N > 1 step
+ *   runs the same fused assembly as the N = 1 step.
  * --------------------------------------------------------------------------------------------------------- */
 long long nu_loss_workspace_bytes(int R, int P);
 int nu_loss_fwd(const float* rgb, const float* acc, const float* rgb_bg, const float* spec_raw, const float* gerr,
                 const float* nrm_sum, const float* gt, const unsigned char* cand, int R, int P, int white_bg, float exp_max,
                 float w_eik, float w_reg, float w_nrm, float* ray_rgb, float* color_spec, float* loss_rgb, float* terms,
-                void* workspace, long long workspace_bytes, hipStream_t stream);
+                const float* point_weight, void* workspace, long long workspace_bytes, hipStream_t stream);
 int nu_loss_bwd(const float* rgb, const float* acc, const float* rgb_bg, const float* spec_raw, const float* gt,
                 const unsigned char* cand, const float* ray_rgb, const float* color_spec, const float* loss_rgb,
-                const float* terms, const float* upstream, int R, int P, int white_bg, float exp_max, float w_eik, float w_reg,
-                float w_nrm, float* d_rgb, float* d_acc, float* d_rgb_bg, float* d_spec_raw, float* d_gerr, float* d_nrm,
+                const float* terms, const float* upstream, const float* point_weight, int R, int P, int white_bg, float exp_max,
+                float w_eik, float w_reg, float w_nrm, float* d_rgb, float* d_acc, float* d_rgb_bg, float* d_spec_raw, float* d_gerr, float* d_nrm,
                 hipStream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------

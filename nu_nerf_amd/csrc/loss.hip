@@ -71,8 +71,11 @@ __global__ __launch_bounds__(NU_LOSS_BLOCK) void loss_fwd_kernel(const float* __
 
 // terms[0..3] = loss_rgb, loss_eikonal, loss_outer_reg, loss_normal (each already weighted, = mean of the entry);
 // terms[4] = their sum; terms[5] = candidate count
+// point_weight (optional device scalar): this rank's share of a per-point mean over the union of all ranks' points
+// (parallel.GradAllReducer.point_weight); it scales the eikonal term and its gradient.  NULL = 1.
 __global__ __launch_bounds__(NU_LOSS_BLOCK) void loss_finish_kernel(const float* __restrict__ partial, int nblk, int R, int P,
-                                                                    float w_eik, float w_reg, float w_nrm, float* __restrict__ terms) {
+                                                                    float w_eik, float w_reg, float w_nrm,
+                                                                    const float* __restrict__ point_weight, float* __restrict__ terms) {
     __shared__ float red[NU_LOSS_BLOCK / 64];
     float s[NU_LOSS_TERMS + 1] = {0.f, 0.f, 0.f, 0.f, 0.f};
     for (int b = threadIdx.x; b < nblk; b += NU_LOSS_BLOCK)
@@ -83,7 +86,9 @@ __global__ __launch_bounds__(NU_LOSS_BLOCK) void loss_finish_kernel(const float*
     for (int k = 0; k < NU_LOSS_TERMS + 1; ++k) t[k] = nu_block_sum(s[k], red);
     if (threadIdx.x == 0) {
         const float l_rgb = R > 0 ? t[0] / (float)R : 0.f;
-        const float l_eik = P > 0 ? w_eik * t[1] / (float)P : 0.f;          // no inner point: the module reports zeros(1)
+        // (mean of gerr * pw) * w_eik, in the registry's order of operations; no inner point: the module reports zeros(1)
+        const float pw = point_weight ? point_weight[0] : 1.0f;
+        const float l_eik = P > 0 ? w_eik * (pw * t[1]) / (float)P : 0.f;
         const float l_reg = t[4] > 0.f ? w_reg * t[2] / (3.0f * t[4]) : 0.f;
         const float l_nrm = R > 0 ? w_nrm * t[3] / (float)R : 0.f;
         terms[0] = l_rgb; terms[1] = l_eik; terms[2] = l_reg; terms[3] = l_nrm;
@@ -97,7 +102,8 @@ __global__ __launch_bounds__(NU_LOSS_BLOCK) void loss_bwd_kernel(const float* __
                                                                  const float* __restrict__ gt, const unsigned char* __restrict__ cand,
                                                                  const float* __restrict__ ray_rgb, const float* __restrict__ color_spec,
                                                                  const float* __restrict__ loss_rgb, const float* __restrict__ terms,
-                                                                 const float* __restrict__ upstream, int R, int P, int white_bg,
+                                                                 const float* __restrict__ upstream,
+                                                                 const float* __restrict__ point_weight, int R, int P, int white_bg,
                                                                  float exp_max, float w_eik, float w_reg, float w_nrm,
                                                                  float* __restrict__ d_rgb, float* __restrict__ d_acc,
                                                                  float* __restrict__ d_rgb_bg, float* __restrict__ d_spec_raw,
@@ -131,7 +137,7 @@ __global__ __launch_bounds__(NU_LOSS_BLOCK) void loss_bwd_kernel(const float* __
         d_acc[i] = da;
         if (d_nrm) d_nrm[i] = up * w_nrm / (float)R;
     }
-    if (i < P) d_gerr[i] = up * w_eik / (float)P;
+    if (i < P) d_gerr[i] = (point_weight ? point_weight[0] : 1.0f) * (up * w_eik / (float)P);
 }
 
 extern "C" long long nu_loss_workspace_bytes(int R, int P) {
@@ -142,7 +148,8 @@ extern "C" long long nu_loss_workspace_bytes(int R, int P) {
 extern "C" int nu_loss_fwd(const float* rgb, const float* acc, const float* rgb_bg, const float* spec_raw, const float* gerr,
                            const float* nrm_sum, const float* gt, const unsigned char* cand, int R, int P, int white_bg,
                            float exp_max, float w_eik, float w_reg, float w_nrm, float* ray_rgb, float* color_spec,
-                           float* loss_rgb, float* terms, void* workspace, long long workspace_bytes, hipStream_t stream) {
+                           float* loss_rgb, float* terms, const float* point_weight, void* workspace, long long workspace_bytes,
+                           hipStream_t stream) {
     if (R <= 0 || P < 0) return NU_ERR_ARG;
     if (workspace_bytes < nu_loss_workspace_bytes(R, P)) return NU_ERR_WORKSPACE;
     const long long n = R > P ? R : P;
@@ -150,19 +157,19 @@ extern "C" int nu_loss_fwd(const float* rgb, const float* acc, const float* rgb_
     hipLaunchKernelGGL(loss_fwd_kernel, dim3(nblk), dim3(NU_LOSS_BLOCK), 0, stream, rgb, acc, rgb_bg, spec_raw, gerr, nrm_sum, gt, cand,
                        R, P, white_bg, exp_max, ray_rgb, color_spec, loss_rgb, (float*)workspace);
     hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(NU_LOSS_BLOCK), 0, stream, (const float*)workspace, nblk, R, P, w_eik, w_reg,
-                       w_nrm, terms);
+                       w_nrm, point_weight, terms);
     return nu_launch_status();
 }
 
 extern "C" int nu_loss_bwd(const float* rgb, const float* acc, const float* rgb_bg, const float* spec_raw, const float* gt,
                            const unsigned char* cand, const float* ray_rgb, const float* color_spec, const float* loss_rgb,
-                           const float* terms, const float* upstream, int R, int P, int white_bg, float exp_max, float w_eik,
-                           float w_reg, float w_nrm, float* d_rgb, float* d_acc, float* d_rgb_bg, float* d_spec_raw, float* d_gerr,
+                           const float* terms, const float* upstream, const float* point_weight, int R, int P, int white_bg,
+                           float exp_max, float w_eik, float w_reg, float w_nrm, float* d_rgb, float* d_acc, float* d_rgb_bg, float* d_spec_raw, float* d_gerr,
                            float* d_nrm, hipStream_t stream) {
     if (R <= 0 || P < 0) return NU_ERR_ARG;
     const long long n = R > P ? R : P;
     hipLaunchKernelGGL(loss_bwd_kernel, dim3((unsigned)nu_cdivl(n, NU_LOSS_BLOCK)), dim3(NU_LOSS_BLOCK), 0, stream, rgb, acc, rgb_bg,
-                       spec_raw, gt, cand, ray_rgb, color_spec, loss_rgb, terms, upstream, R, P, white_bg, exp_max, w_eik, w_reg, w_nrm,
+                       spec_raw, gt, cand, ray_rgb, color_spec, loss_rgb, terms, upstream, point_weight, R, P, white_bg, exp_max, w_eik, w_reg, w_nrm,
                        d_rgb, d_acc, d_rgb_bg, d_spec_raw, d_gerr, d_nrm);
     return nu_launch_status();
 }

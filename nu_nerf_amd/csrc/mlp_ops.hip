@@ -47,7 +47,12 @@ extern "C" int nu_ctx_flush(NuOpCtx* c, hipStream_t stream) {
 static int ctx_take(NuOpCtx* c, long long nbytes, int ndesc_needed, hipStream_t stream, float** out, long long* out_bytes) {
     const long long n = (nbytes + 255) / 256 * 64;          // floats, 256-byte granules
     if (n > c->arena_floats) return NU_ERR_WORKSPACE;
-    if (c->arena_off + n > c->arena_floats || c->ndesc + ndesc_needed > c->cap) CHK(nu_ctx_flush(c, stream));
+    if (c->arena_off + n > c->arena_floats || c->ndesc + ndesc_needed > c->cap) {
+        // a flush on THIS stream reduces every slab taken so far and hands their space out again: only safe when every producer
+        // is ordered before it, i.e. not while a second stream feeds the same arena (engine.py _fork / _join)
+        if (c->forked) return NU_ERR_WORKSPACE;
+        CHK(nu_ctx_flush(c, stream));
+    }
     *out = c->arena + c->arena_off;
     *out_bytes = n * 4;
     c->arena_off += n;

@@ -70,7 +70,8 @@ class Lin(ctypes.Structure):
 class OpCtx(ctypes.Structure):
     """Mirror of NuOpCtx: arithmetic mode, flat gradient buffer, deferred-reduction arena (shared by the Python-sequenced path)."""
     _fields_ = [("prec", c_int), ("h16", c_int), ("flat", c_p), ("arena", c_p), ("arena_floats", c_ll), ("arena_off", c_ll),
-                ("descs", c_p), ("ndesc", c_int), ("cap", c_int), ("ev", c_p), ("ev_meta", c_p), ("nev", c_int), ("ev_cap", c_int)]
+                ("descs", c_p), ("ndesc", c_int), ("cap", c_int), ("ev", c_p), ("ev_meta", c_p), ("nev", c_int), ("ev_cap", c_int),
+                ("forked", c_int), ("pad_", c_int)]
 
 
 class SdfNet(ctypes.Structure):
@@ -179,7 +180,8 @@ class Stage1Engine:
         # one context for both sequencing paths (network-level C entries and the launch-by-launch Python path below): the
         # descriptor count and the arena offset live in the struct
         self._ctx = OpCtx(prec=self.bf16, h16=1 if self.h16 else 0, flat=0, arena=0, arena_floats=0, arena_off=0,
-                          descs=ctypes.cast(self._rd, c_p).value, ndesc=0, cap=self._rd_cap, ev=0, ev_meta=0, nev=0, ev_cap=0)
+                          descs=ctypes.cast(self._rd, c_p).value, ndesc=0, cap=self._rd_cap, ev=0, ev_meta=0, nev=0, ev_cap=0,
+                          forked=0, pad_=0)
         self._ndesc_p = ctypes.cast(ctypes.addressof(self._ctx) + OpCtx.ndesc.offset, ctypes.POINTER(c_int))
         for fn, st in (("nu_op_ctx_size", OpCtx), ("nu_sdf_net_size", SdfNet), ("nu_sdf_bufs_size", SdfBufs), ("nu_nerf_net_size", NerfNet),
                        ("nu_nerf_bufs_size", NerfBufs), ("nu_shade_net_size", ShadeNet), ("nu_shade_bufs_size", ShadeBufs)):
@@ -254,10 +256,12 @@ class Stage1Engine:
         if getattr(self, '_side', None) is None:
             self._side = torch.cuda.Stream(self.dev)
         self._side.wait_stream(torch.cuda.current_stream(self.dev))
+        self._ctx.forked = 1          # until _join: no mid-pass flush of the shared arena (fail closed, NuOpCtx.forked)
         return self._side
 
     def _join(self):
         torch.cuda.current_stream(self.dev).wait_stream(self._side)
+        self._ctx.forked = 0
 
     # Stage 2 runs the ops of ONE engine on two streams (the inner segment on the side stream, the IoR / thickness networks on the
     # caller's): they share this engine's reduction arena and descriptor list, which a flush resets.  The host issues the ops one
@@ -295,9 +299,11 @@ class Stage1Engine:
     def _arena_take(self, nbytes):
         """Device address of `nbytes` of slab space that stays untouched until the next flush_reductions()."""
         n = (int(nbytes) + 255) // 256 * 64          # floats, 256-byte granules
-        if self._arena is None or self._ctx.arena_off + n > self._arena.numel():
-            self.flush_reductions()                   # stream order: later producers may then reuse the space
-            if self._arena is None or n > self._arena.numel():
+        if self._arena is None:
+            self._ensure_arena(n)
+        elif self._ctx.arena_off + n > self._arena.numel():
+            self._forced_flush()                      # stream order: later producers may then reuse the space
+            if n > self._arena.numel():
                 self._ensure_arena(n)
         off = self._ctx.arena_off
         self._ctx.arena_off += n
@@ -309,11 +315,20 @@ class Stage1Engine:
             # >= 4 GiB: the split-reduction slabs of one step come to 1.5-2 GB at every batch size (the split count is capped, not
             # the point count), so the arena never fills inside a step and the one batched reduction runs after the last producer
             # -- which is also what makes the two-stream mode safe (an early flush would reduce slabs the other stream still writes)
-            self._arena = torch.empty(max(n, 1 << 30), dtype=torch.float32, device=self.dev)
+            self._arena = torch.empty(max(n, int(os.environ.get('NU_ARENA_FLOATS', 1 << 30))), dtype=torch.float32, device=self.dev)
             self._ctx.arena, self._ctx.arena_floats = self._arena.data_ptr(), self._arena.numel()
 
     def flush_reductions(self):
         L.check(self.lib.nu_ctx_flush(ctypes.byref(self._ctx), self.stream()), "nu_ctx_flush")
+
+    def _forced_flush(self):
+        """A flush forced by a full arena / descriptor table in the MIDDLE of a pass.  While the engine is forked (two streams feed
+        the one arena) that would reduce slabs the other stream may still be writing and then hand their space out again:
+        fail closed, like the C entries (NuOpCtx.forked -> NU_ERR_WORKSPACE)."""
+        if self._ctx.forked:
+            raise L.NuNerfLibraryError("split-reduction arena (or descriptor table) full while two streams share it: raise "
+                                       "NU_ARENA_FLOATS or lower NU_TWO_STREAM_SAMPLES (NU_ERR_WORKSPACE)")
+        self.flush_reductions()
 
     # ------------------------------------------------------------------ layer tables
     def _build_layers(self):
@@ -609,22 +624,30 @@ class Stage1Engine:
             abytes = 4.0 * groups * (M * (ktrue or K) + M * (ntrue or N) * nmat + N * (ktrue or K))
             kt['nt'].append((e0, e1, 2.0 * M * (ntrue or N) * (ktrue or K) * groups, abytes))
 
-    def begin_kernel_timing(self, reserve=0):
+    def begin_kernel_timing(self, reserve=0, py_reserve=None):
         """Bracket every GEMM launch with HIP events on the launch stream (bench.py's roofline leg).  The network-level C
         entries record the events themselves (NuOpCtx.ev); the Python-sequenced path records them here.  The event pairs cost
-        about 4 ms per step (two queue barriers per launch), so the bench switches `ktime_on` per step to sample."""
+        about 4 ms per step (two queue barriers per launch), so the bench switches `ktime_on` per step to sample.
+        The pool is SPLIT: the first `reserve - py_reserve` events belong to the C entries (used in order, NuOpCtx.ev_cap), the
+        rest to the Python-sequenced launches (stage 2 uses both paths in one step) -- no event is ever recorded twice."""
         self._ktime = {'nt': [], 'tn': []}
         # events are created here, outside the timed region: torch makes the HIP event at the first record(), and creating
         # the ~650 events of one bracketed step used to cost that step 70 ms
-        n = max(int(reserve), 2) // 2 * 2
-        self._ev_pool = [torch.cuda.Event(enable_timing=True) for _ in range(n)]
-        for ev in self._ev_pool:
+        n = max(int(reserve), 4) // 4 * 4
+        if py_reserve is None:
+            py_reserve = n if self.py_seq else n // 4
+        py_reserve = min(max(int(py_reserve), 0) // 2 * 2, n)
+        pool = [torch.cuda.Event(enable_timing=True) for _ in range(n)]
+        for ev in pool:
             ev.record()
         torch.cuda.synchronize(self.dev)
-        self._ev_c = list(self._ev_pool)                      # the C path uses them in order; the Python path pops from the end
-        self._ev_handles = (c_p * n)(*[ev.cuda_event for ev in self._ev_c])
-        self._ev_meta = (ctypes.c_double * (3 * (n // 2)))()
-        self._ctx.nev, self._ctx.ev_cap, self._ctx.ev_meta = 0, (0 if self.py_seq else n), ctypes.addressof(self._ev_meta)
+        n_c = 0 if self.py_seq else n - py_reserve
+        self._ev_c = pool[:n_c]                               # the C entries use these in order
+        self._ev_pool = pool[n_c:]                            # the Python-sequenced launches pop pairs from these
+        self._ev_py_exhausted = False
+        self._ev_handles = (c_p * max(n_c, 1))(*[ev.cuda_event for ev in self._ev_c])
+        self._ev_meta = (ctypes.c_double * (3 * max(n_c // 2, 1)))()
+        self._ctx.nev, self._ctx.ev_cap, self._ctx.ev_meta = 0, n_c, ctypes.addressof(self._ev_meta)
         self.ktime_on = True
 
     @property
@@ -634,13 +657,14 @@ class Stage1Engine:
     @ktime_on.setter
     def ktime_on(self, on):
         self._ktime_on = bool(on)
-        live = self._ktime_on and self._ktime is not None and not self.py_seq
+        live = self._ktime_on and self._ktime is not None and not self.py_seq and self._ctx.ev_cap > 0
         self._ctx.ev = ctypes.addressof(self._ev_handles) if live else 0
 
     def _event_pair(self):
         pool = self._ev_pool
         if len(pool) >= 2:
             return pool.pop(), pool.pop()
+        self._ev_py_exhausted = True                          # reported: events made here cost the bracketed step host time
         return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
     def end_kernel_timing(self):
@@ -650,7 +674,8 @@ class Stage1Engine:
         for i in range(self._ctx.nev // 2):                  # launches the C entries bracketed
             kind, flops, nbytes = self._ev_meta[3 * i:3 * i + 3]
             kt['tn' if kind else 'nt'].append((self._ev_c[2 * i], self._ev_c[2 * i + 1], flops, nbytes))
-        out = {'event_capacity_reached': bool(self._ctx.ev_cap and self._ctx.nev >= self._ctx.ev_cap)}
+        out = {'event_capacity_reached': bool(self._ctx.ev_cap and self._ctx.nev >= self._ctx.ev_cap),
+               'python_event_pool_exhausted': bool(getattr(self, '_ev_py_exhausted', False))}
         self._ctx.nev = 0
         for key, pre in (('nt', ''), ('tn', 'tn_')):
             out[pre + 'seconds'] = sum(a.elapsed_time(b) for a, b, _, _ in kt[key]) * 1e-3
@@ -675,7 +700,7 @@ class Stage1Engine:
     def _wgrad(self, A0, lda0, B0, ldb0, P, N1, N2, dW, ldw, db, A1, lda1, B1, ldb1, groups, sA0, sB0, sA1, sB1, sW, sDb):
         S = self.lib.nu_wgrad_pick_split(P, N1, N2, groups, self.bf16)     # the rule the network-level C entries use too
         if self._ctx.ndesc + 2 * groups > self._rd_cap:
-            self.flush_reductions()
+            self._forced_flush()
         ws, nb = self._arena_take(self.lib.nu_wgrad_workspace_bytes(N1, N2, S, groups))
         g = GemmTN(A0, lda0, B0, ldb0, A1, lda1, B1, ldb1, P, N1, N2, 0, 0, S, groups, sA0, sB0, sA1, sB1, 0, 0, self.bf16, 0)
         L.check(self.lib.nu_wgrad_enqueue(ctypes.byref(g), c_p(dW), ldw, c_ll(sW), c_p(db), c_ll(sDb), c_p(ws), c_ll(nb),
@@ -687,7 +712,7 @@ class Stage1Engine:
 
     def skinny_bwd(self, dy, ldy, H, ldh, P, K, Ws, ldw, NO, dH, lddh, relu_mask, accumulate, dWs, lddw, db):
         if self._ctx.ndesc + 2 > self._rd_cap:
-            self.flush_reductions()
+            self._forced_flush()
         ws, nb = self._arena_take(self.lib.nu_skinny_bwd_workspace_bytes(K, NO))
         L.check(self.lib.nu_skinny_bwd_enqueue(c_p(dy), ldy, c_p(H), ldh, P, K, c_p(Ws), ldw, NO, c_p(dH), lddh, relu_mask,
                                                accumulate, c_p(dWs), lddw, c_p(db), c_p(ws), c_ll(nb), self._rd,
@@ -695,7 +720,7 @@ class Stage1Engine:
 
     def colsum(self, A, lda, P, ncols, out, accumulate):
         if self._ctx.ndesc + 1 > self._rd_cap:
-            self.flush_reductions()
+            self._forced_flush()
         ws, nb = self._arena_take(self.lib.nu_colsum_workspace_bytes(ncols))
         L.check(self.lib.nu_colsum_enqueue(c_p(A), lda, P, ncols, c_p(out), accumulate, c_p(ws), c_ll(nb), self._rd,
                                            self._ndesc_p, self._rd_cap, self.stream()), "nu_colsum_enqueue")

@@ -166,7 +166,7 @@ class _FusedLossFn(torch.autograd.Function):
     Two launches forward, one backward; the upstream gradient never visits the host."""
 
     @staticmethod
-    def forward(ctx, rgb, acc, rgb_bg, spec_raw, gerr, nrm_sum, gt, cand, white_bg, exp_max, w_eik, w_reg, w_nrm):
+    def forward(ctx, rgb, acc, rgb_bg, spec_raw, gerr, nrm_sum, gt, cand, white_bg, exp_max, w_eik, w_reg, w_nrm, point_weight=None):
         import ctypes
         from . import _lib as L
         lib = L.load()
@@ -177,16 +177,18 @@ class _FusedLossFn(torch.autograd.Function):
         ts = [t.detach().contiguous() if t is not None else None for t in (rgb, acc, rgb_bg, spec_raw, gerr, nrm_sum, gt)]
         rgb_, acc_, bg_, spec_, gerr_, nrm_, gt_ = ts
         cand_ = None if cand is None else cand.to(torch.uint8).contiguous()
+        # data parallelism: device scalar that turns the per-rank eikonal mean into this rank's share of the global one
+        pw_ = None if point_weight is None else point_weight.detach().reshape(-1)[:1].to(device=dev, dtype=torch.float32).contiguous()
         nb = lib.nu_loss_workspace_bytes(R, P)
         ws = torch.empty((nb + 3) // 4, device=dev)
         ray_rgb, color_spec, loss_rgb, terms = (torch.empty(R, 3, device=dev), torch.empty(R, 3, device=dev),
                                                 torch.empty(R, device=dev), torch.empty(6, device=dev))
         L.check(lib.nu_loss_fwd(L.ptr(rgb_), L.ptr(acc_), L.ptr(bg_), L.ptr(spec_), L.ptr(gerr_ if P else None), L.ptr(nrm_), L.ptr(gt_),
                                 L.ptr(cand_), R, P, int(white_bg), ctypes.c_float(exp_max), ctypes.c_float(w_eik), ctypes.c_float(w_reg),
-                                ctypes.c_float(w_nrm), L.ptr(ray_rgb), L.ptr(color_spec), L.ptr(loss_rgb), L.ptr(terms), L.ptr(ws),
+                                ctypes.c_float(w_nrm), L.ptr(ray_rgb), L.ptr(color_spec), L.ptr(loss_rgb), L.ptr(terms), L.ptr(pw_), L.ptr(ws),
                                 ctypes.c_longlong(nb), L.stream()), "nu_loss_fwd")
         ctx.save_for_backward(rgb_, acc_, bg_, spec_, gt_, ray_rgb, color_spec, loss_rgb, terms)
-        ctx.cand, ctx.nrm = cand_, nrm_ is not None
+        ctx.cand, ctx.nrm, ctx.pw = cand_, nrm_ is not None, pw_
         ctx.k = (R, P, int(white_bg), float(exp_max), float(w_eik), float(w_reg), float(w_nrm))
         ctx.mark_non_differentiable(terms, ray_rgb, color_spec, loss_rgb)
         return terms[4].clone(), terms, ray_rgb, color_spec, loss_rgb
@@ -205,25 +207,38 @@ class _FusedLossFn(torch.autograd.Function):
         d_gerr = torch.empty(P, device=dev)
         d_nrm = torch.empty(R, device=dev) if ctx.nrm else None
         L.check(lib.nu_loss_bwd(L.ptr(rgb_), L.ptr(acc_), L.ptr(bg_), L.ptr(spec_), L.ptr(gt_), L.ptr(ctx.cand), L.ptr(ray_rgb),
-                                L.ptr(color_spec), L.ptr(loss_rgb), L.ptr(terms), L.ptr(up), R, P, white_bg, ctypes.c_float(exp_max),
+                                L.ptr(color_spec), L.ptr(loss_rgb), L.ptr(terms), L.ptr(up), L.ptr(ctx.pw), R, P, white_bg, ctypes.c_float(exp_max),
                                 ctypes.c_float(w_eik), ctypes.c_float(w_reg), ctypes.c_float(w_nrm), L.ptr(d_rgb), L.ptr(d_acc),
                                 L.ptr(d_bg), L.ptr(d_spec), L.ptr(d_gerr if P else None), L.ptr(d_nrm), L.stream()), "nu_loss_bwd")
-        return d_rgb, d_acc, d_bg, d_spec, d_gerr, d_nrm, None, None, None, None, None, None, None
+        return d_rgb, d_acc, d_bg, d_spec, d_gerr, d_nrm, None, None, None, None, None, None, None, None
 
 
 _FUSED_TYPES = None
 
 
-def fused_stage1_loss(renderer, batch, step, losses, rand=None):
+def fused_stage1_loss(renderer, batch, step, losses, rand=None, reducer=None):
     """One training forward + the trainer's total (train/trainer_zero.py:153-161) with the loss assembly on the HIP loss
     kernels: NeRFRenderLoss (charbonier), EikonalLoss, OuterRegLoss and NormalOrientationLoss are fused; StdRecorder, OccLoss,
     InitSDFRegLoss and MaskLoss entries keep their (O(1)-sized) torch form and are added on.  Returns (total, log, outputs)
-    with the same log keys and values as `total_loss` gives on the unfused outputs."""
+    with the same log keys and values as `total_loss` gives on the unfused outputs.
+
+    reducer (parallel.GradAllReducer, world > 1): the eikonal mean becomes this rank's share of the mean over the union of all
+    ranks' inner points (`reducer.point_weight`, a device scalar handed to the loss kernels), so the data-parallel step runs
+    the SAME fused assembly as the single-GPU step and its all-reduced gradient equals the single-process one."""
+    pw = None
+    if reducer is not None and reducer.world > 1:
+        pw_of = lambda: reducer.point_weight(renderer.engine().last_ctx['P_in_dev'], batch['rays_o'].device)
+    else:
+        pw_of = None
     if renderer.cfg['rgb_loss'] != 'charbonier' or not any(isinstance(ls, NeRFRenderLoss) for ls in losses):
         out = renderer.train_step_rays(batch, step, rand=rand)
+        if pw_of is not None:
+            out['gradient_error'] = out['gradient_error'] * pw_of()
         total, log = total_loss(out, losses, step)
         return total, log, out
     out = renderer.train_step_rays(batch, step, rand=rand, fused=True)
+    if pw_of is not None:
+        pw = pw_of()
     raw = out.pop('_raw')
     w_eik = w_reg = w_nrm = 0.0
     rest = []
@@ -242,7 +257,7 @@ def fused_stage1_loss(renderer, batch, step, losses, rand=None):
     nrm = raw['nrm_sum'] if w_nrm else None
     total, terms, ray_rgb, color_spec, loss_rgb = _FusedLossFn.apply(
         raw['rgb'], raw['acc'], raw['rgb_bg'], raw['spec_raw'], gerr, nrm, batch['rgbs'], raw['cand'], raw['is_nerf'], raw['exp_max'],
-        w_eik, w_reg, w_nrm)
+        w_eik, w_reg, w_nrm, pw)
     cand = raw['cand']
     out['ray_rgb'] = ray_rgb
     out['color_spec'] = color_spec if cand is None else color_spec[cand]

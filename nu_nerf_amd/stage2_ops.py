@@ -121,10 +121,13 @@ class _CompositeFn(torch.autograd.Function):
         alpha, color, T = ctx.saved_tensors
         N, S = alpha.shape
         dalpha, dcolor, dT = torch.empty_like(alpha), torch.empty_like(color), torch.empty_like(T)
+        # named locals: a contiguous copy made inside the argument list dies as soon as addr() returns, and the second copy
+        # could then be handed the first one's block (engine.render_backward has the same rule)
+        dout_c = dout.contiguous() if dout is not None else None
+        dTout_c = dTout.contiguous() if dTout is not None else None
         if N > 0:
             L.check(ctx.eng.lib.nu_s2_composite_bwd(c_p(addr(alpha)), c_p(addr(color)), c_p(addr(T)), N, S,
-                                                    c_p(addr(dout.contiguous() if dout is not None else None)),
-                                                    c_p(addr(dTout.contiguous() if dTout is not None else None)),
+                                                    c_p(addr(dout_c)), c_p(addr(dTout_c)),
                                                     c_p(addr(dalpha)), c_p(addr(dcolor)), c_p(addr(dT)), ctx.eng.stream()),
                     "nu_s2_composite_bwd")
         return None, dalpha, dcolor, dT
@@ -402,8 +405,9 @@ class _NeusAlphaFn(torch.autograd.Function):
         sdf, nrm, dirs, dist, s1 = ctx.saved_tensors
         P = sdf.shape[0]
         g_sdf, g_n, g_d, g_dist, g_s = torch.empty_like(sdf), torch.empty_like(nrm), torch.empty_like(dirs), torch.empty_like(dist), torch.empty_like(sdf)
+        g_c = g.contiguous()
         L.check(ctx.eng.lib.nu_s2_neus_alpha_bwd(c_p(addr(sdf)), c_p(addr(nrm)), c_p(addr(dirs)), c_p(addr(dist)), c_p(addr(s1)),
-                                                 ctypes.c_float(ctx.ca), P, c_p(addr(g.contiguous())), c_p(addr(g_sdf)), c_p(addr(g_n)),
+                                                 ctypes.c_float(ctx.ca), P, c_p(addr(g_c)), c_p(addr(g_sdf)), c_p(addr(g_n)),
                                                  c_p(addr(g_d)), c_p(addr(g_dist)), c_p(addr(g_s)), ctx.eng.stream()), "nu_s2_neus_alpha_bwd")
         return None, g_sdf, g_n, g_d, g_dist, g_s.sum().reshape(ctx.s_shape), None
 

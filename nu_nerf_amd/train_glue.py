@@ -180,11 +180,14 @@ def train_step(network, optimizer, lr_manager, losses, step, batch=None, reducer
     store (forward({'step': step})); otherwise an explicit {'rays_o','rays_d','rgbs'} batch."""
     lr = lr_manager(optimizer, step)
     optimizer.zero_grad(set_to_none=True)
-    if batch is not None and reducer is None and hasattr(network, 'engine') and type(network).__name__ == 'NeROShapeRenderer':
-        # explicit stage-1 ray batch: loss assembly on the HIP loss kernels (loss.fused_stage1_loss), same total and log
+    if batch is not None and hasattr(network, 'engine') and type(network).__name__ == 'NeROShapeRenderer':
+        # explicit stage-1 ray batch: loss assembly on the HIP loss kernels (loss.fused_stage1_loss), same total and log; with a
+        # reducer the eikonal mean takes this rank's point weight inside the kernels, so N > 1 runs the same step as N = 1
         from .loss import fused_stage1_loss
-        total, log_info, _ = fused_stage1_loss(network, batch, step, losses)
+        total, log_info, _ = fused_stage1_loss(network, batch, step, losses, reducer=reducer)
         total.backward()
+        if reducer is not None:
+            reducer.all_reduce()
         optimizer.step()
         return total.detach(), log_info, lr
     outputs = network({'step': step}) if batch is None else network.train_step_rays(batch, step)

@@ -42,3 +42,29 @@ def rel_err(a, b):
 
 STD_CFG = {'n_samples': 64, 'n_importance': 32, 'n_bg_samples': 16, 'sphere_direction': True, 'refrac_freq': 3,
            'eikonal_weight': 0.05, 'outer_reg_loss_weight': 0.1, 'normal_ori': True, 'is_nerf': False}
+
+
+def check_ray_batch_against_reference_fixture(device):
+    """SURVEY 8(a) row a2 on `device`: get_human_coordinate_poses (both fixed_camera settings) and _process_ray_batch
+    (network/renderer.py:346-378) against tests/golden/ray_batch_std.npz (oracle/gen_golden_r2.py)."""
+    from nu_nerf_amd.renderer_std import NeROShapeRenderer as StdRenderer
+    g = golden("ray_batch_std.npz")
+    dev = torch.device(device)
+    poses = torch.from_numpy(g['poses']).to(dev)
+    for fixed, key in ((False, 'human_poses_free'), (True, 'human_poses_fixed')):
+        net = StdRenderer({'is_nerf': False, 'fixed_camera': fixed, 'shader_config': {'sphere_direction': True}}, training=False)
+        hp = net.get_human_coordinate_poses(poses.clone())
+        assert hp.device.type == dev.type
+        np.testing.assert_allclose(hp.cpu().numpy(), g[key], rtol=1e-6, atol=1e-6)
+        assert torch.equal(poses.cpu(), torch.from_numpy(g['poses']))                 # the input is not modified
+    net = StdRenderer({'is_nerf': False, 'shader_config': {'sphere_direction': True}}, training=False)
+    ro, rd, near, far, hpr = net._process_ray_batch({'dirs': torch.from_numpy(g['dirs']).to(dev), 'idxs': torch.from_numpy(g['idxs']).to(dev)},
+                                                    poses)
+    for t in (ro, rd, near, far, hpr):
+        assert t.device.type == dev.type
+    np.testing.assert_allclose(ro.cpu().numpy(), g['rays_o'], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(rd.cpu().numpy(), g['rays_d'], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(near.cpu().numpy(), g['near'], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(far.cpu().numpy(), g['far'], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(hpr.cpu().numpy(), g['human_poses_rays'], rtol=1e-6, atol=1e-6)
+    assert float(near.min()) >= 1e-3 and bool((far - near <= 2.0 + 1e-6).all())

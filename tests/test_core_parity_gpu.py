@@ -221,6 +221,15 @@ def test_fused_loss_kernels_equal_the_loss_registry(gpu, std):
     total_b, log_b, out_b = fused_stage1_loss(b, batch, step, losses, rand=rand)
     total_b.backward()
     np.testing.assert_allclose(float(total_b.detach()), float(total_a.detach()), rtol=2e-6)
+    # ... and DIRECTLY against the reference's own numbers for this step (fixture written by the reference's classes): the fused
+    # total and every term_* the fixture holds, not only through the registry
+    np.testing.assert_allclose(float(total_b.detach()), float(g['total_loss']), rtol=1e-5)
+    n_terms = 0
+    for k, v in g.items():
+        if k.startswith('term_') and k[5:] in log_b:
+            np.testing.assert_allclose(float(torch.mean(log_b[k[5:]]).detach()), float(np.mean(v)), rtol=2e-4, atol=1e-7, err_msg=k)
+            n_terms += 1
+    assert n_terms >= 3, sorted(k for k in g if k.startswith('term_'))
     assert set(k for k in log_a if k.startswith('loss')) == set(k for k in log_b if k.startswith('loss'))
     for k in log_a:
         if k.startswith('loss'):
@@ -231,6 +240,99 @@ def test_fused_loss_kernels_equal_the_loss_registry(gpu, std):
         assert (p.grad is None) == (q.grad is None), n
         if p.grad is not None:
             assert rel_err(q.grad, p.grad) < 1e-5, (n, rel_err(q.grad, p.grad))
+
+
+class _FixedWeightReducer:
+    """Stand-in for parallel.GradAllReducer on one process: world 2, this rank holds 70 % of the union's inner points."""
+    world = 2
+
+    def point_weight(self, n_local, device):
+        return torch.full((1,), 1.4, device=device)
+
+
+def test_fused_loss_with_the_data_parallel_point_weight(gpu):
+    """under data parallelism the eikonal mean is this rank's share of the mean over all ranks' inner points.  The
+    fused loss kernels take that count ratio as a DEVICE scalar (nu_loss_fwd / nu_loss_bwd `point_weight`), so the N > 1 step is
+    the N = 1 step: same total, terms and gradients as the registry path on `gradient_error * point_weight`."""
+    from nu_nerf_amd.loss import name2loss, SPHEREPOT_LOSSES, total_loss, fused_stage1_loss
+    g = golden("train_step20000_r48.npz")
+    step = int(g['step'])
+    batch = {k: torch.from_numpy(g[k]).to(gpu) for k in ('rays_o', 'rays_d', 'rgbs')}
+    rand = (torch.from_numpy(g['u1']).to(gpu), torch.from_numpy(g['u2']).to(gpu))
+    losses = [name2loss[n](CFG) for n in SPHEREPOT_LOSSES]
+    red = _FixedWeightReducer()
+    a, b, c = make_net(gpu), make_net(gpu), make_net(gpu)
+    out_a = a.train_step_rays(batch, step, rand=rand)
+    out_a['gradient_error'] = out_a['gradient_error'] * red.point_weight(None, gpu)
+    total_a, log_a = total_loss(out_a, losses, step)
+    total_a.backward()
+    total_b, log_b, _ = fused_stage1_loss(b, batch, step, losses, rand=rand, reducer=red)
+    total_b.backward()
+    total_c, log_c, _ = fused_stage1_loss(c, batch, step, losses, rand=rand)
+    np.testing.assert_allclose(float(total_b.detach()), float(total_a.detach()), rtol=2e-6)
+    np.testing.assert_allclose(float(log_b['loss_eikonal'].detach()), float(torch.mean(log_a['loss_eikonal']).detach()), rtol=3e-6)
+    np.testing.assert_allclose(float(log_b['loss_eikonal'].detach()), 1.4 * float(log_c['loss_eikonal'].detach()), rtol=3e-6)
+    for (n, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
+        assert (p.grad is None) == (q.grad is None), n
+        if p.grad is not None:
+            assert rel_err(q.grad, p.grad) < 1e-5, (n, rel_err(q.grad, p.grad))
+
+
+@pytest.mark.parametrize("py_seq", [False, True])
+def test_full_arena_flushes_in_one_stream_mode_and_fails_closed_when_forked(gpu, monkeypatch, py_seq):
+    """The split-reduction arena is shared by everything an engine enqueues.  When it (or the descriptor table) fills in the
+    middle of a pass, the pending slabs are reduced on the calling stream and their space is handed out again -- correct on one
+    stream (same gradients, bit for bit), a race while the NeRF++ chain runs on the side stream (engine._fork: the other stream
+    may still be writing those slabs).  The forked engine must therefore fail closed (NuOpCtx.forked -> NU_ERR_WORKSPACE), in
+    both sequencing paths."""
+    from nu_nerf_amd._lib import NuNerfLibraryError
+    from nu_nerf_amd.loss import name2loss, SPHEREPOT_LOSSES, total_loss
+    g = golden("train_step20000_r48.npz")
+    step = int(g['step'])
+    batch = {k: torch.from_numpy(g[k]).to(gpu) for k in ('rays_o', 'rays_d', 'rgbs')}
+    rand = (torch.from_numpy(g['u1']).to(gpu), torch.from_numpy(g['u2']).to(gpu))
+    losses = [name2loss[n](CFG) for n in SPHEREPOT_LOSSES]
+
+    def run(two_stream, arena_floats=None):
+        if arena_floats is None:
+            monkeypatch.delenv('NU_ARENA_FLOATS', raising=False)
+        else:
+            monkeypatch.setenv('NU_ARENA_FLOATS', str(int(arena_floats)))
+        net = make_net(gpu)
+        eng = net.engine()
+        eng.py_seq = py_seq
+        eng._TWO_STREAM_SAMPLES = (1 << 30) if two_stream else 0
+        peak, flushes = [0], [0]
+        real_flush = eng.flush_reductions
+
+        def flush():
+            peak[0] = max(peak[0], int(eng._ctx.arena_off))
+            flushes[0] += 1
+            real_flush()
+        eng.flush_reductions = flush
+        torch.manual_seed(11)
+        out = net.train_step_rays(batch, step, rand=rand)
+        assert eng.last_ctx['two_streams'] == two_stream
+        total, _ = total_loss(out, losses, step)
+        total.backward()
+        torch.cuda.synchronize()
+        return ({n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None}, peak[0], flushes[0],
+                int(eng._arena.numel()))
+
+    ref, peak, flushes0, full = run(False)
+    assert 0 < peak < full
+    small = max(peak // 3, 1 << 16) // 64 * 64
+    got, _, flushes1, numel = run(False, small)
+    assert numel == small < peak                                       # a step's slabs do not fit: the arena filled mid-pass
+    assert set(got) == set(ref)
+    for n in ref:
+        assert torch.equal(got[n], ref[n]), n
+    forked, _, _, _ = run(True)                                        # default arena, two streams: the same gradients
+    for n in ref:
+        assert torch.equal(forked[n], ref[n]), n
+    with pytest.raises(NuNerfLibraryError):
+        run(True, small)
+    torch.cuda.synchronize()
 
 
 def test_network_level_c_entries_equal_launch_by_launch_sequencing(gpu):

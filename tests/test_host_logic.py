@@ -223,23 +223,8 @@ def test_process_ray_batch_and_human_poses_vs_reference_fixture():
     renderer.py:354-355), so the generator called it pose by pose; _process_ray_batch ends in that call, so its ray part
     (renderer.py:367-376: plain arithmetic on the inputs + the reference's near_far_from_sphere) was evaluated line by line
     -- the fixture says so in `process_ray_batch_restated`."""
-    from helpers import golden
-    from nu_nerf_amd.renderer_std import NeROShapeRenderer as StdRenderer
-    g = golden("ray_batch_std.npz")
-    poses = torch.from_numpy(g['poses'])
-    for fixed, key in ((False, 'human_poses_free'), (True, 'human_poses_fixed')):
-        net = StdRenderer({'is_nerf': False, 'fixed_camera': fixed, 'shader_config': {'sphere_direction': True}}, training=False)
-        hp = net.get_human_coordinate_poses(poses.clone())
-        np.testing.assert_allclose(hp.numpy(), g[key], rtol=1e-6, atol=1e-6)
-        assert torch.equal(poses, torch.from_numpy(g['poses']))                       # the input is not modified
-    net = StdRenderer({'is_nerf': False, 'shader_config': {'sphere_direction': True}}, training=False)
-    ro, rd, near, far, hpr = net._process_ray_batch({'dirs': torch.from_numpy(g['dirs']), 'idxs': torch.from_numpy(g['idxs'])}, poses)
-    np.testing.assert_allclose(ro.numpy(), g['rays_o'], rtol=1e-6, atol=1e-6)
-    np.testing.assert_allclose(rd.numpy(), g['rays_d'], rtol=1e-6, atol=1e-6)
-    np.testing.assert_allclose(near.numpy(), g['near'], rtol=1e-6, atol=1e-6)
-    np.testing.assert_allclose(far.numpy(), g['far'], rtol=1e-6, atol=1e-6)
-    np.testing.assert_allclose(hpr.numpy(), g['human_poses_rays'], rtol=1e-6, atol=1e-6)
-    assert float(near.min()) >= 1e-3 and bool((far - near <= 2.0 + 1e-6).all())
+    from helpers import check_ray_batch_against_reference_fixture
+    check_ray_batch_against_reference_fixture('cpu')
 
 
 def test_forward_routes_eval_requests_to_test_step_cpu_side():

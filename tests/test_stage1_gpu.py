@@ -314,3 +314,10 @@ def test_standard_renderer_sphere_direction_vs_reference_golden(gpu):
     for k in g:
         if k.startswith('grad__'):
             assert rel_err(named[k[6:]].grad.cpu(), g[k]) < 3e-2, k   # element-wise: sensitive to the shifted samples
+
+
+def test_process_ray_batch_and_human_poses_on_the_device(gpu):
+    """Row a2 on the GPU: the same assertions as the CPU test (tests/test_host_logic.py), on `cuda` tensors -- the real-capture
+    ray construction is what feeds the device-resident ray store."""
+    from helpers import check_ray_batch_against_reference_fixture
+    check_ray_batch_against_reference_fixture(gpu)
