@@ -278,20 +278,84 @@ class NeROShapeRenderer(nn.Module):
 
     # ---- data ----------------------------------------------------------------------------------
     def _init_dataset(self):
-        """Ray-batch store.  Only the synthetic source exists offline (`database_name: synthetic/<n_rays>`);
-        the reference's image databases (dataset/database.py) are out of scope."""
+        """Ray-batch store (renderer_zerothick.py:167-190).  `database_name: synthetic/<n_rays>` builds the seeded synthetic
+        pool.  For the reference's image databases (nerf/..., real/...) LOADING the images is outside this build (SURVEY.md
+        row 14: dataset/database.py needs the dataset files): the module is constructed without a store and the caller hands
+        the loaded images over with `set_ray_store(train_imgs_info[, test_imgs_info])` -- the second half of the reference's
+        _init_dataset -- before the first train_step."""
         name = self.cfg['database_name']
+        self.train_batch_i = 0
+        self._batch_dev = None
+        self.test_imgs_info = None
         if not name.startswith('synthetic'):
-            raise NotImplementedError(
-                f"database '{name}': image databases are outside this build's scope; use 'synthetic/<n_rays>' "
-                "or construct with training=False and call render()/train_step_rays() with your own rays")
+            self.train_batch, self.train_poses, self.tbn = None, None, 0
+            return
         parts = name.split('/')
         n = int(parts[1]) if len(parts) > 1 else 1 << 20
         rays = synthetic.make_rays(n, seed=int(self.cfg.get('ray_seed', 6033)))
         self.train_batch = {k: torch.from_numpy(v) for k, v in rays.items()}
+        self.train_poses = None
         self.tbn = n
-        self.train_batch_i = 0
-        self._batch_dev = None
+
+    @staticmethod
+    def _construct_ray_batch(imgs_info, device=None):
+        """Real captures (renderer_zerothick.py:199-220): per-pixel camera-space directions K^-1 [x + 0.5, y + 0.5, 1], colours
+        and image indices, pixel-major per image; built on `device` (default: where the images are).
+        -> (ray_batch {'dirs','rgbs','idxs'}, poses, n_rays, h, w)."""
+        imgs = imgs_info['imgs']
+        device = imgs.device if device is None else torch.device(device)
+        imn, _, h, w = imgs.shape
+        ys, xs = torch.meshgrid(torch.arange(h, device=device), torch.arange(w, device=device), indexing='ij')
+        coords = torch.stack([xs, ys], -1).float().reshape(1, h * w, 2).repeat(imn, 1, 1)
+        coords = torch.cat([coords + 0.5, torch.ones(imn, h * w, 1, dtype=torch.float32, device=device)], 2)
+        dirs = coords @ torch.inverse(imgs_info['Ks'].to(device)).permute(0, 2, 1)
+        rgbs = imgs.to(device).permute(0, 2, 3, 1).reshape(imn, h * w, 3)
+        idxs = torch.arange(imn, dtype=torch.int64, device=device)[:, None, None].repeat(1, h * w, 1)
+        rn = imn * h * w
+        batch = {'dirs': dirs.float().reshape(rn, 3), 'rgbs': rgbs.float().reshape(rn, 3), 'idxs': idxs.reshape(rn, 1)}
+        return batch, imgs_info['poses'], rn, h, w
+
+    @staticmethod
+    def _construct_nerf_ray_batch(imgs_info, device=None, is_train=True):
+        """NeRF-synthetic data (renderer_zerothick.py:222-254): ONE intrinsic matrix (Ks[0]), d = R [ (i - cx) / fx, -(j - cy) / fy,
+        -1 ], o = camera centre, world space; masks for the training set.  Vectorised over the images and built on `device`.
+        -> (ray_batch {'rgbs','idxs','rays_o','rays_d'[,'masks']}, poses, n_rays, h, w)."""
+        imgs = imgs_info['imgs']
+        device = imgs.device if device is None else torch.device(device)
+        imn, _, h, w = imgs.shape
+        j, i = torch.meshgrid(torch.linspace(0, h - 1, h, device=device), torch.linspace(0, w - 1, w, device=device), indexing='ij')
+        K = imgs_info['Ks'][0].to(device)
+        dirs = torch.stack([(i - K[0][2]) / K[0][0], -(j - K[1][2]) / K[1][1], -torch.ones_like(i)], -1)       # h, w, 3
+        poses = imgs_info['poses']
+        P = poses.to(device).float()
+        # rays_d[n, p, a] = sum_b dirs[p, b] * R_n[a, b]  (the reference's per-image sum(dirs[..., None, :] * R, -1))
+        rays_d = torch.sum(dirs.reshape(1, h * w, 1, 3) * P[:, None, :3, :3], -1)
+        rays_o = P[:, None, :3, 3].expand(imn, h * w, 3)
+        rn = imn * h * w
+        batch = {'rgbs': imgs.to(device).permute(0, 2, 3, 1).reshape(rn, 3).float(),
+                 'idxs': torch.arange(imn, dtype=torch.int64, device=device)[:, None, None].repeat(1, h * w, 1).reshape(rn, 1),
+                 'rays_o': rays_o.reshape(rn, 3).float().contiguous(), 'rays_d': rays_d.reshape(rn, 3).float().contiguous()}
+        if is_train:
+            batch['masks'] = imgs_info['masks'].to(device).reshape(rn).float()
+        return batch, poses, rn, h, w
+
+    def set_ray_store(self, train_imgs_info, test_imgs_info=None, device=None):
+        """The second half of the reference's _init_dataset (renderer_zerothick.py:173-190) for a caller that has loaded the
+        images itself: `imgs_info` = {'imgs' [n,3,h,w] in [0,1], 'Ks' [n,3,3], 'poses' [n,3,4] (world -> camera for real captures,
+        camera -> world for NeRF-synthetic data, as in the reference), 'masks' [n,1,h,w] (NeRF-synthetic only)} as numpy arrays or
+        tensors.  The ray store is built ON the module's device (or `device`) and stays there: train_step slices it, no per-step
+        host -> device copy.  test_imgs_info (optional; may carry 'depths' [n,h,w]) serves test_step."""
+        dev = torch.device(device) if device is not None else next(self.parameters()).device
+        as_t = lambda info: {k: (torch.from_numpy(np.ascontiguousarray(v)) if isinstance(v, np.ndarray) else v).to(dev)
+                             for k, v in info.items()}
+        info = as_t(train_imgs_info)
+        build = self._construct_nerf_ray_batch if self.is_nerf else self._construct_ray_batch
+        self.train_batch, poses, self.tbn, _, _ = build(info, dev)
+        self.train_poses = poses.float().to(dev)
+        self.train_num = int(info['imgs'].shape[0])
+        self.test_imgs_info = as_t(test_imgs_info) if test_imgs_info is not None else None
+        self._batch_dev = dev
+        self._shuffle_train_batch()
 
     def _shuffle_train_batch(self):
         self.train_batch_i = 0
@@ -312,6 +376,34 @@ class NeROShapeRenderer(nn.Module):
         b = 2.0 * torch.sum(rays_o * rays_d, dim=-1, keepdim=True)
         mid = 0.5 * (-b) / a
         return torch.clamp(mid - 1.0, min=1e-3), mid + 1.0
+
+    def get_human_coordinate_poses(self, poses):
+        """renderer_zerothick.py:329-345 / renderer.py:329-345 (only consumed by human_light, which is off in every config)."""
+        pn = poses.shape[0]
+        cam_cen = (-poses[:, :, :3].permute(0, 2, 1) @ poses[:, :, 3:])[..., 0]
+        if not self.cfg['fixed_camera']:
+            cam_cen = cam_cen.clone()
+            cam_cen[..., 2] = 0
+        Y = torch.zeros(pn, 3, device=poses.device)
+        Y[:, 2] = -1.0
+        Z = poses[:, 2, :3].clone()
+        Z[:, 2] = 0
+        Z = F.normalize(Z, dim=-1)
+        X = torch.cross(Y, Z, dim=-1)
+        R = torch.stack([X, Y, Z], 1)
+        t = -R @ cam_cen[:, :, None]
+        return torch.cat([R, t], -1)
+
+    def _process_ray_batch(self, ray_batch, poses):
+        """Real-capture rays from camera poses: o = -R^T t, d = normalize(R^T dirs), near/far from the unit sphere
+        (renderer_zerothick.py:347-361 / renderer.py:347-361)."""
+        rays_d = ray_batch['dirs']
+        idxs = ray_batch['idxs'][..., 0]
+        rays_o = (poses[:, :, :3].permute(0, 2, 1) @ -poses[:, :, 3:])[idxs, :, 0]
+        rays_d = (poses[idxs, :, :3].permute(0, 2, 1) @ rays_d.unsqueeze(-1))[..., 0]
+        rays_d = F.normalize(rays_d, dim=-1)
+        near, far = self.near_far_from_sphere(rays_o, rays_d)
+        return rays_o, rays_d, near, far, self.get_human_coordinate_poses(poses)[idxs]
 
     def _process_nerf_ray_batch(self, ray_batch, poses=None):
         rays_d = F.normalize(ray_batch['rays_d'], dim=-1)
@@ -475,46 +567,77 @@ class NeROShapeRenderer(nn.Module):
         return self.train_step(step)
 
     def test_step(self, index, step):
-        """Full-image validation render of camera `index` (renderer_zerothick.py:397-445) for the ray-pool datasets of this
-        build: every pixel of the (down-sampled) synthetic camera, chunks of cfg['test_ray_num'] rays, no jitter, cos_anneal
-        0, is_train=False; same output keys and image shapes as the reference (gt_depth / gt_mask are empty scenes' zeros:
-        a synthetic pool has no depth maps)."""
-        if not hasattr(self, 'train_batch'):
-            raise RuntimeError("test_step needs the module's ray store: construct with training=True")
+        """Full-image validation render of camera `index` (renderer_zerothick.py:397-445): chunks of cfg['test_ray_num'] rays, no
+        jitter, cos_anneal 0, is_train=False; same output keys and image shapes as the reference.  The rays come from the
+        test images handed to set_ray_store (their 'depths' / 'masks' give gt_depth / gt_mask when present) or, for the synthetic
+        pool, from every pixel of the (down-sampled) synthetic camera (no depth maps: zeros)."""
+        if getattr(self, 'train_batch', None) is None:
+            raise RuntimeError("test_step needs the module's ray store: construct with training=True (and, for an image "
+                               "database, hand the loaded images over with set_ray_store)")
         from .validation import render_eval
-        hw = int(self.cfg.get('synthetic_hw', 800))
-        ratio = float(self.cfg['downsample_ratio']) if self.cfg['test_downsample_ratio'] else 1.0
-        rays, h, w = synthetic.make_image_rays(index, hw=hw, seed=int(self.cfg.get('ray_seed', 6033)), downsample=ratio)
         dev = self.deviation_network.variance.device
-        batch = {k: torch.from_numpy(v).to(dev) for k, v in rays.items()}
-        outputs = render_eval(self, batch, step)
+        if self.test_imgs_info is not None:
+            info = {k: v[index:index + 1] for k, v in self.test_imgs_info.items()}
+            if self.cfg['test_downsample_ratio'] and float(self.cfg['downsample_ratio']) != 1.0:
+                raise NotImplementedError("test_downsample_ratio with an image store: down-sample the test images before "
+                                          "set_ray_store (imgs_info_downsample resizes with OpenCV, outside this build)")
+            if self.is_nerf:
+                batch, poses, rn, h, w = self._construct_nerf_ray_batch(info, dev, is_train=False)
+            else:
+                batch, poses, rn, h, w = self._construct_ray_batch(info, dev)
+                ro, rd, _, _, _ = self._process_ray_batch(batch, poses.float().to(dev))
+                batch = {'rays_o': ro, 'rays_d': rd, 'rgbs': batch['rgbs']}
+            batch = {k: v for k, v in batch.items() if k in ('rays_o', 'rays_d', 'rgbs')}
+            outputs = render_eval(self, batch, step)
+            depth = info['depths'][0].reshape(h, w, 1).float().cpu() if 'depths' in info else torch.zeros(h, w, 1)
+            mask = (info['masks'][0].reshape(h, w, 1) > 0).to(torch.int32).cpu() if 'masks' in info else torch.zeros(h, w, 1, dtype=torch.int32)
+        else:
+            hw = int(self.cfg.get('synthetic_hw', 800))
+            ratio = float(self.cfg['downsample_ratio']) if self.cfg['test_downsample_ratio'] else 1.0
+            rays, h, w = synthetic.make_image_rays(index, hw=hw, seed=int(self.cfg.get('ray_seed', 6033)), downsample=ratio)
+            batch = {k: torch.from_numpy(v).to(dev) for k, v in rays.items()}
+            outputs = render_eval(self, batch, step)
+            depth, mask = torch.zeros(h, w, 1), torch.zeros(h, w, 1, dtype=torch.int32)
         outputs['gt_rgb'] = batch['rgbs'].reshape(h, w, 3)
         outputs['ray_rgb'] = outputs['ray_rgb'].reshape(h, w, 3)
-        outputs['gt_depth'] = torch.zeros(h, w, 1)
-        outputs['gt_mask'] = torch.zeros(h, w, 1, dtype=torch.int32)
+        outputs['gt_depth'] = depth
+        outputs['gt_mask'] = mask
         self.zero_grad()
         return outputs
 
     def train_step(self, step):
+        """renderer_zerothick.py:447-466 on the module's device-resident ray store."""
+        if getattr(self, 'train_batch', None) is None:
+            raise RuntimeError(f"database '{self.cfg['database_name']}': no ray store yet -- loading image databases is outside this "
+                               "build; hand the loaded images over with set_ray_store(train_imgs_info[, test_imgs_info]), or use "
+                               "'synthetic/<n_rays>', or call train_step_rays() with your own rays")
         rn = self.cfg['train_ray_num']
         dev = self.deviation_network.variance.device
         if self._batch_dev != dev:
             self.train_batch = {k: v.to(dev) for k, v in self.train_batch.items()}
+            if self.train_poses is not None:
+                self.train_poses = self.train_poses.to(dev)
             self._batch_dev = dev
             self._shuffle_train_batch()
         batch = {k: v[self.train_batch_i:self.train_batch_i + rn] for k, v in self.train_batch.items()}
         self.train_batch_i += rn
         if self.train_batch_i + rn >= self.tbn:
             self._shuffle_train_batch()
+        if 'dirs' in batch:          # real captures: world-space rays from the camera poses (renderer_zerothick.py:347-361)
+            return self.train_step_rays(batch, step, poses=self.train_poses)
         return self.train_step_rays(batch, step)
 
-    def train_step_rays(self, batch, step, rand=None, fused=False):
-        """One training forward on an explicit ray batch {'rays_o','rays_d','rgbs'} (renderer_zerothick.py:447-466).
+    def train_step_rays(self, batch, step, rand=None, fused=False, poses=None):
+        """One training forward on an explicit ray batch {'rays_o','rays_d','rgbs'} -- or {'dirs','idxs','rgbs'} with the
+        camera `poses` of a real capture -- (renderer_zerothick.py:447-466).
         fused=True leaves the colour finishing and the RGB loss to loss.fused_stage1_loss (HIP loss kernels)."""
-        rays_o, rays_d, near, far, poses = self._process_nerf_ray_batch(batch)
-        if not self.is_nerf:    # real captures: near / far bracket the unit sphere (renderer_zerothick.py:320-327, :357)
-            near, far = self.near_far_from_sphere(rays_o, rays_d)
-        outputs = self.render(rays_o, rays_d, near, far, poses, -1, self.get_anneal_val(step), is_train=True, step=step,
+        if 'dirs' in batch:
+            rays_o, rays_d, near, far, hp = self._process_ray_batch(batch, poses)
+        else:
+            rays_o, rays_d, near, far, hp = self._process_nerf_ray_batch(batch)
+            if not self.is_nerf:    # real captures: near / far bracket the unit sphere (renderer_zerothick.py:320-327, :357)
+                near, far = self.near_far_from_sphere(rays_o, rays_d)
+        outputs = self.render(rays_o, rays_d, near, far, hp, -1, self.get_anneal_val(step), is_train=True, step=step,
                               is_nerf=self.is_nerf, rand=rand, fused=fused)
         if not fused:
             outputs['loss_rgb'] = self.compute_rgb_loss(outputs['ray_rgb'], batch['rgbs'])

@@ -123,6 +123,10 @@ class Stage2Renderer(nn.Module):
     # ---- data: the ray-pool store of the stage-1 module (`database_name: synthetic/<n_rays>`; image databases are out of scope) ----
     _init_dataset = NeROShapeRenderer._init_dataset
     _shuffle_train_batch = NeROShapeRenderer._shuffle_train_batch
+    # an image database loaded by the caller: the same device-resident ray store as stage 1 (renderer.set_ray_store)
+    _construct_ray_batch = NeROShapeRenderer._construct_ray_batch
+    _construct_nerf_ray_batch = NeROShapeRenderer._construct_nerf_ray_batch
+    set_ray_store = NeROShapeRenderer.set_ray_store
 
     # ---- construction helpers ---------------------------------------------------------------------
     def _load_stage1_cfg(self):
@@ -450,16 +454,24 @@ class Stage2Renderer(nn.Module):
         """renderer_zerothick.py:1259-1275 on the module's device-resident ray store."""
         rn = self.cfg['train_ray_num']
         dev = self.IORs.device
-        if not hasattr(self, 'train_batch'):
-            raise RuntimeError("train_step needs the module's ray store: construct with training=True")
+        if getattr(self, 'train_batch', None) is None:
+            raise RuntimeError("train_step needs the module's ray store: construct with training=True (and, for an image database, "
+                               "hand the loaded images over with set_ray_store)")
         if self._batch_dev != dev:
             self.train_batch = {k: v.to(dev) for k, v in self.train_batch.items()}
+            if getattr(self, 'train_poses', None) is not None:
+                self.train_poses = self.train_poses.to(dev)
             self._batch_dev = dev
             self._shuffle_train_batch()
         batch = {k: v[self.train_batch_i:self.train_batch_i + rn] for k, v in self.train_batch.items()}
         self.train_batch_i += rn
         if self.train_batch_i + rn >= self.tbn:
             self._shuffle_train_batch()
+        if 'dirs' in batch:         # real captures: world-space rays from the camera poses (renderer_zerothick.py:347-361)
+            poses, idxs = self.train_poses, batch['idxs'][..., 0]
+            rays_o = (poses[:, :, :3].permute(0, 2, 1) @ -poses[:, :, 3:])[idxs, :, 0]
+            rays_d = (poses[idxs, :, :3].permute(0, 2, 1) @ batch['dirs'].unsqueeze(-1))[..., 0]
+            batch = {'rays_o': rays_o, 'rays_d': rays_d, 'rgbs': batch['rgbs']}
         return self.train_step_rays(batch, step)
 
     _EVAL_KEYS = ('ray_rgb', 'gradient_error', 'normal', 'tir_mask', 'specular_light', 'specular_color', 'specular_ref')

@@ -68,3 +68,26 @@ def check_ray_batch_against_reference_fixture(device):
     np.testing.assert_allclose(far.cpu().numpy(), g['far'], rtol=1e-6, atol=1e-6)
     np.testing.assert_allclose(hpr.cpu().numpy(), g['human_poses_rays'], rtol=1e-6, atol=1e-6)
     assert float(near.min()) >= 1e-3 and bool((far - near <= 2.0 + 1e-6).all())
+
+
+def check_ray_store_against_reference_fixture(device):
+    """SURVEY 8(a) rows a1/a2, first half: the ray batches the reference builds from an already-loaded image set
+    (renderer_zerothick.py:199-254) -- tests/golden/ray_store.npz, written by the reference's own _construct_nerf_ray_batch /
+    _construct_ray_batch (oracle/gen_golden_r3.py) -- against the device-side construction of nu_nerf_amd/renderer.py."""
+    from nu_nerf_amd.renderer import NeROShapeRenderer
+    g = golden("ray_store.npz")
+    dev = torch.device(device)
+    info = {k[3:]: torch.from_numpy(g[k]).to(dev) for k in g if k.startswith('in_')}
+    nb, poses, rn, h, w = NeROShapeRenderer._construct_nerf_ray_batch(info, dev)
+    assert (rn, h, w) == (90, 6, 5) and sorted(nb) == ['idxs', 'masks', 'rays_d', 'rays_o', 'rgbs']
+    for k, v in nb.items():
+        assert v.device.type == dev.type and v.dtype == torch.from_numpy(g['nerf_' + k]).dtype, k
+        np.testing.assert_allclose(v.cpu().numpy(), g['nerf_' + k], rtol=1e-6, atol=1e-6, err_msg=k)
+    ev, _, _, _, _ = NeROShapeRenderer._construct_nerf_ray_batch({k: v for k, v in info.items() if k != 'masks'}, dev, is_train=False)
+    assert sorted(ev) == ['idxs', 'rays_d', 'rays_o', 'rgbs']
+    rb, poses2, rn2, h2, w2 = NeROShapeRenderer._construct_ray_batch(info, dev)
+    assert (rn2, h2, w2) == (90, 6, 5) and sorted(rb) == ['dirs', 'idxs', 'rgbs']
+    for k, v in rb.items():
+        np.testing.assert_allclose(v.cpu().numpy(), g['real_' + k], rtol=2e-6, atol=1e-6, err_msg=k)
+    np.testing.assert_array_equal(poses2.cpu().numpy(), g['real_poses'])
+    return info

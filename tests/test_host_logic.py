@@ -227,6 +227,30 @@ def test_process_ray_batch_and_human_poses_vs_reference_fixture():
     check_ray_batch_against_reference_fixture('cpu')
 
 
+def test_ray_store_construction_vs_reference_fixture_and_unmodified_yaml_names():
+    """A YAML's own `database_name` (nerf/spherepot) no longer stops the module from being constructed for training: the
+    image files are the caller's to load, `set_ray_store(imgs_info)` turns them into the ray store exactly as the reference's
+    _init_dataset does after loading (fixture from the reference's own methods)."""
+    from helpers import check_ray_store_against_reference_fixture
+    from nu_nerf_amd.renderer import name2renderer
+    info = check_ray_store_against_reference_fixture('cpu')
+    net = name2renderer['shape']({'database_name': 'nerf/spherepot', 'is_nerf': True, 'train_ray_num': 16}, training=True)
+    with pytest.raises(RuntimeError, match='set_ray_store'):
+        net.train_step(0)
+    net.set_ray_store(info, test_imgs_info=info)
+    assert net.tbn == 90 and net.train_num == 3 and net.train_batch['rays_o'].shape == (90, 3)
+    # the store is a permutation of the fixture's rays: every (origin, direction, colour) row is one of the reference's
+    from helpers import golden
+    g = golden("ray_store.npz")
+    ref = np.concatenate([g['nerf_rays_o'], g['nerf_rays_d'], g['nerf_rgbs']], 1)
+    got = torch.cat([net.train_batch[k] for k in ('rays_o', 'rays_d', 'rgbs')], 1).numpy()
+    assert np.allclose(np.sort(got.view([('', got.dtype)] * 9), axis=0).view(got.dtype), np.sort(ref.view([('', ref.dtype)] * 9), axis=0).view(ref.dtype),
+                       rtol=1e-6, atol=1e-6)
+    real = name2renderer['shape']({'database_name': 'real/bear', 'is_nerf': False, 'train_ray_num': 16}, training=True)
+    real.set_ray_store(info)
+    assert sorted(real.train_batch) == ['dirs', 'idxs', 'rgbs'] and real.train_poses.shape == (3, 3, 4)
+
+
 def test_forward_routes_eval_requests_to_test_step_cpu_side():
     """forward({'index','eval','step'}) is the ValidationEvaluator's call (train/train_valid.py:25-29), first made at step 0
     (trainer_zero.py:174): it must reach test_step, not raise.  (The render itself needs the GPU: tests/test_eval_gpu.py.)"""

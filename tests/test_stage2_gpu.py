@@ -63,6 +63,69 @@ def test_stage2_train_step_vs_reference_golden(gpu):
             assert rel_err(named[k[6:]].grad.cpu(), g[k]) < 2e-2, k
 
 
+def test_stage2_train_step_at_the_reference_sample_placement(gpu, monkeypatch):
+    """Second pass of the golden step with the sample placement of the REFERENCE run: the inner segment's 128 fractions are
+    recovered from the fixture's `path1`, the far-ray importance nodes of the rays that leave the scene from `path0` / `path2`
+    (both placements are no-gradient inverse-CDF draws, which amplify last-bit differences of the densities they are drawn from:
+    tests/test_oracle_golden.py).  Everything downstream of the placement then has to agree with the reference at fp32 rounding:
+    loss terms 1e-5, every gradient norm 1e-3 (the first pass, with the build's own samplers in the loop, allows 5e-4 / 5e-3)."""
+    import torch.nn.functional as F
+    from nu_nerf_amd.loss import name2loss, total_loss
+    from nu_nerf_amd import stage2_ops
+    g = golden("stage2_step6000_r24.npz")
+    net, cfg = build(gpu)
+    step = int(g['step'])
+    batch = {k: torch.from_numpy(g[k]).to(gpu) for k in ('rays_o', 'rays_d', 'rgbs')}
+    P = [torch.from_numpy(g['path%d' % i]).to(gpu) for i in range(3)]
+
+    def reference_inner(n2, start, dirs, end):
+        num = torch.linalg.norm(P[1] - P[1][:, :1], dim=-1)
+        return num / num[:, -1:]
+
+    calls = []
+
+    def reference_far(eng, start, dirs):
+        # called for segment 0 (camera rays that miss the mesh) and segment 2 (rays that have left the object): the rows are
+        # matched to the fixture's paths by direction, the node distances are read off the fixture's nodes
+        Pb = P[0] if not calls else P[2]
+        calls.append(start.shape[0])
+        if start.shape[0] == 0:
+            return torch.empty(0, 256, device=start.device)
+        gd = F.normalize(Pb[:, -1] - Pb[:, 0], dim=-1)
+        cos, idx = (F.normalize(dirs, dim=-1) @ gd.T).max(1)
+        assert float(cos.min()) > 1.0 - 1e-5
+        # node = start + dirs * z (refracted directions are not unit vectors in the reference: |d| = 0.9999...)
+        return ((Pb[idx] - start[:, None, :]) * dirs[:, None, :]).sum(-1) / (dirs * dirs).sum(-1, keepdim=True)
+
+    net._upsample_inner = reference_inner
+    monkeypatch.setattr(stage2_ops, 'far_importance_nodes', reference_far)
+    out = net.train_step_rays(batch, step)
+    total, log = total_loss(out, [name2loss[n](cfg) for n in ('eikonal', 'std', 'nerf_render')], step)
+    total.backward()
+    assert calls == [int((~g['conv0'].reshape(-1)).sum()), g['path2'].shape[0]]    # the camera rays that miss; every ray that left the object
+    for i in range(3):
+        ref = g['path%d' % i]
+        got = out['_paths'][i].detach().cpu().numpy()
+        assert np.all(np.abs(got - ref) <= 3e-6 * np.linalg.norm(ref, axis=-1, keepdims=True) + 2e-5), i
+    np.testing.assert_allclose(out['ray_rgb'].detach().cpu().numpy(), g['out_ray_rgb'], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(out['gradient_error'].detach().cpu().numpy(), g['out_gradient_error'], rtol=2e-3, atol=1e-6)
+    for k in g:
+        if k.startswith('term_'):
+            np.testing.assert_allclose(float(torch.mean(log[k[5:]]).detach()), float(g[k]), rtol=1e-5, err_msg=k)
+    np.testing.assert_allclose(float(total.detach()), float(g['total_loss']), rtol=1e-5)
+    named = dict(net.named_parameters())
+    worst = 0.0
+    for n, ref_norm in zip([str(n) for n in g['grad_names']], g['grad_norms']):
+        got = float(named[n].grad.double().norm())
+        if ref_norm > 1e-6:
+            worst = max(worst, abs(got - ref_norm) / ref_norm)
+        assert abs(got - ref_norm) <= 1e-3 * ref_norm + 2e-9, (n, got, ref_norm)
+    print("worst gradient-norm deviation at the reference's sample placement", worst)
+    for k in g:
+        if k.startswith('grad__'):
+            assert rel_err(named[k[6:]].grad.cpu(), g[k]) < 5e-3, (k, rel_err(named[k[6:]].grad.cpu(), g[k]))
+
+
 def test_stage2_validation_render_vs_reference_golden(gpu):
     """render(..., is_train=False) -- test_step's per-chunk call (renderer_zerothick.py:1238-1240) -- against the reference's
     outputs on the fixture's rays: RGB, TIR mask and the validation images of the first surface; then the trainer protocol
@@ -85,3 +148,62 @@ def test_stage2_validation_render_vs_reference_golden(gpu):
     with torch.no_grad():
         ev = net2({'index': 1, 'eval': True, 'step': 0})
     assert ev['ray_rgb'].shape == (24, 24, 3) and ev['normal'].shape == (576, 3) and torch.isfinite(ev['ray_rgb']).all()
+
+
+@pytest.mark.parametrize("thick", [False, True])
+def test_stage2_full_size_config3_properties(gpu, thick):
+    """BASELINE.json configs[2] at its full size -- 4096 rays against a 20 480-face mesh, both stage-2 models: thousands of rays
+    per ragged subset (hit / refracting / inner-sample sets, capacity classes, the two-stream fork / join, index_put with large
+    index sets), which the 24-ray fixtures cannot exercise.  Size-independent properties: rays are independent units, so a
+    100-ray sub-batch renders BIT-identically alone and inside the batch (colour and TIR mask); the loss and every gradient of
+    the full batch are finite; the parameters that get gradients are the same as in the small golden step."""
+    from nu_nerf_amd.params import init_stage1_params, init_stage2_params
+    from nu_nerf_amd.lbvh import icosphere
+    from nu_nerf_amd.synthetic import make_rays, make_object_rays
+    from nu_nerf_amd.loss import name2loss, total_loss
+    s1 = init_stage1_params(6033)
+    cfg = {'name': 's2', 'network': 'stage2', 'is_nerf': True, 'shader_config': {'sphere_direction': False, 'human_light': False},
+           'eikonal_weight': 0.02, 'freeze_inv_s_step': 5000,
+           'stage1_cfg': {'is_nerf': True, 'apply_occ_loss': True, 'occ_loss_step': 15000, 'freeze_inv_s_step': 15000},
+           'stage1_mesh_arrays': icosphere(5, 0.5)}
+    if thick:
+        from nu_nerf_amd.stage2_thick import Stage2Renderer as ThickRenderer
+        from nu_nerf_amd.params import init_stage2_thick_own_params
+        cfg.update({'get_mask': False, 'is_nerf': False})
+        cfg['stage1_cfg'] = dict(cfg['stage1_cfg'], get_mask=False, is_nerf=False)
+        net = ThickRenderer(cfg, training=False)
+        net.load_param_dict(init_stage2_thick_own_params(7044, net.color_network_inner.cfg))
+        net.load_param_dict({'stage1_network.' + k: v for k, v in s1.items()})
+    else:
+        from nu_nerf_amd.stage2 import Stage2Renderer
+        p2 = init_stage2_params(6033, 7044, {'sphere_direction': False})
+        for k, v in s1.items():
+            p2['stage1_network.' + k] = v
+            p2['color_network.stage1_network.' + k] = v
+        net = Stage2Renderer(cfg, training=False)
+        net.load_param_dict(p2)
+    net = net.to(gpu)
+    assert int(net.nets()[0] is not None) and net.scene.bvh.n_faces == 20480
+    # half Spherepot-shaped camera rays (most miss the object), half aimed at it (all three bounces)
+    cam, obj = make_rays(2048, seed=311), make_object_rays(2048, seed=312)
+    batch = {k: torch.from_numpy(np.concatenate([cam[k], obj[k]], 0)).to(gpu) for k in ('rays_o', 'rays_d', 'rgbs')}
+    step = 6000
+    out = net.train_step_rays(batch, step)
+    total, _ = total_loss(out, [name2loss[n](cfg) for n in ('eikonal', 'std', 'nerf_render')], step)
+    total.backward()
+    assert out['ray_rgb'].shape == (4096, 3) and bool(torch.isfinite(out['ray_rgb']).all()) and np.isfinite(float(total.detach()))
+    entered = out['_paths'][1].shape[0]
+    assert entered > 1000, entered                                    # thousands of rays in the ragged subsets
+    with_grad = [n for n, p in net.named_parameters() if p.grad is not None and float(p.grad.abs().sum()) > 0.0]
+    assert len(with_grad) > 200
+    for n, p in net.named_parameters():
+        if p.grad is not None:
+            assert bool(torch.isfinite(p.grad).all()), n
+    sub = torch.arange(0, 4096, 41, device=gpu)[:100]
+    assert sub.numel() == 100
+    with torch.no_grad():
+        whole = net.train_step_rays(batch, step)
+        alone = net.train_step_rays({k: v[sub].contiguous() for k, v in batch.items()}, step)
+    assert torch.equal(whole['ray_rgb'], out['ray_rgb'].detach())     # run-to-run reproducible
+    assert torch.equal(alone['tir_mask'], whole['tir_mask'][sub])
+    assert torch.equal(alone['ray_rgb'], whole['ray_rgb'][sub]), float((alone['ray_rgb'] - whole['ray_rgb'][sub]).abs().max())
