@@ -10,7 +10,8 @@ import os
 import torch  # noqa: F401  (must precede CDLL: see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libnunerf.so")
+# NU_NERF_LIB: another build of the same C ABI (development A/B runs of two kernel generations in one call); default: the in-tree library
+_LIB_PATH = os.environ.get("NU_NERF_LIB") or os.path.join(_HERE, "libnunerf.so")
 _lib = None
 
 c_int = ctypes.c_int

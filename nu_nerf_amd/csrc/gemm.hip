@@ -49,6 +49,7 @@ __device__ unsigned nu_lab_hwid[1024][2];
 __device__ int nu_lab_skip_epi;      // 1: store nothing in the epilogue (pure main loop + tile switch)
 static int nu_lab_grid = 0;          // persistent grid size override (0: default)
 static int nu_lab_v1 = 0;            // 1: first-generation fp32 NT kernel
+static int nu_lab_small = -1;        // 64-row tiles: -1 library rule, 0 never, 1 always (gen 2)
 __device__ int nu_lab_stamps;        // 1: wave 0 of block 0 stamps the stages of its third tile (perturbs that tile)
 __device__ long long nu_lab_stage[8][8];
 __device__ int nu_lab_small_a;       // 1: every tile reads A from an 8 MB window (memory-latency ablation, gen 2)
@@ -134,10 +135,13 @@ static __device__ inline unsigned long long* nt_mask_words(const NtEpiArgs<EPI>&
 }
 
 // NBH: row groups whose auxiliary loads are in flight together in the fast path (register budget of the caller)
-template <int EPI, int NBH, bool H16 = false>
-static __device__ __forceinline__ void nt_epilogue(const NuGemmNT& g, const NtEpiArgs<EPI>& ea, f32x16 (&acc)[2][2], float* scr,
+// TMN / tm0: the wave holds TMN 32-row blocks of the 64 x 64 slab `wid` of the 128 x 128 tile at (m0, n0), starting at block tm0
+// (2 / 0: the whole slab -- the 128-row-tile kernels; 1 / 0 or 1: one block -- the 64-row-tile kernel, where the two waves that
+// share a slab's sign-bit words belong to different workgroups).
+template <int EPI, int NBH, bool H16 = false, int TMN = 2>
+static __device__ __forceinline__ void nt_epilogue(const NuGemmNT& g, const NtEpiArgs<EPI>& ea, f32x16 (&acc)[TMN][2], float* scr,
                                                    int m0, int n0, unsigned long long* mwave, unsigned mlo, unsigned mhi,
-                                                   int lane, int wid, bool lab_skip) {
+                                                   int lane, int wid, bool lab_skip, int tm0 = 0) {
     typedef NtEpiArgs<EPI> E;
     constexpr bool kMaskW = E::kMaskW, kMaskR = E::kMaskR, kNeedH = E::kNeedH, kNeedD = E::kNeedD, kNeedAdd = E::kNeedAdd, kBias = E::kBias;
     float* const C = ea.C; float* const C2 = ea.C2;
@@ -176,14 +180,15 @@ static __device__ __forceinline__ void nt_epilogue(const NuGemmNT& g, const NtEp
     const unsigned oH = (lrow * (unsigned)g.ldh + (unsigned)colq) * (unsigned)ex, oD = (lrow * (unsigned)g.ldd + (unsigned)colq) * (unsigned)ex;
     const unsigned oA = (lrow * (unsigned)g.ldadd + (unsigned)colq) * (unsigned)ex;
 #pragma unroll
-    for (int tm = 0; tm < 2; ++tm) {
+    for (int tt = 0; tt < TMN; ++tt) {
+        const int tm = tm0 + tt;
 #pragma unroll
         for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                scr[((r & 3) + 8 * (r >> 2) + 4 * lh) * EPI_LDS + tn * 32 + li] = acc[tm][tn][r];
+                scr[((r & 3) + 8 * (r >> 2) + 4 * lh) * EPI_LDS + tn * 32 + li] = acc[tt][tn][r];
         if (lab_skip) {
-            if (acc[tm][0][0] == 123.456f) C[0] = acc[tm][1][3];      // keeps the accumulators live
+            if (acc[tt][0][0] == 123.456f) C[0] = acc[tt][1][3];      // keeps the accumulators live
         } else if (slab_full) {
             // wave-uniform fast path (every interior tile): straight-line code, no per-lane guards; the auxiliary loads of
             // four row groups are in flight together; the activation math is branch-free (nu_common.h)
@@ -301,7 +306,8 @@ static __device__ __forceinline__ void nt_epilogue(const NuGemmNT& g, const NtEp
             }
         }
     }
-    if (kMaskW && mwave) mwave[lane] = ((unsigned long long)whi << 32) | wlo;
+    // (a wave that holds one block of a slab owns the words of that block only: lanes 32 tm0 .. 32 tm0 + 31)
+    if (kMaskW && mwave && (TMN == 2 || (lane >> 5) == tm0)) mwave[lane] = ((unsigned long long)whi << 32) | wlo;
 }
 
 // One LDS buffer (36.9 KB per workgroup) -> 3 workgroups per CU.  The next k-chunk travels global -> registers
@@ -560,8 +566,12 @@ __global__ __launch_bounds__(256, PREC == 2 ? 2 : NT_WPC) void gemm_nt_kernel(Nu
 // The epilogue (shared with the first generation) uses the stage that was just consumed as its scratch.
 // ------------------------------------------------------------------------------------------------
 #define NT2_STAGE (2 * TBM * NT_LDS)   // floats per stage: [A 128 x 36 | B 128 x 36]
-template <int EPI>
+// TMN = 2: 128 x 128 tiles (wave tile 64 x 64).  TMN = 1: 64 x 128 tiles (4 waves as 2 x 2, wave tile 32 x 64) for launches whose
+// 128-row tiles would leave CUs empty (point sets of a few thousand rows: the reference's default batch of 512 rays, the stage-2
+// segments): twice the tiles, half the work each; same stages, same chunk flow, the A pieces 2-3 and the a1 fragments drop out.
+template <int EPI, int TMN>
 __global__ __launch_bounds__(256, 2) void gemm_nt2_kernel(NuGemmNT g) {
+    constexpr int BM = 64 * TMN;                            // tile rows
     __shared__ __attribute__((aligned(16))) float smem[2 * NT2_STAGE];
 
     const int tid = threadIdx.x;
@@ -570,7 +580,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt2_kernel(NuGemmNT g) {
     const int wr = wid >> 1, wc = wid & 1;
     const int z = blockIdx.z;
     const int ntn = (g.N + TBN - 1) / TBN;
-    const int mtiles = (g.M + TBM - 1) / TBM;
+    const int mtiles = (g.M + BM - 1) / BM;
     const int nslots = ((mtiles + 7) / 8) * 8 * ntn;       // slot order: see gemm_nt_kernel
     const float* __restrict__ A = g.A + (long long)z * g.sA;
     const float* __restrict__ B = g.B + (long long)z * g.sB;
@@ -578,8 +588,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt2_kernel(NuGemmNT g) {
     const int r0 = tid >> 3;
     const int nk = g.K / TBK;
     const int li = lane & 31, lh = lane >> 5;
-    const int a_off = (wr * 64 + li) * NT_LDS + 4 * lh;
+    const int a_off = (wr * 32 * TMN + li) * NT_LDS + 4 * lh;
     const int b_off = TBM * NT_LDS + (wc * 64 + li) * NT_LDS + 4 * lh;
+    const int a0_off = a_off, a1_off = a_off + 32 * NT_LDS, b0_off = b_off, b1_off = b_off + 32 * NT_LDS;   // the four fragments
     const int w_off = r0 * NT_LDS + 4 * c4;                 // this thread's slot of a staged operand row group
 
     auto slot_tile = [&](int j, int& mt, int& nt) -> bool {
@@ -609,7 +620,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt2_kernel(NuGemmNT g) {
 #endif
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            int ra = mt_ * TBM + r0 + 32 * i;
+            int ra = mt_ * BM + r0 + 32 * (i < 2 * TMN ? i : 0);
             ra = ra < g.M ? ra : g.M - 1;
             ap[i] = A + (long long)ra * g.lda + 4 * c4;
             bp[i] = B + (long long)(nt_ * TBN + r0 + 32 * i) * g.ldb + 4 * c4;
@@ -623,7 +634,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt2_kernel(NuGemmNT g) {
     //   write_piece(st, i)   registers -> LDS stage st
     int ld_koff = 0;
     auto load_piece = [&](int i) {
-        ra4[i] = *reinterpret_cast<const f32x4*>(ap[i] + ld_koff);
+        if (i < 2 * TMN) ra4[i] = *reinterpret_cast<const f32x4*>(ap[i] + ld_koff);
         rb4[i] = *reinterpret_cast<const f32x4*>(bp[i] + ld_koff);
     };
     auto advance = [&]() {
@@ -638,14 +649,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nt2_kernel(NuGemmNT g) {
     };
     auto write_piece = [&](int st, int i) {
         float* s0 = &smem[st * NT2_STAGE];
-        *reinterpret_cast<f32x4*>(&s0[w_off + 32 * i * NT_LDS]) = ra4[i];
+        if (i < 2 * TMN) *reinterpret_cast<f32x4*>(&s0[w_off + 32 * i * NT_LDS]) = ra4[i];
         *reinterpret_cast<f32x4*>(&s0[TBM * NT_LDS + w_off + 32 * i * NT_LDS]) = rb4[i];
     };
     struct Frag { f32x4 a0, a1, b0, b1; };
     auto read_frag = [&](Frag& f, int st, int kk) {
         const float* s0 = &smem[st * NT2_STAGE];
         f.a0 = *reinterpret_cast<const f32x4*>(&s0[a_off + kk * 8]);
-        f.a1 = *reinterpret_cast<const f32x4*>(&s0[a_off + 32 * NT_LDS + kk * 8]);
+        if (TMN == 2) f.a1 = *reinterpret_cast<const f32x4*>(&s0[a_off + 32 * NT_LDS + kk * 8]);
         f.b0 = *reinterpret_cast<const f32x4*>(&s0[b_off + kk * 8]);
         f.b1 = *reinterpret_cast<const f32x4*>(&s0[b_off + 32 * NT_LDS + kk * 8]);
     };
@@ -656,6 +667,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt2_kernel(NuGemmNT g) {
 #ifdef NU_LAB
     int lab_tile = 0;
     const unsigned long long lab_c0 = clock64(), lab_w0 = wall_clock64();
+    if (tid == 0 && blockIdx.x < 1024) {
+        nu_lab_hwid[blockIdx.x][0] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);     // HW_ID
+        nu_lab_hwid[blockIdx.x][1] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20);    // XCC_ID
+    }
 #endif
     // ---- prologue: chunk 0 -> stage 0, chunk 1 -> registers, first fragments ----
     set_ptrs(mt, nt);
@@ -673,15 +688,18 @@ __global__ __launch_bounds__(256, 2) void gemm_nt2_kernel(NuGemmNT g) {
     int cur = 0;
 
     while (true) {
-        const int m0 = mt * TBM, n0 = nt * TBN;
-        unsigned long long* mwave = nt_mask_words<EPI>(ea, g, mt, nt, z, ntn, wid);
+        // the 128 x 128 tile this tile is (part of), the 64 x 64 slab of it this wave works in, and the wave's 32-row block there
+        const int mt128 = TMN == 2 ? mt : (mt >> 1);
+        const int slab = TMN == 2 ? wid : (((mt & 1) << 1) | wc), tm0 = TMN == 2 ? 0 : wr;
+        const int m0 = mt128 * TBM, n0 = nt * TBN;
+        unsigned long long* mwave = nt_mask_words<EPI>(ea, g, mt128, nt, z, ntn, slab);
         unsigned long long mword = 0;
         if (kMaskR && mwave) mword = mwave[lane];
         const unsigned mlo = (unsigned)mword, mhi = (unsigned)(mword >> 32);
 
-        f32x16 acc[2][2];
+        f32x16 acc[TMN][2];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < TMN; ++i)
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
@@ -689,60 +707,68 @@ __global__ __launch_bounds__(256, 2) void gemm_nt2_kernel(NuGemmNT g) {
 #ifdef NU_LAB
         if (tid == 0 && blockIdx.x < 1024 && lab_tile < NU_LAB_TILES) nu_lab_trace[blockIdx.x][lab_tile][0] = wall_clock64();
 #endif
-#define NT2_QUAD(F, e)                                                                                     \
-    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(F.a0[e], F.b0[e], acc[0][0], 0, 0, 0);                 \
-    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(F.a0[e], F.b1[e], acc[0][1], 0, 0, 0);                 \
-    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(F.a1[e], F.b0[e], acc[1][0], 0, 0, 0);                 \
-    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(F.a1[e], F.b1[e], acc[1][1], 0, 0, 0);                 \
-    __builtin_amdgcn_sched_barrier(0);
 #define NT2_PIN __builtin_amdgcn_sched_barrier(0);
+#define NT2_M(F, e, i, j) if constexpr (i < TMN) { acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(F.a##i[e], F.b##j[e], acc[i][j], 0, 0, 0); NT2_PIN }
 #ifdef NU_LAB
 #define NT2_STAMP(I) if (lab_stamp && kt < 8) { nu_lab_stage[kt][I] = clock64(); __builtin_amdgcn_sched_barrier(0); }
         const bool lab_stamp = nu_lab_stamps != 0 && tid == 0 && blockIdx.x == 0 && lab_tile == 2;
 #else
 #define NT2_STAMP(I)
 #endif
-        // One chunk = 4 k-groups of 16 MFMAs (4 quads).  Everything else sits between quads, pinned by sched_barrier(0):
-        //   k-group 0: fragment reads of k-group 1
-        //   k-group 1: fragment reads of k-group 2; the NEXT chunk goes registers -> other LDS stage (8 ds_write_b128)
-        //   k-group 2: fragment reads of k-group 3; the chunk AFTER that goes global -> registers (8 global_load_dwordx4)
-        //   barrier (the other stage is complete, this one fully consumed); first fragments of the next chunk
-        //   k-group 3: under which those fragments land
+        // One chunk = 4 k-groups of 16 MFMAs.  An in-order wave issues nothing while one of its own instructions issues, and the
+        // matrix pipe runs dry when that takes longer than the MFMA in front of it executes (64 cycles): a ds_write_b128 costs
+        // ~43 issue cycles, a global_load_dwordx4 ~34, a ds_read_b128 ~20 -- ONE of them hides behind an MFMA, two in a row do not
+        // (measured with the phase stamps: 4 reads + 8 writes in two gaps cost a lone workgroup 200 of a k-group's 1024 cycles).
+        // So every memory instruction of the chunk sits ALONE between two MFMAs, pinned by sched_barrier(0):
+        //   k-group 0: the 4 fragment reads of k-group 1
+        //   k-group 1: the NEXT chunk goes registers -> other LDS stage (8 ds_write_b128); the 4 fragment reads of k-group 2
+        //   k-group 2: the chunk AFTER that goes global -> registers (8 global_load_dwordx4); the 4 fragment reads of k-group 3
+        //   barrier (the other stage is complete, this one fully consumed)
+        //   k-group 3: the first fragments of the next chunk
+        const float* sc = &smem[cur * NT2_STAGE];
         for (int kt = 0; kt < nk; ++kt) {
+            float* so = &smem[(cur ^ 1) * NT2_STAGE];
+#define NT2_RD(F, S, kk, m) F.m = *reinterpret_cast<const f32x4*>(&(S)[m##_off + (kk) * 8]); NT2_PIN
+#define NT2_RD1(F, S, kk) if constexpr (TMN == 2) { NT2_RD(F, S, kk, a1) }
+#define NT2_WA(i) if constexpr (i < 2 * TMN) { *reinterpret_cast<f32x4*>(&so[w_off + 32 * (i) * NT_LDS]) = ra4[i]; NT2_PIN }
+#define NT2_WB(i) *reinterpret_cast<f32x4*>(&so[TBM * NT_LDS + w_off + 32 * (i) * NT_LDS]) = rb4[i]; NT2_PIN
+#define NT2_LA(i) if constexpr (i < 2 * TMN) { ra4[i] = *reinterpret_cast<const f32x4*>(ap[i] + ld_koff); NT2_PIN }
+#define NT2_LB(i) rb4[i] = *reinterpret_cast<const f32x4*>(bp[i] + ld_koff); NT2_PIN
             NT2_STAMP(0)
-            NT2_QUAD(F0, 0) NT2_QUAD(F0, 1)
-            read_frag(F1, cur, 1); NT2_PIN
-            NT2_QUAD(F0, 2) NT2_QUAD(F0, 3)
+            NT2_M(F0, 0, 0, 0) NT2_M(F0, 0, 0, 1) NT2_RD(F1, sc, 1, a0) NT2_M(F0, 0, 1, 0) NT2_M(F0, 0, 1, 1)
+            NT2_M(F0, 1, 0, 0) NT2_M(F0, 1, 0, 1) NT2_RD1(F1, sc, 1) NT2_M(F0, 1, 1, 0) NT2_M(F0, 1, 1, 1)
+            NT2_M(F0, 2, 0, 0) NT2_M(F0, 2, 0, 1) NT2_RD(F1, sc, 1, b0) NT2_M(F0, 2, 1, 0) NT2_M(F0, 2, 1, 1)
+            NT2_M(F0, 3, 0, 0) NT2_M(F0, 3, 0, 1) NT2_RD(F1, sc, 1, b1) NT2_M(F0, 3, 1, 0) NT2_M(F0, 3, 1, 1)
             NT2_STAMP(1)
-            NT2_QUAD(F1, 0)
-            write_piece(cur ^ 1, 0); NT2_PIN
-            NT2_QUAD(F1, 1)
-            read_frag(F0, cur, 2); NT2_PIN
-            write_piece(cur ^ 1, 1); NT2_PIN
-            NT2_QUAD(F1, 2)
-            write_piece(cur ^ 1, 2); NT2_PIN
-            NT2_QUAD(F1, 3)
-            write_piece(cur ^ 1, 3); NT2_PIN
+            NT2_M(F1, 0, 0, 0) NT2_WA(0) NT2_M(F1, 0, 0, 1) NT2_RD(F0, sc, 2, a0) NT2_M(F1, 0, 1, 0) NT2_WB(0) NT2_M(F1, 0, 1, 1)
+            NT2_M(F1, 1, 0, 0) NT2_WA(1) NT2_M(F1, 1, 0, 1) NT2_RD1(F0, sc, 2) NT2_M(F1, 1, 1, 0) NT2_WB(1) NT2_M(F1, 1, 1, 1)
+            NT2_M(F1, 2, 0, 0) NT2_WA(2) NT2_M(F1, 2, 0, 1) NT2_RD(F0, sc, 2, b0) NT2_M(F1, 2, 1, 0) NT2_WB(2) NT2_M(F1, 2, 1, 1)
+            NT2_M(F1, 3, 0, 0) NT2_WA(3) NT2_M(F1, 3, 0, 1) NT2_RD(F0, sc, 2, b1) NT2_M(F1, 3, 1, 0) NT2_WB(3) NT2_M(F1, 3, 1, 1)
             NT2_STAMP(2)
-            NT2_QUAD(F0, 0)
-            load_piece(0); NT2_PIN
-            NT2_QUAD(F0, 1)
-            read_frag(F1, cur, 3); NT2_PIN
-            load_piece(1); NT2_PIN
-            NT2_QUAD(F0, 2)
-            load_piece(2); NT2_PIN
-            NT2_QUAD(F0, 3)
-            load_piece(3); NT2_PIN
+            NT2_M(F0, 0, 0, 0) NT2_LA(0) NT2_M(F0, 0, 0, 1) NT2_RD(F1, sc, 3, a0) NT2_M(F0, 0, 1, 0) NT2_LB(0) NT2_M(F0, 0, 1, 1)
+            NT2_M(F0, 1, 0, 0) NT2_LA(1) NT2_M(F0, 1, 0, 1) NT2_RD1(F1, sc, 3) NT2_M(F0, 1, 1, 0) NT2_LB(1) NT2_M(F0, 1, 1, 1)
+            NT2_M(F0, 2, 0, 0) NT2_LA(2) NT2_M(F0, 2, 0, 1) NT2_RD(F1, sc, 3, b0) NT2_M(F0, 2, 1, 0) NT2_LB(2) NT2_M(F0, 2, 1, 1)
+            NT2_M(F0, 3, 0, 0) NT2_LA(3) NT2_M(F0, 3, 0, 1) NT2_RD(F1, sc, 3, b1) NT2_M(F0, 3, 1, 0) NT2_LB(3) NT2_M(F0, 3, 1, 1)
             NT2_STAMP(4)
             advance();
             __syncthreads();        // the other stage is complete; every wave holds its last fragments of this one
             NT2_STAMP(5)
-            read_frag(F0, cur ^ 1, 0);      // (after the very last chunk: stale bytes, never used)
-            NT2_PIN
-            NT2_QUAD(F1, 0) NT2_QUAD(F1, 1) NT2_QUAD(F1, 2) NT2_QUAD(F1, 3)
+            // (after the very last chunk the reads below return stale bytes that are never used)
+            NT2_M(F1, 0, 0, 0) NT2_M(F1, 0, 0, 1) NT2_RD(F0, so, 0, a0) NT2_M(F1, 0, 1, 0) NT2_M(F1, 0, 1, 1)
+            NT2_M(F1, 1, 0, 0) NT2_M(F1, 1, 0, 1) NT2_RD1(F0, so, 0) NT2_M(F1, 1, 1, 0) NT2_M(F1, 1, 1, 1)
+            NT2_M(F1, 2, 0, 0) NT2_M(F1, 2, 0, 1) NT2_RD(F0, so, 0, b0) NT2_M(F1, 2, 1, 0) NT2_M(F1, 2, 1, 1)
+            NT2_M(F1, 3, 0, 0) NT2_M(F1, 3, 0, 1) NT2_RD(F0, so, 0, b1) NT2_M(F1, 3, 1, 0) NT2_M(F1, 3, 1, 1)
             NT2_STAMP(6)
             cur ^= 1;
+            sc = so;
         }
+#undef NT2_M
+#undef NT2_RD
+#undef NT2_RD1
+#undef NT2_WA
+#undef NT2_WB
+#undef NT2_LA
+#undef NT2_LB
 #undef NT2_QUAD
 #undef NT2_PIN
 #undef NT2_STAMP
@@ -755,7 +781,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt2_kernel(NuGemmNT g) {
         constexpr bool lab_skip = false;
 #endif
         // ---- epilogue: the stage consumed last (cur ^ 1 after the flip) is free until the next chunk's hand-over ----
-        nt_epilogue<EPI, 4>(g, ea, acc, &smem[(cur ^ 1) * NT2_STAGE] + wid * (32 * EPI_LDS), m0, n0, mwave, mlo, mhi, lane, wid, lab_skip);
+        nt_epilogue<EPI, 4, false, TMN>(g, ea, acc, &smem[(cur ^ 1) * NT2_STAGE] + wid * (32 * EPI_LDS), m0, n0, mwave, mlo, mhi, lane, slab, lab_skip, tm0);
 #ifdef NU_LAB
         if (tid == 0 && blockIdx.x < 1024 && lab_tile < NU_LAB_TILES) nu_lab_trace[blockIdx.x][lab_tile][2] = wall_clock64();
         ++lab_tile;
@@ -1172,11 +1198,22 @@ int nu_gemm_nt_launch(const NuGemmNT& g, hipStream_t stream) {
         return nu_launch_status();
     }
     if (prec == 0 && !v1) {
+        // 64-row tiles when the 128-row tiles cannot give every CU its two workgroups (point sets of a few thousand rows)
+#ifdef NU_LAB
+        const int small_env = nu_lab_small;
+#else
+        static const int small_env = getenv("NU_NT_SMALL") ? atoi(getenv("NU_NT_SMALL")) : -1;     // development switch: 0 never, 1 always
+#endif
+        const bool small = small_env >= 0 ? small_env != 0 : (long long)nu_cdiv(g.M, TBM) * ntn * groups < 512;
+        const long long nslots2 = small ? (long long)nu_rup(nu_cdiv(g.M, 64), 8) * ntn : nslots;
+        if (nslots2 > 0x7fffffffLL) return NU_ERR_ARG;
         long long per2 = nu_rup(nu_cdiv(grid_env ? grid_env : 512, groups), 8);       // two workgroups per CU
-        if (per2 > nslots) per2 = nslots;
+        if (per2 > nslots2) per2 = nslots2;
         dim3 grid2((unsigned)per2, 1, groups);
+        const NuGemmNT& gs = g;
         switch (g.epi) {
-#define NU_CASE2(E) case E: hipLaunchKernelGGL((gemm_nt2_kernel<E>), grid2, block, 0, stream, g); break;
+#define NU_CASE2(E) case E: if (small) hipLaunchKernelGGL((gemm_nt2_kernel<E, 1>), grid2, block, 0, stream, gs); \
+                            else hipLaunchKernelGGL((gemm_nt2_kernel<E, 2>), grid2, block, 0, stream, gs); break;
             NU_CASE2(NU_EPI_BIAS_NONE)
             NU_CASE2(NU_EPI_BIAS_RELU)
             NU_CASE2(NU_EPI_BIAS_SOFTPLUS)
@@ -1795,19 +1832,24 @@ __global__ __launch_bounds__(512, 1) void gemm_tn16x256_kernel(NuGemmTN g) {
 // thread and chunk now feed 128 MFMAs per wave instead of 64: half the load-issue time per matrix cycle.
 // Same slab layout, same bias sums, same ragged-tail rules as gemm_tn_kernel.
 // ------------------------------------------------------------------------------------------------
-template <bool BIG>
-__global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(NuGemmTN g) {
-    __shared__ __attribute__((aligned(16))) float smem[2][2][256 * NT_LDS];   // [stage][A | B][column][k (+4 pad)] = 2 x 73,728 B
+// NJ = 4: the 256 x 256 tile (512 threads, 8 waves as 4 x 2, wave tile 64 x 128).  NJ = 2: the same pipeline on a 128 x 128 tile (256
+// threads, 4 waves as 2 x 2, wave tile 64 x 64, two workgroups per CU) for the shapes the big tile does not fit (N1 or N2 not a
+// multiple of 256, or too few tiles to fill the chip) -- measured no faster there than the first-generation gemm_tn_kernel, which
+// stays the default for those shapes (see nu_gemm_tn_launch).
+template <bool BIG, int NJ>
+__global__ __launch_bounds__(128 * NJ, 2) void gemm_tn2_kernel(NuGemmTN g) {
+    constexpr int T = 64 * NJ;                       // tile edge: 256 or 128
+    __shared__ __attribute__((aligned(16))) float smem[2][2][T * NT_LDS];     // [stage][A | B][column][k (+4 pad)]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wid = tid >> 6;
-    const int wr = wid >> 1, wc = wid & 1;           // wave tile: rows (N1) 64 wr .. +64, columns (N2) 128 wc .. +128
-    const int t2 = g.N2 / 256;
+    const int wr = wid >> 1, wc = wid & 1;           // wave tile: rows (N1) 64 wr .. +64, columns (N2) 32 NJ wc .. + 32 NJ
+    const int t2 = (g.N2 + T - 1) / T;
     const int n1t = blockIdx.x / t2, n2t = blockIdx.x - n1t * t2;
-    const int n1_0 = n1t * 256, n2_0 = n2t * 256;
+    const int n1_0 = n1t * T, n2_0 = n2t * T;
     const int split = blockIdx.y;
     const int grp = blockIdx.z;
-    const int N1p = g.N1, N2p = g.N2;                // multiples of 256 (launcher)
+    const int N1p = ((g.N1 + 127) / 128) * 128, N2p = ((g.N2 + 127) / 128) * 128;      // slab extents (nu_wgrad_workspace_bytes)
 
     int rows_per = (g.P + g.S - 1) / g.S;
     rows_per = ((rows_per + TBK - 1) / TBK) * TBK;
@@ -1818,15 +1860,15 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(NuGemmTN g) {
     const int npair = g.A1 ? 2 : 1;
     const int total = ntile * npair;
 
-    const int c = tid & 255;    // column of the 256-wide operand tile this thread fetches
-    const int kg = tid >> 8;    // which 16 of the chunk's 32 reduced rows (wave-uniform)
+    const int c = tid & (T - 1);    // column of the T-wide operand tile this thread fetches
+    const int kg = tid / T;         // which 16 of the chunk's 32 reduced rows (wave-uniform)
     const bool do_bias = (g.bias_slab != nullptr) && (n2t == 0);
 
-    f32x16 acc[2][4];
+    f32x16 acc[2][NJ];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
@@ -1839,7 +1881,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(NuGemmTN g) {
     // address arithmetic, 8 ds_write_b128 -- is time in which NEITHER issues MFMAs (measured: matrix pipe 74 % busy).
     const char* __restrict__ ldA = nullptr;
     const char* __restrict__ ldB = nullptr;
-    int ld_lda = 0, ld_ldb = 0, ld_ca = 0, ld_cb = 0, ld_pbase = 0;
+    int ld_lda = 0, ld_ldb = 0, ld_ca = 0, ld_cb = 0, ld_pbase = 0, ld_pbase_u = 0;
     int nvalid_ld = 16;
     bool pair0_ld = true;
     auto load_begin = [&](int t) {
@@ -1853,6 +1895,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(NuGemmTN g) {
         ld_ca = ld_ca < ld_lda ? ld_ca : ld_lda - 1;
         ld_cb = ld_cb < ld_ldb ? ld_cb : ld_ldb - 1;
         ld_pbase = p_begin + kt * TBK + kg * 16;
+        ld_pbase_u = p_begin + kt * TBK;                  // (wave-uniform part)
         nvalid_ld = p_end - ld_pbase;
         pair0_ld = pair == 0;
     };
@@ -1905,44 +1948,131 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(NuGemmTN g) {
 
     const int li = lane & 31, lh = lane >> 5;
     const int a_off = (wr * 64 + li) * NT_LDS + 4 * lh;
-    const int b_off = (wc * 128 + li) * NT_LDS + 4 * lh;
-    int cur = 0;
-    for (int t = 0; t < total; ++t) {
-        const bool st_on = t + 1 < total, ld_on = t + 2 < total;
-        if (ld_on) load_begin(t + 2);
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            f32x4 a[2], b[4];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const f32x4*>(&smem[cur][0][a_off + 32 * i * NT_LDS + kk * 8]);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const f32x4*>(&smem[cur][1][b_off + 32 * j * NT_LDS + kk * 8]);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                // register piece kk: handed to the other stage behind the first group of 8 MFMAs, re-issued behind the next two
-                if (e == 0 && st_on) store_piece(cur ^ 1, kk);
-                if (e == 1 && ld_on) load_piece(kk, 0, 2);
-                if (e == 2 && ld_on) load_piece(kk, 2, 4);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+    const int b_off = (wc * 32 * NJ + li) * NT_LDS + 4 * lh;
+    // Fragments are double-buffered in registers and EVERY memory instruction of a chunk sits alone between two MFMAs (see
+    // gemm_nt2_kernel: an in-order wave issues nothing while one of its own instructions issues, and the two waves of a SIMD belong
+    // to this one workgroup and run in phase -- whatever one of them issues in a block, the other issues at the same time).
+    // A chunk is 16 slots of 8 MFMAs (k-group kk = slot / 4, k-step e = slot % 4):
+    //   slot 0 / 4 / 8 / 9      register piece 0 / 1 / 2 / 3 of chunk t+1 -> the other LDS stage (zeroing of the ragged tail, bias sums)
+    //   slots 1-2, 5-6, 10 + 12, 13-14   the same pieces re-issued global -> registers for chunk t+2 (one scalar load per gap)
+    //   slots 3, 7, 11          the 6 fragment reads of the next k-group; barrier behind slot 11; slot 15: first fragments of chunk t+1
+    struct FragT { f32x4 a[2]; f32x4 b[NJ]; };
+    FragT F0, F1;
+    // One scalar load: the ROW of the operand is wave-uniform (kg = tid / T is the same for a whole wave), so its address is a
+    // scalar 64-bit base (two or three SALU instructions) and the lane only adds its column offset -- global_load_dword v, v_off, s[base]
+    // -- no per-lane multiply-add in front of each of the 32 loads of a chunk (they cost the narrow tile a third of its issue slots).
+    // The rows are visited in increasing order, so the base advances by one row stride per load (and stops at the last row of the
+    // split: the ragged tail re-reads it, zeroed at the hand-over).
+    const int kg_u = __builtin_amdgcn_readfirstlane(kg);
+    const char* rpA = nullptr;
+    const char* rpB = nullptr;
+    int prA = 0, prB = 0;                                   // (wave-uniform) row the bases point at
+    auto ld_rows_begin = [&]() {
+        int pr = ld_pbase_u + kg_u * 16;
+        pr = pr < p_end ? pr : p_end - 1;
+        prA = prB = pr;
+        rpA = ldA + (long long)pr * ld_lda * 4;
+        rpB = ldB + (long long)pr * ld_ldb * 4;
+    };
+    auto ld_one = [&](bool isA, int i, int e) {
+        if (isA) {
+            ra4[i][e] = *reinterpret_cast<const float*>(rpA + (unsigned)ld_ca * 4u);
+            const bool more = prA + 1 < p_end;
+            rpA += more ? (long long)ld_lda * 4 : 0;
+            prA += more ? 1 : 0;
+        } else {
+            rb4[i][e] = *reinterpret_cast<const float*>(rpB + (unsigned)ld_cb * 4u);
+            const bool more = prB + 1 < p_end;
+            rpB += more ? (long long)ld_ldb * 4 : 0;
+            prB += more ? 1 : 0;
         }
+    };
+    // the chunk in registers (nvalid / pend_pair0 describe it): zero the ragged tail, then (a gap later) bias sums + hand-over
+    auto st_zero = [&](bool isA, int i) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (isA) ra4[i][e] = (4 * i + e < nvalid) ? ra4[i][e] : 0.f;
+            else rb4[i][e] = (4 * i + e < nvalid) ? rb4[i][e] : 0.f;
+        }
+    };
+    bool bias_on = false;
+    auto st_write = [&](bool isA, int st, int i) {
+        if (isA) {
+            const float rs = (ra4[i][0] + ra4[i][1]) + (ra4[i][2] + ra4[i][3]);
+            bs += bias_on ? rs : 0.f;                    // (a select, not a branch: see the note at the loop)
+            *reinterpret_cast<f32x4*>(&smem[st][0][c * NT_LDS + kg * 16 + 4 * i]) = ra4[i];
+        } else {
+            *reinterpret_cast<f32x4*>(&smem[st][1][c * NT_LDS + kg * 16 + 4 * i]) = rb4[i];
+        }
+    };
+    int cur = 0;
+    if (total > 0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) F0.a[i] = *reinterpret_cast<const f32x4*>(&smem[0][0][a_off + 32 * i * NT_LDS]);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) F0.b[j] = *reinterpret_cast<const f32x4*>(&smem[0][1][b_off + 32 * j * NT_LDS]);
+    }
+#define TN_PIN __builtin_amdgcn_sched_barrier(0);
+#define TN_M(F, e, i, j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(F.a[i][e], F.b[j][e], acc[i][j], 0, 0, 0); TN_PIN
+    // the k-th MFMA of a k-step: (k / 4, k % 4) on the 64 x 128 wave tile, (k / 2, k % 2) on the 64 x 64 one
+#define TN_MK(F, e, k) if constexpr (NJ == 4) { TN_M(F, e, (k) / 4, (k) % 4) } else if constexpr ((k) < 4) { TN_M(F, e, (k) / 2, (k) % 2) }
+    // one k-step (8 or 4 MFMAs) with one auxiliary statement behind each MFMA (the wide tile has seven slots, the narrow one four)
+#define TN_SLOT(F, e, ...) TN_SLOT_(F, e, __VA_ARGS__)      /* (one more level: the list macros below expand first) */
+#define TN_SLOT_(F, e, X0, X1, X2, X3, X4, X5, X6)                                                   \
+    TN_MK(F, e, 0) X0; TN_PIN TN_MK(F, e, 1) X1; TN_PIN TN_MK(F, e, 2) X2; TN_PIN TN_MK(F, e, 3) X3; TN_PIN     \
+    if constexpr (NJ == 4) { TN_MK(F, e, 4) X4; TN_PIN TN_MK(F, e, 5) X5; TN_PIN TN_MK(F, e, 6) X6; TN_PIN TN_MK(F, e, 7) }
+#define TN_RDA(F, ST, kk, i) F.a[i] = *reinterpret_cast<const f32x4*>(&smem[ST][0][a_off + 32 * (i) * NT_LDS + (kk) * 8])
+#define TN_RDB(F, ST, kk, j) F.b[j] = *reinterpret_cast<const f32x4*>(&smem[ST][1][b_off + 32 * (j) * NT_LDS + (kk) * 8])
+#define TN_RDB4(F, ST, kk, j) (void)0; if constexpr (NJ == 4) { TN_RDB(F, ST, kk, j); }
+#define TN_READS(F, ST, kk) TN_RDA(F, ST, kk, 0), TN_RDA(F, ST, kk, 1), TN_RDB(F, ST, kk, 0), TN_RDB(F, ST, kk, 1), TN_RDB4(F, ST, kk, 2), TN_RDB4(F, ST, kk, 3), (void)0
+#define TN_LD2(i, e) ld_one(true, i, e), ld_one(false, i, e), ld_one(true, i, (e) + 1), ld_one(false, i, (e) + 1), (void)0, (void)0, (void)0
+#define TN_ST(i) st_zero(true, i), st_write(true, cur ^ 1, i), st_zero(false, i), st_write(false, cur ^ 1, i), (void)0, (void)0, (void)0
+    // No instruction of the loop body is conditional: a branch around a load makes hipcc wait vmcnt(0) at the join (every scalar
+    // load then waits for all loads before it -- measured 66 instead of 115 TFLOP/s).  Past the end of the split the loader
+    // re-reads the last chunk (valid addresses, data never used) and the hand-over writes a stage nobody reads again; only the
+    // bias sum must not see those chunks (a select).
+    for (int t = 0; t < total; ++t) {
+        bias_on = do_bias && pend_pair0 && t + 1 < total;
+        load_begin(t + 2 < total ? t + 2 : total - 1);
+        ld_rows_begin();
+        TN_SLOT(F0, 0, TN_ST(0))
+        TN_SLOT(F0, 1, TN_LD2(0, 0))
+        TN_SLOT(F0, 2, TN_LD2(0, 2))
+        TN_SLOT(F0, 3, TN_READS(F1, cur, 1))
+        TN_SLOT(F1, 0, TN_ST(1))
+        TN_SLOT(F1, 1, TN_LD2(1, 0))
+        TN_SLOT(F1, 2, TN_LD2(1, 2))
+        TN_SLOT(F1, 3, TN_READS(F0, cur, 2))
+        TN_SLOT(F0, 0, TN_ST(2))
+        TN_SLOT(F0, 1, TN_ST(3))
+        TN_SLOT(F0, 2, TN_LD2(2, 0))
+        TN_SLOT(F0, 3, TN_READS(F1, cur, 3))
+        __syncthreads();            // the other stage is complete; every wave holds its last fragments of this one
+        TN_SLOT(F1, 0, TN_LD2(2, 2))
+        TN_SLOT(F1, 1, TN_LD2(3, 0))
+        TN_SLOT(F1, 2, TN_LD2(3, 2))
+        TN_SLOT(F1, 3, TN_READS(F0, cur ^ 1, 0))      // (after the last chunk: stale bytes, never used)
         nvalid = nvalid_ld; pend_pair0 = pair0_ld;
-        __syncthreads();
         cur ^= 1;
     }
+#undef TN_PIN
+#undef TN_M
+#undef TN_MK
+#undef TN_SLOT
+#undef TN_SLOT_
+#undef TN_RDA
+#undef TN_RDB
+#undef TN_RDB4
+#undef TN_READS
+#undef TN_LD2
+#undef TN_ST
 
     float* __restrict__ slab = g.slab + (long long)grp * g.sSlab + (long long)split * N1p * N2p;
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-        for (int tn = 0; tn < 4; ++tn) {
-            const int col = n2_0 + wc * 128 + tn * 32 + li;
+        for (int tn = 0; tn < NJ; ++tn) {
+            const int col = n2_0 + wc * 32 * NJ + tn * 32 + li;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = n1_0 + wr * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -1951,9 +2081,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(NuGemmTN g) {
         }
     if (do_bias) {
         float* red = &smem[0][0][0];
-        red[kg * 256 + c] = bs;
+        red[kg * T + c] = bs;
         __syncthreads();
-        if (tid < 256) g.bias_slab[(long long)grp * g.sBiasSlab + (long long)split * N1p + n1_0 + tid] = red[tid] + red[256 + tid];
+        if (tid < T) g.bias_slab[(long long)grp * g.sBiasSlab + (long long)split * N1p + n1_0 + tid] = red[tid] + red[T + tid];
     }
 }
 
@@ -1990,13 +2120,26 @@ int nu_gemm_tn_launch(const NuGemmTN& g, hipStream_t stream) {
     const int prec = g.bf16 & 3;
     if (prec == 3 || ((g.bf16 & ~3) && prec != 1)) return NU_ERR_ARG;
     const bool big_tile = nu_tn_big_tile(g.N1, g.N2, g.groups, g.bf16, g.S);
-    if ((g.bf16 & 3) == 0 && big_tile) {
-        dim3 grid2((g.N1 / 256) * (g.N2 / 256), g.S, g.groups > 0 ? g.groups : 1);
+    if ((g.bf16 & 3) == 0) {         // exact fp32: the pipelined kernel, 256 x 256 tiles where the shape allows, else 128 x 128
+        // 128 x 128 tiles: the first-generation kernel stays the default -- the pipelined one measured 85.5 vs 89.8 TFLOP/s on the
+        // 1024 x 288 shape and 109 vs 110 on 256 x 256 with 128 splits (profiles/r03): at 64 MFMAs per chunk and wave the 32 scalar
+        // loads are a third of the issue slots however they are placed.  NU_TN_V1=0 selects the pipelined kernel (development A/B).
+        static const bool tn_v1 = !(getenv("NU_TN_V1") && atoi(getenv("NU_TN_V1")) == 0);
         const long long mld = (g.lda0 > g.ldb0 ? g.lda0 : g.ldb0) > (g.A1 ? (g.lda1 > g.ldb1 ? g.lda1 : g.ldb1) : 0)
                                   ? (g.lda0 > g.ldb0 ? g.lda0 : g.ldb0) : (g.lda1 > g.ldb1 ? g.lda1 : g.ldb1);
-        if ((long long)g.P * mld * 4 >= (1LL << 32)) hipLaunchKernelGGL((gemm_tn256_kernel<true>), grid2, dim3(512), 0, stream, g);
-        else hipLaunchKernelGGL((gemm_tn256_kernel<false>), grid2, dim3(512), 0, stream, g);
-        return nu_launch_status();
+        const bool big = (long long)g.P * mld * 4 >= (1LL << 32);
+        if (big_tile) {
+            dim3 grid2((g.N1 / 256) * (g.N2 / 256), g.S, g.groups > 0 ? g.groups : 1);
+            if (big) hipLaunchKernelGGL((gemm_tn2_kernel<true, 4>), grid2, dim3(512), 0, stream, g);
+            else hipLaunchKernelGGL((gemm_tn2_kernel<false, 4>), grid2, dim3(512), 0, stream, g);
+            return nu_launch_status();
+        }
+        if (!tn_v1) {
+            dim3 grid2(nu_cdiv(g.N1, 128) * nu_cdiv(g.N2, 128), g.S, g.groups > 0 ? g.groups : 1);
+            if (big) hipLaunchKernelGGL((gemm_tn2_kernel<true, 2>), grid2, dim3(256), 0, stream, g);
+            else hipLaunchKernelGGL((gemm_tn2_kernel<false, 2>), grid2, dim3(256), 0, stream, g);
+            return nu_launch_status();
+        }
     }
     dim3 grid(nu_cdiv(g.N1, 128) * nu_cdiv(g.N2, 128), g.S, g.groups > 0 ? g.groups : 1), block(256);
     const long long max_ld = (g.lda0 > g.ldb0 ? g.lda0 : g.ldb0) > (g.A1 ? (g.lda1 > g.ldb1 ? g.lda1 : g.ldb1) : 0)

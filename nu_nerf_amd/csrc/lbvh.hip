@@ -321,14 +321,17 @@ static __device__ inline bool nu_ray_box(const float* o, const float* invd, cons
 // row).  The first pass runs with a SHORT stack (16 entries = 4 KB per wave, so LDS no longer pins the kernel at 8 waves per
 // CU: measured 1.22 -> 1.85 G rays/s on 20480 faces, 0.61 -> 1.33 on 327680; 8 / 12 / 24 / 32 entries are slower); a lane whose traversal would need more marks its ray (hit = -1) and the second pass re-traces exactly those rays with
 // the full 64-entry stack (a Morton tree over 30-bit codes + index tie-break is at most 62 deep).  RETRACE: only marked rays.
-template <int STACK, bool RETRACE>
-__global__ __launch_bounds__(256) void lbvh_trace_kernel(const char* __restrict__ buf, NuBvhLayout L, const float* __restrict__ rays,
-                                                         int N, float tmin, float tmax, float* __restrict__ hit,
-                                                         int* __restrict__ idx, float* __restrict__ tout) {
-    __shared__ int stack[4][STACK][64];
+// RPW rays per wave: a traversal is a chain of dependent node fetches (latency-bound), so a small batch is faster spread thin --
+// 4096 rays as 64 per wave are 64 waves on 16 CUs (78 us); as 16 per wave they are 256 single-wave workgroups, one per CU.
+template <int STACK, bool RETRACE, int RPW = 64>
+__global__ __launch_bounds__(RPW == 64 ? 256 : 64) void lbvh_trace_kernel(const char* __restrict__ buf, NuBvhLayout L,
+                                                                           const float* __restrict__ rays, int N, float tmin, float tmax,
+                                                                           float* __restrict__ hit, int* __restrict__ idx,
+                                                                           float* __restrict__ tout) {
+    __shared__ int stack[RPW == 64 ? 4 : 1][STACK][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= N) return;
+    const int r = RPW == 64 ? blockIdx.x * blockDim.x + threadIdx.x : blockIdx.x * RPW + lane;
+    if (r >= N || lane >= RPW) return;
     if (RETRACE && hit[r] >= 0.0f) return;
     bool overflow = false;
     const NuBvhHeader* h = (const NuBvhHeader*)(buf + L.header);
@@ -400,6 +403,21 @@ extern "C" int nu_lbvh_trace(const void* bvh, int n_faces, const float* rays, in
         return nu_launch_status();
     }
     static const int short_env = getenv("NU_LBVH_SHORT") ? atoi(getenv("NU_LBVH_SHORT")) : 16;   // development sweep: 16 measured best
+    static const int rpw_env = getenv("NU_LBVH_RPW") ? atoi(getenv("NU_LBVH_RPW")) : 0;          // development switch: rays per wave
+    // small batches (a training step traces 4096 rays or fewer per bounce): 16 or 32 rays per single-wave workgroup, so that the
+    // batch covers the chip's 256 CUs; from 16 384 rays on, full waves
+    const int rpw = rpw_env ? rpw_env : (N <= 8192 ? 16 : (N <= 16384 ? 32 : 64));
+    if (rpw == 16 || rpw == 32) {
+        const dim3 grid(nu_cdiv(N, rpw)), block(64);
+        if (rpw == 16) {
+            hipLaunchKernelGGL((lbvh_trace_kernel<16, false, 16>), grid, block, 0, stream, (const char*)bvh, L, rays, N, tmin, tmax, hit, idx, t_out);
+            hipLaunchKernelGGL((lbvh_trace_kernel<NU_STACK, true, 16>), grid, block, 0, stream, (const char*)bvh, L, rays, N, tmin, tmax, hit, idx, t_out);
+        } else {
+            hipLaunchKernelGGL((lbvh_trace_kernel<16, false, 32>), grid, block, 0, stream, (const char*)bvh, L, rays, N, tmin, tmax, hit, idx, t_out);
+            hipLaunchKernelGGL((lbvh_trace_kernel<NU_STACK, true, 32>), grid, block, 0, stream, (const char*)bvh, L, rays, N, tmin, tmax, hit, idx, t_out);
+        }
+        return nu_launch_status();
+    }
 #define NU_TRACE1(S) hipLaunchKernelGGL((lbvh_trace_kernel<S, false>), dim3(nu_cdiv(N, 256)), dim3(256), 0, stream, (const char*)bvh, L, \
                                         rays, N, tmin, tmax, hit, idx, t_out)
     if (short_env == 8) NU_TRACE1(8); else if (short_env == 12) NU_TRACE1(12);

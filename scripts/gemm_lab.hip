@@ -133,6 +133,23 @@ int main(int argc, char** argv) {
         }
         nu_lab_grid = 0; nu_lab_v1 = 0;
         set_int(nu_lab_skip_epi, 0);
+    } else if (!strcmp(mode, "small")) {
+        // 64-row tiles (gen 2, TMN = 1) against 128-row tiles on point sets that do not fill the chip
+        for (int i = 0; i < 3; ++i) time_nt(b256, NU_EPI_PLAIN, 10);
+        for (int pass = 0; pass < 2; ++pass)
+            for (int m : {2048, 4096, 8192, 16384, 24576, 32768, 49152, 65536, 131072}) {
+                Bufs bs = b256;
+                bs.M = m;
+                double r[2][3];
+                for (int sm = 0; sm < 2; ++sm) {
+                    nu_lab_small = sm;
+                    int i = 0;
+                    for (int epi : {NU_EPI_BIAS_RELU, NU_EPI_BIAS_SOFTPLUS, NU_EPI_Q_SP}) r[sm][i++] = time_nt(bs, epi, 200) * 1e3;
+                }
+                printf("M=%6d K=256 N=256: 128-row tiles relu %6.1f us softplus %6.1f us q_sp %6.1f us | 64-row tiles relu %6.1f softplus %6.1f q_sp %6.1f  (%.0f / %.0f TFLOP/s relu)\n",
+                       m, r[0][0], r[0][1], r[0][2], r[1][0], r[1][1], r[1][2], tf(bs, r[0][0] * 1e-3), tf(bs, r[1][0] * 1e-3));
+            }
+        nu_lab_small = -1;
     } else if (!strcmp(mode, "calib")) {
         // run under `rocprofv3 --pmc FETCH_SIZE`: each launch reads exactly 553,648,128 bytes (the 540672 x 256 fp32 operand)
         const long long n = (long long)M * 256;

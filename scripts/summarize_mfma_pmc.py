@@ -12,7 +12,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(float))
 seen = collections.defaultdict(set)
 for r in csv.DictReader(open(cc_csv)):
     name = r['Kernel_Name']
-    k = 'gemm_nt_kernel' if ('gemm_nt_kernel' in name or 'gemm_nt2_kernel' in name) else ('gemm_tn_kernel' if ('gemm_tn_kernel' in name or 'gemm_tn256_kernel' in name) else None)
+    k = 'gemm_nt_kernel' if ('gemm_nt_kernel' in name or 'gemm_nt2_kernel' in name) else ('gemm_tn_kernel' if ('gemm_tn_kernel' in name or 'gemm_tn256_kernel' in name or 'gemm_tn2_kernel' in name) else None)
     if not k:
         continue
     acc[k][r['Counter_Name']] += float(r['Counter_Value'])

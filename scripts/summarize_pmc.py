@@ -9,7 +9,7 @@ def agg(path, name):
         if r['Counter_Name'] != name:
             continue
         kn = r['Kernel_Name']
-        k = 'gemm_nt_kernel' if ('gemm_nt_kernel' in kn or 'gemm_nt2_kernel' in kn or 'gemm_nt16' in kn) else ('gemm_tn_kernel' if ('gemm_tn_kernel' in kn or 'gemm_tn256_kernel' in kn or 'gemm_tn16' in kn) else
+        k = 'gemm_nt_kernel' if ('gemm_nt_kernel' in kn or 'gemm_nt2_kernel' in kn or 'gemm_nt16' in kn) else ('gemm_tn_kernel' if ('gemm_tn_kernel' in kn or 'gemm_tn256_kernel' in kn or 'gemm_tn2_kernel' in kn or 'gemm_tn16' in kn) else
              ('calib_read4' if 'calib_read4' in kn else ('calib_read16' if 'calib_read16' in kn else None)))
         if k:
             out[k][0] += 1
@@ -25,7 +25,7 @@ for k in f:
               "note": "FETCH_SIZE x2 (gfx950 128-B request correction), KiB units; separate --pmc passes"}
     res[k]["hbm_bytes_per_launch"] = res[k]["fetch_bytes_per_launch"] + res[k]["write_bytes_per_launch"]
     if k == 'gemm_tn_kernel':
-        res[k]["note"] += ("; all weight-gradient launches (gemm_tn256_kernel + gemm_tn_kernel); the x2 factor was calibrated for 4-byte-"
+        res[k]["note"] += ("; all weight-gradient launches (gemm_tn2_kernel / gemm_tn256_kernel + gemm_tn_kernel); the x2 factor was calibrated for 4-byte-"
                            "per-lane reads too (scripts/gemm_lab calib)")
 json.dump(res, open(out_json, 'w'), indent=1)
 print(json.dumps(res, indent=1))

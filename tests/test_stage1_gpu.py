@@ -329,7 +329,8 @@ def test_ray_store_from_loaded_images_on_the_device(gpu):
     from helpers import check_ray_store_against_reference_fixture
     from nu_nerf_amd.renderer import name2renderer
     info = check_ray_store_against_reference_fixture(gpu)
-    small = {'n_samples': 16, 'n_importance': 16, 'n_bg_samples': 8, 'train_ray_num': 32, 'test_ray_num': 20}
+    small = {'n_samples': 16, 'n_importance': 16, 'n_bg_samples': 8, 'train_ray_num': 32, 'test_ray_num': 20,
+             'test_downsample_ratio': False}      # (down-sampling test images is image preprocessing: the caller's, before set_ray_store)
     for is_nerf, name in ((True, 'nerf/spherepot'), (False, 'real/bear')):
         net = name2renderer['shape'](dict(small, database_name=name, is_nerf=is_nerf), training=True).to(gpu)
         poses = info['poses'].clone()

