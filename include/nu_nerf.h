@@ -335,6 +335,12 @@ typedef struct NuSdfBufs {
 int nu_sdf_net_size(void);
 int nu_sdf_bufs_size(void);
 int nu_sdf_mlp_fwd(NuOpCtx* ctx, const NuSdfNet* net, const float* X, int x_ld, NuSdfBufs* bufs, int want_feat, hipStream_t stream);
+/* The no-gradient forward as ONE fully-fused kernel (csrc/fused_sdf.hip): sdf[P] = SDFNetwork(x)[..., 0] for X [P, x_ld] (x = the
+ * first three floats of a row), exact fp32, nothing kept -- embedding, the eight softplus layers and the sdf head with the
+ * activations of a 32- or 64-point tile held in LDS and the weights streamed through it.  Bit-identical to nu_sdf_mlp_fwd(...,
+ * want_feat = 0).  Serves the hierarchical sampler (renderer_zerothick.py:525-612: 64 + 3 x 16 queries per ray), the occlusion
+ * probe (field.py:501-554), extract_fields (field.py:1286-1307) and the stage-2 inner up-sampler (renderer_zerothick.py:1742-1760). */
+int nu_sdf_fused_fwd(const NuSdfNet* net, const float* X, int x_ld, int P, float* sdf, hipStream_t stream);
 int nu_sdf_mlp_normal(NuOpCtx* ctx, const NuSdfNet* net, NuSdfBufs* bufs, hipStream_t stream);
 int nu_sdf_mlp_bwd(NuOpCtx* ctx, const NuSdfNet* net, NuSdfBufs* bufs, const float* dYX, const float* nbar, float* dx,
                    hipStream_t stream);

@@ -1204,7 +1204,12 @@ int nu_gemm_nt_launch(const NuGemmNT& g, hipStream_t stream) {
 #else
         static const int small_env = getenv("NU_NT_SMALL") ? atoi(getenv("NU_NT_SMALL")) : -1;     // development switch: 0 never, 1 always
 #endif
-        const bool small = small_env >= 0 ? small_env != 0 : (long long)nu_cdiv(g.M, TBM) * ntn * groups < 512;
+        // ... and when they shorten the last round: the persistent grid walks ceil(tiles / 512) rounds, so 1054 tiles of 128 rows
+        // (a 67 k-row point set, the outer points of a 512-ray batch) take three rounds for 2.06 rounds of work; as 2108 tiles of
+        // 64 rows they take 5 for 4.12.  A 64-row tile costs ~5 % more per FLOP (half the reuse of the weight tile).
+        auto round_eff = [&](long long tiles) { return (double)tiles / (double)(nu_cdivl(tiles, 512) * 512); };
+        const long long t128 = (long long)nu_cdiv(g.M, TBM) * ntn * groups, t64 = (long long)nu_cdiv(g.M, 64) * ntn * groups;
+        const bool small = small_env >= 0 ? small_env != 0 : (t128 < 512 || 0.95 * round_eff(t64) > round_eff(t128));
         const long long nslots2 = small ? (long long)nu_rup(nu_cdiv(g.M, 64), 8) * ntn : nslots;
         if (nslots2 > 0x7fffffffLL) return NU_ERR_ARG;
         long long per2 = nu_rup(nu_cdiv(grid_env ? grid_env : 512, groups), 8);       // two workgroups per CU

@@ -190,6 +190,8 @@ class Stage1Engine:
         self.py_seq = os.environ.get('NU_PY_SEQ', '0') != '0'
         if self.py_seq and self.h16:
             raise ValueError("NU_PY_SEQ=1 (launch-by-launch sequencing) has no bf16-storage mode: unset it or set NU_BF16_STORAGE=0")
+        # NU_FUSED_SDF=0: the no-gradient SDF evaluations through the layered path (development A/B)
+        self._fused_sdf = os.environ.get('NU_FUSED_SDF', '1') != '0'
         self._ws = None
         self._ptr_sig = None
         self._ktime = None
@@ -251,6 +253,7 @@ class Stage1Engine:
     # below `_TWO_STREAM_SAMPLES` ray samples the NeRF++ chain runs on a second HIP stream.  Both chains push their split reductions
     # to the shared arena from this (single) host thread; the batched reduction runs after the join.
     _TWO_STREAM_SAMPLES = int(os.environ.get('NU_TWO_STREAM_SAMPLES', 200000))
+    _FUSED_SDF_MAX_POINTS = int(os.environ.get('NU_FUSED_SDF_MAX_POINTS', 40000))
 
     def _fork(self):
         if getattr(self, '_side', None) is None:
@@ -732,6 +735,14 @@ class Stage1Engine:
         Returns a dict of activation tensors."""
         lib, S = self.lib, self.stream()
         e = self.empty
+        if (not keep and not want_feat and self.bf16 == 0 and self._fused_sdf and P <= self._FUSED_SDF_MAX_POINTS
+                and getattr(self, '_sdf_net', None) is not None):
+            # nothing is kept: the whole network in ONE kernel (csrc/fused_sdf.hip), bit-identical to the layered path below.
+            # Measured (scripts/bench_fused_sdf.py, profiles/r03): 93 vs 122 us at 8 192 points, 153 vs 186 at 16 384, 304 vs 315
+            # at 32 768; from 65 536 points on the layered GEMMs (two workgroups per CU) are 4 % faster, so those keep them
+            sdf = e(P)
+            L.check(lib.nu_sdf_fused_fwd(ctypes.byref(self._sdf_net), c_p(X), x_ld, P, c_p(addr(sdf)), S), "nu_sdf_fused_fwd")
+            return {'P': P, 'sdf': sdf}
         a = {'P': P}
         a['E'] = e(P, 64)
         a['U4'] = e(P, 256)
@@ -1023,7 +1034,7 @@ class Stage1Engine:
                 "nu_shading_stack_fwd")
         return s
 
-    def _c_shading_backward(self, a, s, pt, idx, dcolor_rm, flat, d_spec_raw, d_occ_raw):
+    def _c_shading_backward(self, a, s, pt, idx, dcolor_rm, flat, d_spec_raw, d_occ_raw, d_mat_raw=None):
         lib, S, e, P = self.lib, self.stream(), self.empty, s['P']
         rows_ol, R = s['rows_ol'], s['R']
         cb = s['cb']
@@ -1040,6 +1051,8 @@ class Stage1Engine:
                 dOLo[3 * P:].zero_()
         if d_occ_raw is not None:
             dIWo += d_occ_raw
+        if d_mat_raw is not None:
+            dMraw += d_mat_raw
         keep = []
         for i, rows in enumerate((rows_ol, 2 * P, P, P)):
             t = self.empty_h(rows, 256)
@@ -1060,13 +1073,13 @@ class Stage1Engine:
         L.check(lib.nu_shading_stack_bwd(*args, 1, S), "nu_shading_stack_bwd(1)")
         return dYX, dn
 
-    def shading_backward(self, a, s, pt, idx, dcolor_rm, flat, d_spec_raw=None, d_occ_raw=None):
+    def shading_backward(self, a, s, pt, idx, dcolor_rm, flat, d_spec_raw=None, d_occ_raw=None, d_mat_raw=None):
         """Returns (dYX [P,288] with feature/x columns filled, dn_shade [P,3])."""
         lib, S, P = self.lib, self.stream(), s['P']
         e = self.empty
         rows_ol, R = s['rows_ol'], s['R']
         if self._use_c() and 'cb' in s:
-            return self._c_shading_backward(a, s, pt, idx, dcolor_rm, flat, d_spec_raw, d_occ_raw)
+            return self._c_shading_backward(a, s, pt, idx, dcolor_rm, flat, d_spec_raw, d_occ_raw, d_mat_raw)
         dMraw, dOLo, dILo, dIWo, dRLo, dNoV = e(P, 8), e(rows_ol, 4), e(2 * P, 4), e(P), e(P, 4), e(P)
         L.check(lib.nu_shade_combine_bwd(c_p(addr(s['Mraw'])), 8, c_p(addr(s['OLo'])), c_p(addr(s['ILo'])),
                                          c_p(addr(s['IWo'])), c_p(addr(s['RLo'])), c_p(addr(s['SD'])),
@@ -1081,6 +1094,8 @@ class Stage1Engine:
                 dOLo[3 * P:].zero_()
         if d_occ_raw is not None:
             dIWo += d_occ_raw
+        if d_mat_raw is not None:
+            dMraw += d_mat_raw
         # heads + hidden stacks of the four light predictors
         ld_ol, ld_rl = self.ld_ol, self.ld_rl
         dOLin, dILin = e(rows_ol, ld_ol), e(2 * P, 128)
@@ -1361,7 +1376,7 @@ class Stage1Engine:
         return out, ctx
 
     def render_backward(self, ctx, d_rgb, d_acc, d_rgb_bg, d_gerr=None, d_spec_raw=None, d_occ_raw=None, d_sdf_in=None,
-                        train_inv_s=False, d_nrm_sum=None):
+                        train_inv_s=False, d_nrm_sum=None, d_trans=None, d_metal=None):
         """Hand-derived backward of render_forward w.r.t. every network parameter.  Returns the flat gradient
         buffer (layout: self.grad_views)."""
         lib, S_ = self.lib, self.stream()
@@ -1389,8 +1404,20 @@ class Stage1Engine:
                                    self.inner_weight + self.refrac_light)
         if P_in > 0:
             a, s = ctx['sdf'], ctx['shade']
+            d_mat = None
+            if d_trans is not None or d_metal is not None:
+                # cotangents of the post-sigmoid transmission weight / metallic (the registry's TransmissionRegLoss and
+                # MetallicRegLoss): d raw = d y * y (1 - y), added to the raw material heads' gradient (columns 5 and 0 of Mraw)
+                aux = s['aux']
+                d_mat = torch.zeros(P_in, 8, device=aux.device)
+                if d_trans is not None:
+                    t = aux[:, 1]
+                    d_mat[:, 5] = d_trans.reshape(-1) * t * (1.0 - t)
+                if d_metal is not None:
+                    m = aux[:, 2]
+                    d_mat[:, 0] = d_metal.reshape(-1) * m * (1.0 - m)
             dYX, dn = self.shading_backward(a, s, ctx['pt_in'], ctx['idx_in'], dcolor_rm, flat,
-                                            d_spec_raw=d_spec_raw, d_occ_raw=d_occ_raw)
+                                            d_spec_raw=d_spec_raw, d_occ_raw=d_occ_raw, d_mat_raw=d_mat)
             nbar = e(P_in, 3)
             var = self.p['deviation_network.variance']
             L.check(lib.nu_neus_alpha_bwd(c_p(addr(a['YX'])), 288, c_p(addr(a['n'])), c_p(addr(ctx['pt_in'])),

@@ -6,6 +6,7 @@ all parameter gradients happen inside the renderer's HIP ops.
 """
 import numpy as np
 import torch
+import torch.nn.functional as F
 
 
 class Loss:
@@ -108,6 +109,45 @@ class MaskLoss(Loss):
         return {}
 
 
+class MaterialRegLoss(Loss):
+    """network/loss.py:51-62: passes `loss_mat_reg` / `loss_diffuse_light` through when the renderer provides them (no shipped
+    renderer does)."""
+
+    def __init__(self, cfg):
+        pass
+
+    def __call__(self, data_pr, data_gt, step, *args, **kwargs):
+        return {k: data_pr[k] for k in ('loss_mat_reg', 'loss_diffuse_light') if k in data_pr}
+
+
+class TransmissionRegLoss(Loss):
+    """network/loss.py:166-177: 0.1 * mean(transmission_weight^2) over the inner points."""
+    default_cfg = {'transmission_reg_loss_weight': 0.1}
+
+    def __init__(self, cfg):
+        self.cfg = {**self.default_cfg, **cfg}
+
+    def __call__(self, data_pr, data_gt, step, *args, **kwargs):
+        if 'transmission' in data_pr:
+            t = data_pr['transmission']
+            return {'loss_trans_reg': F.mse_loss(t, torch.zeros_like(t)) * self.cfg['transmission_reg_loss_weight']}
+        return {}
+
+
+class MetallicRegLoss(Loss):
+    """network/loss.py:179-190: 0.1 * mean(metallic^2) over the inner points."""
+    default_cfg = {'metallic_reg_loss_weight': 0.1}
+
+    def __init__(self, cfg):
+        self.cfg = {**self.default_cfg, **cfg}
+
+    def __call__(self, data_pr, data_gt, step, *args, **kwargs):
+        if 'metallic' in data_pr:
+            m = data_pr['metallic']
+            return {'loss_metal_reg': F.mse_loss(m, torch.zeros_like(m)) * self.cfg['metallic_reg_loss_weight']}
+        return {}
+
+
 class OuterRegLoss(Loss):
     default_cfg = {'outer_reg_loss_weight': 0.5}
 
@@ -116,7 +156,7 @@ class OuterRegLoss(Loss):
 
     def __call__(self, data_pr, data_gt, step, *args, **kwargs):
         if 'color_bkgr' in data_pr and step >= 15000:
-            return {'loss_outer_reg': torch.nn.functional.mse_loss(data_pr['color_bkgr'].flatten(),
+            return {'loss_outer_reg': F.mse_loss(data_pr['color_bkgr'].flatten(),
                                                                    data_pr['color_spec'].flatten())
                     * self.cfg['outer_reg_loss_weight']}
         return {}
@@ -140,6 +180,9 @@ name2loss = {
     'occ': OccLoss,
     'mask': MaskLoss,
     'outer_reg': OuterRegLoss,
+    'mat_reg': MaterialRegLoss,
+    'transmission_reg': TransmissionRegLoss,
+    'metallic_reg': MetallicRegLoss,
     'normal_ori': NormalOrientationLoss,
 }
 

@@ -141,20 +141,24 @@ class _RenderCoreFn(torch.autograd.Function):
         P_in = c['P_in']
         if P_in > 0:
             gerr, spec, occ, sdf_in = out['gradient_error'], out['spec_raw'].clone(), out['occ_raw'].clone(), out['sdf_in'].clone()
+            # transmission weight and metallic of the inner points (post-sigmoid; renderer_zerothick.py:800-802): differentiable
+            # outputs, so that the TransmissionRegLoss / MetallicRegLoss of the registry (network/loss.py:166-192) train the heads
+            trans, metal = out['aux'][:, 1:2].clone(), out['aux'][:, 2:3].clone()
         else:
             gerr = torch.zeros(0, device=dev)
             spec, occ, sdf_in = torch.zeros(o.shape[0], 3, device=dev), torch.zeros(0, device=dev), torch.zeros(0, device=dev)
-        return out['rgb'], out['acc'], out['rgb_bg'], gerr, spec, occ, sdf_in, out['nrm_sum']
+            trans = metal = torch.zeros(0, 1, device=dev)
+        return out['rgb'], out['acc'], out['rgb_bg'], gerr, spec, occ, sdf_in, out['nrm_sum'], trans, metal
 
     @staticmethod
-    def backward(ctx, d_rgb, d_acc, d_rgb_bg, d_gerr, d_spec, d_occ, d_sdf, d_nrm):
+    def backward(ctx, d_rgb, d_acc, d_rgb_bg, d_gerr, d_spec, d_occ, d_sdf, d_nrm, d_trans, d_metal):
         eng, c = ctx.engine, ctx.c
         R = c['R']
         dev = c['alpha_rm'].device
         if d_rgb is None:
             d_rgb = torch.zeros(R, 3, device=dev)
         flat = eng.render_backward(c, d_rgb, d_acc, d_rgb_bg, d_gerr, d_spec, d_occ, d_sdf, train_inv_s=ctx.train_inv_s,
-                                   d_nrm_sum=d_nrm)
+                                   d_nrm_sum=d_nrm, d_trans=d_trans, d_metal=d_metal)
         grads = []
         for n in ctx.names:
             off, shape = eng.grad_views[n]
@@ -456,7 +460,7 @@ class NeROShapeRenderer(nn.Module):
         cfg = self.cfg
         frozen = cfg['freeze_inv_s_step'] is not None and step < cfg['freeze_inv_s_step']
         spec_pts, cand = self._spec_query_points(rays_o, rays_d, z_vals)
-        rgb, acc, rgb_bg, gerr, spec_raw, occ_raw, sdf_in, nrm_sum = _RenderCoreFn.apply(
+        rgb, acc, rgb_bg, gerr, spec_raw, occ_raw, sdf_in, nrm_sum, trans, metal = _RenderCoreFn.apply(
             eng, rays_o, rays_d, z_vals, float(cos_anneal_ratio), not frozen, self._grad_names, spec_pts, *self._grad_params)
         exp_max = eng.exp_max
         if fused and is_train:
@@ -485,10 +489,9 @@ class NeROShapeRenderer(nn.Module):
         outputs['std'] = (1.0 / inv_s) if gerr.numel() else torch.zeros(1, device=rgb.device)
         c = eng.last_ctx
         P_in = c['P_in']
-        if P_in > 0:
-            aux = c['shade']['aux']
-            outputs['transmission'] = aux[:, 1:2]   # logged only by the shipped configs (no gradient path here)
-            outputs['metallic'] = aux[:, 2:3]
+        if P_in > 0:       # (renderer_zerothick.py:800-802; with a gradient path to the material heads: network/loss.py:166-192)
+            outputs['transmission'] = trans
+            outputs['metallic'] = metal
         if step < 1000:
             outputs['sdf_pts'], outputs['sdf_vals'] = self._init_reg_points(eng, c, sdf_in)
         if cfg['apply_occ_loss']:

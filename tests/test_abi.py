@@ -30,7 +30,7 @@ def test_header_declares_the_expected_surface():
         assert must in names
     # network-level entries of SURVEY 8(b) and the fused loss (N1)
     for must in ("nu_sdf_mlp_fwd", "nu_sdf_mlp_normal", "nu_sdf_mlp_bwd", "nu_nerfpp_mlp_fwd", "nu_nerfpp_mlp_bwd", "nu_shading_stack_fwd",
-                 "nu_shading_stack_bwd", "nu_ctx_flush", "nu_loss_fwd", "nu_loss_bwd", "nu_lbvh_build", "nu_lbvh_trace",
+                 "nu_shading_stack_bwd", "nu_ctx_flush", "nu_loss_fwd", "nu_loss_bwd", "nu_sdf_fused_fwd", "nu_lbvh_build", "nu_lbvh_trace",
                  "nu_s2_seg_count", "nu_s2_seg_write", "nu_s2_ddist", "nu_s2_seg_bwd", "nu_s2_composite_fwd", "nu_s2_composite_bwd",
                  "nu_s2_refract_fwd", "nu_s2_refract_bwd", "nu_s2_hit_fwd", "nu_s2_hit_bwd", "nu_s2_far_points", "nu_s2_far_resample",
                  "nu_s2_shade_combine_fwd", "nu_s2_shade_combine_bwd", "nu_s2_neus_alpha_fwd", "nu_s2_neus_alpha_bwd",

@@ -242,6 +242,48 @@ def test_fused_loss_kernels_equal_the_loss_registry(gpu, std):
             assert rel_err(q.grad, p.grad) < 1e-5, (n, rel_err(q.grad, p.grad))
 
 
+def test_material_regularisers_have_a_gradient_path(gpu):
+    """network/loss.py:166-192 (`transmission_reg`, `metallic_reg`; `mat_reg` passes its inputs through): 0.1 * mean(y^2) of the
+    inner points' transmission weight / metallic.  The renderer hands both out as differentiable outputs; values and the
+    gradients they add to the material heads are checked against the CPU oracle, through both loss paths."""
+    from nu_nerf_amd.loss import name2loss, SPHEREPOT_LOSSES, total_loss, fused_stage1_loss
+    g = golden("train_step20000_r48.npz")
+    step = int(g['step'])
+    batch = {k: torch.from_numpy(g[k]).to(gpu) for k in ('rays_o', 'rays_d', 'rgbs')}
+    rand = (torch.from_numpy(g['u1']).to(gpu), torch.from_numpy(g['u2']).to(gpu))
+    names = list(SPHEREPOT_LOSSES) + ['mat_reg', 'transmission_reg', 'metallic_reg']
+    losses = [name2loss[n](CFG) for n in names]
+    P = parity_params(requires_grad=True)
+    from helpers import oracle_cfg
+    ot, oterms, oout = O.train_step(P, oracle_cfg(), torch.from_numpy(g['rays_o']), torch.from_numpy(g['rays_d']), torch.from_numpy(g['rgbs']), step,
+                                    rand=(torch.from_numpy(g['u1']), torch.from_numpy(g['u2'])))
+    o_trans = 0.1 * torch.mean(oout['transmission'] ** 2)
+    o_metal = 0.1 * torch.mean(oout['metallic'] ** 2)
+    (ot + o_trans + o_metal).backward()
+    heads = ['color_network.transmisstion_weight.6.weight_v', 'color_network.metallic_predictor.6.weight_v',
+             'color_network.transmisstion_weight.0.weight_v', 'sdf_network.lin8.weight_v']
+    for fused in (False, True):
+        net = make_net(gpu)
+        if fused:
+            total, log, out = fused_stage1_loss(net, batch, step, losses, rand=rand)
+        else:
+            out = net.train_step_rays(batch, step, rand=rand)
+            total, log = total_loss(out, losses, step)
+        total.backward()
+        np.testing.assert_allclose(float(log['loss_trans_reg'].detach()), float(o_trans.detach()), rtol=2e-5)
+        np.testing.assert_allclose(float(log['loss_metal_reg'].detach()), float(o_metal.detach()), rtol=2e-5)
+        np.testing.assert_allclose(float(total.detach()), float((ot + o_trans + o_metal).detach()), rtol=2e-5)
+        named = dict(net.named_parameters())
+        for n in heads:
+            assert rel_err(named[n].grad.cpu(), P[n].grad) < 2e-3, (fused, n, rel_err(named[n].grad.cpu(), P[n].grad))
+    # without the regularisers the transmission head's gradient is a different one (the path is live, not a constant)
+    net = make_net(gpu)
+    out = net.train_step_rays(batch, step, rand=rand)
+    total, _ = total_loss(out, [name2loss[n](CFG) for n in SPHEREPOT_LOSSES], step)
+    total.backward()
+    assert rel_err(dict(net.named_parameters())[heads[0]].grad.cpu(), P[heads[0]].grad) > 1e-2
+
+
 class _FixedWeightReducer:
     """Stand-in for parallel.GradAllReducer on one process: world 2, this rank holds 70 % of the union's inner points."""
     world = 2

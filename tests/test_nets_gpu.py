@@ -107,3 +107,43 @@ def test_predictor_stack_and_materials(nets, gpu):
     assert rel_err(m.cpu(), torch.cat(raws, -1)) < 1e-5
     (m * cm.to(gpu)).sum().backward()
     assert rel_err(fg.grad.cpu(), fo.grad) < 1e-4 and rel_err(xg.grad.cpu(), xo.grad) < 1e-4
+
+
+@pytest.mark.parametrize("P", [1, 31, 64, 1000, 8192, 20000])
+def test_fused_sdf_forward_is_bit_identical_to_the_layered_path(gpu, P):
+    """csrc/fused_sdf.hip: the no-gradient SDF forward as one kernel (field.py:133-153 + the embedding :47-61 + the skip concat
+    :142-143) -- same MFMA k order, same softplus, same head reduction as the layer-by-layer path, so the results are equal BIT for
+    bit (32- and 64-row tiles, ragged last tile, one point); and equal to a float64 torch evaluation of the network to fp32
+    rounding.  x_ld = 3 (sampler points) and 8 (point records)."""
+    import ctypes
+    from nu_nerf_amd.engine import addr
+    from test_stage1_gpu import make_net
+    net = make_net(gpu)
+    eng = net.engine()
+    eng.pack()
+    torch.manual_seed(P)
+    for x_ld in (3, 8):
+        X = (torch.rand(P, x_ld, device=gpu) * 2 - 1) * 0.9
+        eng._fused_sdf, eng._FUSED_SDF_MAX_POINTS = True, 1 << 30
+        fused = eng.sdf_forward(addr(X), x_ld, P, keep=False, want_feat=False)['sdf'].clone()
+        eng._fused_sdf = False
+        layered = eng.sdf_forward(addr(X), x_ld, P, keep=False, want_feat=False)['sdf'].clone()
+        eng._fused_sdf = True
+        assert torch.equal(fused, layered), float((fused - layered).abs().max())
+    # float64 reference of SDFNetwork.forward with the module's own weights
+    sd = {k: v.detach().double() for k, v in net.state_dict().items() if k.startswith('sdf_network.')}
+    x = X[:, :3].double()
+    emb = [x]
+    for k in range(6):
+        emb += [torch.sin(x * 2.0 ** k), torch.cos(x * 2.0 ** k)]
+    inp = torch.cat(emb, -1)
+    h = inp
+    for l in range(9):
+        v, g, b = (sd[f'sdf_network.lin{l}.{n}'] for n in ('weight_v', 'weight_g', 'bias'))
+        W = g * v / v.norm(dim=1, keepdim=True)
+        if l == 4:
+            h = torch.cat([h, inp], -1) / 2 ** 0.5
+        h = h @ W.t() + b
+        if l < 8:
+            h = torch.nn.functional.softplus(h, beta=100)
+    torch.testing.assert_close(fused.double(), h[:, 0], rtol=2e-5, atol=2e-6)
