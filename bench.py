@@ -334,11 +334,13 @@ def stage1_leg(args, dist_ctx):
     n_iter = args.steps + args.warmup
     # --object-rays: every ray aimed at the unit sphere's interior (inner-point share ~0.5, the survey's 8.1 TFLOP/iter case:
     # SURVEY 8(d)) instead of full camera frusta (share ~0.19: most image rays miss the sphere)
-    pool = (make_object_rays if args.object_rays else make_rays)(R * world * min(n_iter, 16), seed=6033)
+    # (always 16 batches per rank, whatever --steps is: the rays -- and with them the inner / outer point counts of the workload --
+    # must not depend on how long a run is, or a short profiling pass would measure another workload than the timed line)
+    pool = (make_object_rays if args.object_rays else make_rays)(R * world * 16, seed=6033)
     pool_dev = {k: torch.from_numpy(v).to(dev) for k, v in pool.items() if k != 'idxs'}
 
     def batch_for(it):
-        b = (it % min(n_iter, 16)) * world + rank
+        b = (it % 16) * world + rank
         return {k: v[b * R:(b + 1) * R] for k, v in pool_dev.items()}
 
     eng = net.engine()

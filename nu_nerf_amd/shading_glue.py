@@ -1,21 +1,17 @@
-"""Surface shading assembled from the HIP network ops (nets.Stage1Nets): stack inputs (nu_s2_shade_encode_*), the predictor /
-material stacks, the BRDF mix (nu_(s2_)shade_combine_*); the eager torch formulation below serves validation images and the tests.
+"""Surface shading assembled from the HIP network ops (nets.Stage1Nets): ONE path for rendering -- stack inputs
+(nu_s2_shade_encode_*), the predictor / material stacks, the BRDF mix (nu_(s2_)shade_combine_*) -- and the validation
+images of `inter_results=True` (the intermediate terms of the same formulas as O(points) torch glue over the same network
+ops; only test_step renders them).
 
 Used where the fused stage-1 shading kernels do not apply: stage 2 (input gradients needed, ragged per-bounce point
-sets) and validation rendering (intermediate images wanted).  Every MLP GEMM still runs in libnunerf.so.
+sets) and validation rendering (intermediate images wanted).  Every MLP GEMM runs in libnunerf.so.  The eager formulation that
+checks the kernel pairs in the parity tests lives with the tests (tests/eager_shading.py), not here.
 Reference: AppShadingNetwork.forward / predict_specular_lights / predict_diffuse_lights (network/field.py:636-777),
 AppShadingNetwork_S2.forward (field.py:909-1010)."""
-import os
-
 import torch
 import torch.nn.functional as F
 
 from . import torch_glue as G
-
-
-FUSED_COMBINE = True     # False: the eager formulation everywhere (the parity tests' checker)
-# False (or NU_FUSED_ENCODE=0): the stacks' inputs from separate encoding ops + torch glue (checker of nu_s2_shade_encode_*)
-FUSED_ENCODE = os.environ.get('NU_FUSED_ENCODE', '1') != '0'
 
 
 def offset_points_to_sphere(points):
@@ -62,28 +58,42 @@ def lights(nets, exp_max, points, n, refl, rough, sphere=False, detail=False, po
     return lo[:P], light, light0
 
 
-def raw_lights(nets, points, n, refl, rough, sphere=False, pos_freq=6):
-    """Raw (pre-activation) heads of the light predictors, row-batched as `lights` does: outer_light [3P,3], inner_light [2P,3],
-    inner_weight [P,1]."""
-    P = points.shape[0]
-    one, zero = torch.ones_like(rough), torch.zeros_like(rough)
-    enc = torch.cat([G.ide(n, one), G.ide(refl, rough), G.ide(refl, zero)], 0)
-    if sphere:
-        sn, sr = sphere_point(points, n), sphere_point(points, refl)
-        enc_ol = torch.cat([enc, torch.cat([G.ide(sn, one), G.ide(sr, rough), G.ide(sr, rough)], 0)], -1)
-    else:
-        enc_ol = enc
-    ol = nets.predictor('outer_light', enc_ol)
-    pe = G.embed(points, pos_freq)
-    il = nets.predictor('inner_light', torch.cat([torch.cat([pe, enc[P:2 * P]], -1), torch.cat([pe, enc[2 * P:]], -1)], 0))
-    iw = nets.predictor('inner_weight', torch.cat([pe.detach(), G.embed(refl, 6).detach()], -1))
-    return ol, il, iw
-
-
 def shade(nets, scfg, lut, points, normals, view_dirs, feats, s2=False, is_internal=False, inter_results=False, aux=None):
-    """AppShadingNetwork.forward (field.py:684-777) or, with s2=True, AppShadingNetwork_S2.forward (field.py:909-1010).
-    Without inter_results the BRDF mix runs as one HIP kernel pair on the raw head outputs (stage2_ops.shade_combine); the
-    eager formulation below it serves the validation images (inter_results=True)."""
+    """AppShadingNetwork.forward (field.py:684-777) or, with s2=True, AppShadingNetwork_S2.forward (field.py:909-1010): materials ->
+    ONE kernel for every stack's padded input rows (n^, v^, NoV, r, IDE / position / refraction codes, sphere points; gradients to
+    points, normals, view directions and the roughness logit) -> the four stacks -> the BRDF mix as one kernel pair on the raw
+    heads.  inter_results=True (validation images of test_step) returns the intermediate terms as well."""
+    if not points.is_cuda:
+        from ._lib import NuNerfLibraryError
+        raise NuNerfLibraryError("shade needs CUDA(HIP) tensors: there is no CPU fallback for the product path")
+    if inter_results:
+        return _shade_with_images(nets, scfg, lut, points, normals, view_dirs, feats, s2, is_internal)
+    exp_max = scfg['light_exp_max']
+    rl_max = scfg.get('refrac_exp_max', exp_max)
+    pos_freq = int(scfg.get('light_pos_freq', 6))
+    sphere = bool(scfg.get('sphere_direction', False))
+    if points.shape[0] == 0:
+        if aux is not None:
+            aux.update(occ_raw=points.new_zeros(0, 1), reflective=points.new_zeros(0, 3))
+        return points.new_zeros(0, 3), (points.new_zeros(0, 1) if s2 else None)
+    from . import stage2_ops as O
+    m_raw = nets.materials(feats, points)
+    rf = -1 if s2 else int(scfg.get('refrac_freq', 6))
+    OL, IL, IW, RL, nov1, SD = O.shade_encode(nets.eng, points, normals, view_dirs, m_raw, sphere, pos_freq, rf)
+    ol, il, iw = nets.predictor('outer_light', OL), nets.predictor('inner_light', IL), nets.predictor('inner_weight', IW)
+    rl = None
+    if not s2:
+        rl = nets.predictor('refrac_light', RL)
+        if rl_max < exp_max:     # AppShadingNetwork_SpecInner's refrac_light caps at exp(-0.2) (field.py:1373): clamp the raw head,
+            rl = torch.clamp(rl, max=rl_max)     # the kernel's own min(., exp_max) is then the identity
+    if aux is not None:          # what the occlusion probe of the caller needs (occ_info of field.py:1533-1537)
+        aux.update(occ_raw=iw, reflective=SD[:, 8:11])
+    color, rc = O.shade_combine(nets.eng, m_raw, ol, il, iw, rl, nov1[:, None], lut, exp_max, s2=s2, internal=is_internal)
+    return color, (rc if s2 else None)
+
+
+def _shade_with_images(nets, scfg, lut, points, normals, view_dirs, feats, s2, is_internal):
+    """The validation images (field.py:747-770, :984-1003): the shading formulas term by term on the outputs of the network ops."""
     exp_max = scfg['light_exp_max']
     rl_max = scfg.get('refrac_exp_max', exp_max)
     pos_freq = int(scfg.get('light_pos_freq', 6))
@@ -91,38 +101,6 @@ def shade(nets, scfg, lut, points, normals, view_dirs, feats, s2=False, is_inter
     n, v = F.normalize(normals, dim=-1), F.normalize(view_dirs, dim=-1)
     nov = torch.sum(n * v, -1, keepdim=True)
     refl = nov * n * 2 - v
-    if FUSED_COMBINE and FUSED_ENCODE and not inter_results and points.is_cuda and points.shape[0] > 0:
-        # materials -> ONE kernel for every stack's padded input rows (n^, v^, NoV, r, IDE / position / refraction codes, sphere
-        # points) with gradients to points, normals, view directions and the roughness logit -> the four stacks -> BRDF mix
-        from . import stage2_ops as O
-        m_raw = nets.materials(feats, points)
-        rf = -1 if s2 else int(scfg.get('refrac_freq', 6))
-        OL, IL, IW, RL, nov1, SD = O.shade_encode(nets.eng, points, normals, view_dirs, m_raw, sphere, pos_freq, rf)
-        ol, il, iw = nets.predictor('outer_light', OL), nets.predictor('inner_light', IL), nets.predictor('inner_weight', IW)
-        rl = None
-        if not s2:
-            rl = nets.predictor('refrac_light', RL)
-            if rl_max < exp_max:
-                rl = torch.clamp(rl, max=rl_max)
-        if aux is not None:
-            aux.update(occ_raw=iw, reflective=SD[:, 8:11])
-        color, rc = O.shade_combine(nets.eng, m_raw, ol, il, iw, rl, nov1[:, None], lut, exp_max, s2=s2, internal=is_internal)
-        return color, (rc if s2 else None)
-    if FUSED_COMBINE and not inter_results and points.is_cuda and points.shape[0] > 0:
-        from . import stage2_ops as O
-        m_raw = nets.materials(feats, points)
-        rough = torch.sigmoid(m_raw[:, 1:2])
-        ol, il, iw = raw_lights(nets, points, n, refl, rough, sphere, pos_freq)
-        rl = None
-        if not s2:
-            rf = scfg.get('refrac_freq', 6)
-            rl = nets.predictor('refrac_light', torch.cat([G.embed(points, rf), G.embed(v, rf)], -1))
-            if rl_max < exp_max:     # AppShadingNetwork_SpecInner's refrac_light caps at exp(-0.2) (field.py:1373): clamp the raw head,
-                rl = torch.clamp(rl, max=rl_max)     # the kernel's own min(., exp_max) is then the identity
-        if aux is not None:      # what the occlusion probe of the caller needs (occ_info of field.py:1533-1537)
-            aux.update(occ_raw=iw, reflective=refl)
-        color, rc = O.shade_combine(nets.eng, m_raw, ol, il, iw, rl, nov, lut, exp_max, s2=s2, internal=is_internal)
-        return color, (rc if s2 else None)
     m = torch.sigmoid(nets.materials(feats, points))
     metallic, rough, albedo, trans = m[:, 0:1], m[:, 1:2], m[:, 2:5], m[:, 5:6]
     diffuse_light, light, light0, occ, indirect = lights(nets, exp_max, points, n, refl, rough, sphere, detail=True, pos_freq=pos_freq)
@@ -139,18 +117,14 @@ def shade(nets, scfg, lut, points, normals, view_dirs, feats, s2=False, is_inter
         color = base + (fres * light0) * trans
         if is_internal:
             color = color * 0
-        if inter_results:      # the validation images of the first surface (field.py:984-1003)
-            c01 = lambda x: torch.clamp(x, 0.0, 1.0)
-            inter = {'specular_ref': c01(spec_ref), 'specular_light': c01(G.linear_to_srgb(light0)),
-                     'specular_color': c01(G.linear_to_srgb(spec_color) * (1 - trans) + fres * light0 * trans)}
-            return G.linear_to_srgb(color), (1 - fres) * trans, inter
-        return G.linear_to_srgb(color), (1 - fres) * trans
+        c01 = lambda x: torch.clamp(x, 0.0, 1.0)       # the validation images of the first surface (field.py:984-1003)
+        inter = {'specular_ref': c01(spec_ref), 'specular_light': c01(G.linear_to_srgb(light0)),
+                 'specular_color': c01(G.linear_to_srgb(spec_color) * (1 - trans) + fres * light0 * trans)}
+        return G.linear_to_srgb(color), (1 - fres) * trans, inter
     rf = scfg.get('refrac_freq', 6)
     refrac = torch.exp(torch.clamp(nets.predictor('refrac_light', torch.cat([G.embed(points, rf), G.embed(v, rf)], -1)),
                                    max=min(exp_max, rl_max)))
     color = G.linear_to_srgb(base + (fres * light0 + (1 - fres) * refrac) * trans)
-    if not inter_results:
-        return color, None
     c01 = lambda x: torch.clamp(x, 0.0, 1.0)
     spec_color_srgb = G.linear_to_srgb(spec_color)
     inter = {   # field.py:747-770 (specular_color mixes the sRGB specular term with a linear one, as the reference does)

@@ -1,17 +1,10 @@
-"""Small differentiable torch helpers used by the FIRST stage-2 implementation (nu_nerf_amd/stage2.py).
-
-Stage 2's ragged per-bounce bookkeeping and its element-wise glue (encodings, BRDF mix, segment composites) run as torch
-ops on the GPU in this round; every MLP contraction goes through the HIP library (nu_nerf_amd/nets.py).  Fusing this glue
-into HIP kernels with hand-derived input gradients -- as stage 1 already does -- is the next step for this path.
-Formulas cite the reference (paths relative to its repository root).
+"""autograd wrappers of the encoding kernels (get_embedder, integrated directional encoding) and the few O(points) torch
+helpers the stage-2 / validation code shares (sRGB transfer, the split-sum LUT lookup of the validation images, the
+weight-normed linear of the parameter-holder modules).  There is no CPU fallback: the encodings raise on tensors that are
+not on the GPU, like every other op of the product path.  Formulas cite the reference (paths relative to its repository root).
 """
-import math
-
-import numpy as np
 import torch
 import torch.nn.functional as F
-
-from .params import load_fg_lut  # noqa: F401
 
 
 class _EmbedFn(torch.autograd.Function):
@@ -91,55 +84,30 @@ class _EmbedNFn(torch.autograd.Function):
         return dx, None
 
 
+def _require_cuda(t, what):
+    if not t.is_cuda:
+        from ._lib import NuNerfLibraryError
+        raise NuNerfLibraryError(f"{what} needs a CUDA(HIP) tensor: there is no CPU fallback for the product path")
+
+
 def embed(x, n_freq):
-    """network/field.py:14-61.  CUDA tensors [P,3] run on the HIP kernels (6 frequencies and fewer through the SDF path's
-    embedding, up to 10 through the generic pair)."""
-    if x.is_cuda and x.dim() == 2 and x.shape[1] == 3 and x.shape[0] > 0:
-        if n_freq <= 6:
-            return _EmbedFn.apply(x, n_freq)
-        if n_freq <= 10:
-            return _EmbedNFn.apply(x, n_freq)
-    out = [x]
-    for k in range(n_freq):
-        f = float(2 ** k)
-        out.append(torch.sin(x * f))
-        out.append(torch.cos(x * f))
-    return torch.cat(out, -1)
-
-
-_IDE_CACHE = {}
-
-
-def _ide_tables(device):
-    if device not in _IDE_CACHE:
-        ml = [(m, 2 ** i) for i in range(5) for m in range(2 ** i + 1)]
-        mat = np.zeros((17, len(ml)))
-        for i, (m, l) in enumerate(ml):
-            for k in range(l - m + 1):
-                binom = np.prod(0.5 * (l + k + m - 1.0) - np.arange(l)) / math.factorial(l)
-                leg = (-1) ** m * 2 ** l * math.factorial(l) / math.factorial(k) / math.factorial(l - k - m) * binom
-                mat[k, i] = math.sqrt((2.0 * l + 1.0) * math.factorial(l - m) / (4.0 * math.pi * math.factorial(l + m))) * leg
-        _IDE_CACHE[device] = (torch.tensor([m for m, _ in ml], device=device), torch.tensor([float(l) for _, l in ml], device=device),
-                              torch.from_numpy(mat.astype(np.float32)).to(device))
-    return _IDE_CACHE[device]
+    """get_embedder(n_freq, 3) (network/field.py:14-61) of points [P,3] on the HIP kernels: 6 frequencies and fewer through the
+    SDF path's embedding kernel, up to 10 through the generic pair; input gradient included."""
+    _require_cuda(x, "embed")
+    if x.dim() != 2 or x.shape[1] != 3 or n_freq > 10:
+        raise ValueError("embed: expects [P, 3] points and at most 10 frequencies")
+    if x.shape[0] == 0:
+        return x.new_zeros(0, 3 + 6 * n_freq)
+    return _EmbedFn.apply(x, n_freq) if n_freq <= 6 else _EmbedNFn.apply(x, n_freq)
 
 
 def ide(xyz, kappa_inv):
-    """utils/ref_utils.py:84-114 in real arithmetic: (x+iy)^m by repeated multiplication, polynomial in z, vMF attenuation.
-    CUDA tensors [P,3] / [P,1] run on the HIP kernels."""
-    if xyz.is_cuda and xyz.dim() == 2 and xyz.shape[0] > 0:
-        return _IdeFn.apply(xyz, kappa_inv.expand(xyz.shape[0], 1))
-    m, l, mat = _ide_tables(xyz.device)
-    x, y, z = xyz[..., 0:1], xyz[..., 1:2], xyz[..., 2:3]
-    zp = torch.cat([torch.ones_like(z)] + [z ** i for i in range(1, 17)], -1)
-    re, im = [torch.ones_like(x)], [torch.zeros_like(x)]
-    for _ in range(16):
-        re.append(re[-1] * x - im[-1] * y)
-        im.append(re[-2] * y + im[-1] * x)
-    re, im = torch.cat(re, -1)[..., m], torch.cat(im, -1)[..., m]
-    poly = zp @ mat
-    att = torch.exp(-0.5 * l * (l + 1) * kappa_inv)
-    return torch.cat([re * poly * att, im * poly * att], -1)
+    """Integrated directional encoding (utils/ref_utils.py:84-114) of directions [P,3] with roughness [P,1] on the HIP kernels
+    (nu_ide / nu_ide_bwd)."""
+    _require_cuda(xyz, "ide")
+    if xyz.shape[0] == 0:
+        return xyz.new_zeros(0, 72)
+    return _IdeFn.apply(xyz, kappa_inv.expand(xyz.shape[0], 1))
 
 
 def linear_to_srgb(x):
@@ -163,26 +131,6 @@ def lut_bilinear_clamp(lut, uv):
     top = lut[y0, x0] * (1 - tx) + lut[y0, x1] * tx
     bot = lut[y1, x0] * (1 - tx) + lut[y1, x1] * tx
     return top * (1 - ty) + bot * ty
-
-
-def sample_pdf_det(bins, weights, n):
-    """field.py:468-498 with det=True."""
-    w = weights + 1e-5
-    pdf = w / torch.sum(w, -1, keepdim=True)
-    cdf = torch.cat([torch.zeros_like(pdf[..., :1]), torch.cumsum(pdf, -1)], -1)
-    u = torch.linspace(0.5 / n, 1.0 - 0.5 / n, steps=n, device=bins.device).expand(list(cdf.shape[:-1]) + [n]).contiguous()
-    idx = torch.searchsorted(cdf, u, right=True)
-    lo, hi = torch.clamp(idx - 1, min=0), torch.clamp(idx, max=cdf.shape[-1] - 1)
-    c_lo, c_hi = torch.gather(cdf, -1, lo), torch.gather(cdf, -1, hi)
-    b_lo, b_hi = torch.gather(bins, -1, lo), torch.gather(bins, -1, hi)
-    den = c_hi - c_lo
-    den = torch.where(den < 1e-5, torch.ones_like(den), den)
-    return b_lo + (u - c_lo) / den * (b_hi - b_lo)
-
-
-def cumprod_excl(alpha):
-    ones = torch.ones_like(alpha[..., :1])
-    return torch.cumprod(torch.cat([ones, 1. - alpha + 1e-7], -1), -1)
 
 
 def wn_linear(x, lin):

@@ -17,8 +17,16 @@ def agg(path, name):
     return out
 
 fetch_csv, write_csv, out_json = sys.argv[1:4]
+bench_json = sys.argv[4] if len(sys.argv) > 4 else None      # the bench line printed by the profiled run: records the workload
 f, w = agg(fetch_csv, 'FETCH_SIZE'), agg(write_csv, 'WRITE_SIZE')
 res = {}
+if bench_json:
+    b = json.loads(open(bench_json).read().strip().splitlines()[-1])
+    c = b['config']
+    # what bench.py matches a later run against before it quotes these numbers as that run's `roofline.traffic`
+    res['workload_record'] = {"rays": c['rays_per_gpu'], "real_capture": 'real-capture' in c['workload'], "mlp_dtype": {'f32': 'fp32', 'bf16': 'bf16'}.get(b['dtype'], b['dtype']),
+                              "bf16_storage": b['dtype'] == 'bf16', "mean_inner_points": c['mean_inner_points'],
+                              "mean_outer_points": c['mean_outer_points'], "steps": b['steps'], "warmup": b['warmup']}
 for k in f:
     n = f[k][0]
     res[k] = {"launches": n, "fetch_bytes_per_launch": 2.0 * 1024 * f[k][1] / n, "write_bytes_per_launch": 1024 * w[k][1] / max(w[k][0], 1),

@@ -91,3 +91,23 @@ def check_ray_store_against_reference_fixture(device):
         np.testing.assert_allclose(v.cpu().numpy(), g['real_' + k], rtol=2e-6, atol=1e-6, err_msg=k)
     np.testing.assert_array_equal(poses2.cpu().numpy(), g['real_poses'])
     return info
+
+
+def sample_pdf_det(bins, weights, n):
+    """field.py:468-498 with det=True (test-side eager formulation)."""
+    w = weights + 1e-5
+    pdf = w / torch.sum(w, -1, keepdim=True)
+    cdf = torch.cat([torch.zeros_like(pdf[..., :1]), torch.cumsum(pdf, -1)], -1)
+    u = torch.linspace(0.5 / n, 1.0 - 0.5 / n, steps=n, device=bins.device).expand(list(cdf.shape[:-1]) + [n]).contiguous()
+    idx = torch.searchsorted(cdf, u, right=True)
+    lo, hi = torch.clamp(idx - 1, min=0), torch.clamp(idx, max=cdf.shape[-1] - 1)
+    c_lo, c_hi = torch.gather(cdf, -1, lo), torch.gather(cdf, -1, hi)
+    b_lo, b_hi = torch.gather(bins, -1, lo), torch.gather(bins, -1, hi)
+    den = c_hi - c_lo
+    den = torch.where(den < 1e-5, torch.ones_like(den), den)
+    return b_lo + (u - c_lo) / den * (b_hi - b_lo)
+
+
+def cumprod_excl(alpha):
+    ones = torch.ones_like(alpha[..., :1])
+    return torch.cumprod(torch.cat([ones, 1. - alpha + 1e-7], -1), -1)

@@ -5,6 +5,8 @@ import pytest
 import torch
 import torch.nn.functional as F
 
+from helpers import cumprod_excl, sample_pdf_det
+
 pytestmark = pytest.mark.gpu
 
 
@@ -32,7 +34,7 @@ def test_segment_composite_matches_torch(gpu):
         g1, g2 = torch.randn_like(out), torch.randn_like(Tend)
         ga, gc, gT = torch.autograd.grad((out * g1).sum() + (Tend * g2).sum(), (alpha, col, T))
         lin = G.srgb_to_linear(col[..., :3])
-        cpx = G.cumprod_excl(alpha)
+        cpx = cumprod_excl(alpha)
         w = alpha * cpx[:, :-1]
         ref, Tref = (lin * w[..., None]).sum(1) * T, T * cpx[:, -1:]
         ra, rc, rT = torch.autograd.grad((ref * g1).sum() + (Tref * g2).sum(), (alpha, col, T))
@@ -176,8 +178,8 @@ def test_far_importance_nodes_match_the_eager_formulation(gpu):
         dists = torch.cat([dists, dists[..., -1:]], -1)
         alpha, _ = net._density_alpha(n1, pts.reshape(-1, 3), dists.reshape(-1), dm[:, None, :].expand(-1, 192, 3).reshape(-1, 3))
         alpha = alpha.reshape(M, 192)
-        w = alpha * G.cumprod_excl(alpha)[:, :-1]
-        newz = G.sample_pdf_det(zo2.contiguous(), w[:, :-1], 64)
+        w = alpha * cumprod_excl(alpha)[:, :-1]
+        newz = sample_pdf_det(zo2.contiguous(), w[:, :-1], 64)
         ref = torch.sort(torch.cat([zo2, newz], -1), dim=-1)[0]
     assert z.shape == ref.shape and bool((z[:, 1:] >= z[:, :-1]).all())
     # the 192 coarse nodes are reproduced exactly; the 64 inverse-CDF samples to the rounding of the running sums
@@ -186,9 +188,10 @@ def test_far_importance_nodes_match_the_eager_formulation(gpu):
 
 @pytest.mark.parametrize("s2,internal", [(True, False), (True, True), (False, False)])
 def test_fused_brdf_mix_matches_the_eager_shading(gpu, s2, internal):
-    """shade() with the BRDF mix on nu_(s2_)shade_combine_* against the eager torch formulation of AppShadingNetwork(_S2).forward:
-    colour, (1 - F) T, and the gradients w.r.t. points, normals, view directions, features and every parameter."""
-    from nu_nerf_amd import shading_glue as SG
+    """The BRDF mix on nu_(s2_)shade_combine_* against the eager torch formulation of AppShadingNetwork(_S2).forward (the test-side
+    checker tests/eager_shading.py): colour, (1 - F) T, and the gradients w.r.t. points, normals, view directions, features and every
+    parameter."""
+    from eager_shading import shade_eager
     net, n1 = _eng(gpu)
     s1c = net.stage1_network.color_network
     torch.manual_seed(41)
@@ -198,19 +201,13 @@ def test_fused_brdf_mix_matches_the_eager_shading(gpu, s2, internal):
     gcol, grc = torch.randn(P, 3, device=gpu), torch.randn(P, 1, device=gpu)
     params = [p for p in net.stage1_network.color_network.parameters() if p.requires_grad]
     res = {}
-    for fused in (True, False):
-        SG.FUSED_COMBINE = fused
-        SG.FUSED_ENCODE = False       # the stacks' inputs from the same separate ops on both sides: this test is about the mix
-        try:
-            n1.begin_pass()
-            ins = [t.clone().requires_grad_(True) for t in base]
-            color, rc = SG.shade(n1, s1c.cfg, s1c.FG_LUT, ins[0], ins[1], ins[2], ins[3], s2=s2, is_internal=internal)
-            loss = (color * gcol).sum() + ((rc * grc).sum() if s2 else 0.0)
-            grads = torch.autograd.grad(loss, ins + params, allow_unused=True)
-            res[fused] = (color.detach(), rc.detach() if s2 else None, grads)
-        finally:
-            SG.FUSED_COMBINE = True
-            SG.FUSED_ENCODE = True
+    for fused in (True, False):      # the stacks' inputs from the same separate ops on both sides: this test is about the mix
+        n1.begin_pass()
+        ins = [t.clone().requires_grad_(True) for t in base]
+        color, rc = shade_eager(n1, s1c.cfg, s1c.FG_LUT, ins[0], ins[1], ins[2], ins[3], s2=s2, is_internal=internal, fused_combine=fused)
+        loss = (color * gcol).sum() + ((rc * grc).sum() if s2 else 0.0)
+        grads = torch.autograd.grad(loss, ins + params, allow_unused=True)
+        res[fused] = (color.detach(), rc.detach() if s2 else None, grads)
     torch.testing.assert_close(res[True][0], res[False][0], rtol=1e-5, atol=1e-6)
     if s2:
         torch.testing.assert_close(res[True][1], res[False][1], rtol=1e-5, atol=1e-6)
@@ -372,6 +369,7 @@ def test_fused_shade_encode_matches_the_separate_encoding_ops(gpu, which):
     2 refraction frequencies, sphere directions), the plain inner shader (6 / 6, no sphere directions); points inside and outside
     radius 0.999 (the sphere-point offset branch), normals and view directions of arbitrary length."""
     from nu_nerf_amd import shading_glue as SG
+    from eager_shading import shade_eager
     if which == "inner_plain":
         net, _ = _eng(gpu)
         nets, ccfg, lut, s2 = net.nets()[1], net.color_network_inner.cfg, net.color_network_inner.FG_LUT, False
@@ -396,17 +394,16 @@ def test_fused_shade_encode_matches_the_separate_encoding_ops(gpu, which):
     gcol, grc = torch.randn(P, 3, device=gpu), torch.randn(P, 1, device=gpu)
     res = {}
     for fused in (True, False):
-        SG.FUSED_ENCODE = fused
-        try:
-            nets.begin_pass()
-            ins = [t.clone().requires_grad_(True) for t in base]
-            aux = {}
+        nets.begin_pass()
+        ins = [t.clone().requires_grad_(True) for t in base]
+        aux = {}
+        if fused:       # the product path
             color, rc = SG.shade(nets, ccfg, lut, ins[0], ins[1], ins[2], ins[3], s2=s2, aux=aux)
-            loss = (color * gcol).sum() + ((rc * grc).sum() if s2 else 0.0) + (aux['occ_raw'] * grc).sum()
-            grads = torch.autograd.grad(loss, ins + params, allow_unused=True)
-            res[fused] = (color.detach(), rc.detach() if s2 else None, aux['reflective'].detach(), grads)
-        finally:
-            SG.FUSED_ENCODE = True
+        else:           # the separate encoding ops + torch glue it replaces (tests/eager_shading.py)
+            color, rc = shade_eager(nets, ccfg, lut, ins[0], ins[1], ins[2], ins[3], s2=s2, aux=aux, fused_combine=True)
+        loss = (color * gcol).sum() + ((rc * grc).sum() if s2 else 0.0) + (aux['occ_raw'] * grc).sum()
+        grads = torch.autograd.grad(loss, ins + params, allow_unused=True)
+        res[fused] = (color.detach(), rc.detach() if s2 else None, aux['reflective'].detach(), grads)
     # Integration-level tolerances: the two paths round the reflected direction differently (kernel FMA vs torch ops, 1e-7), and
     # the degree-16 terms of the directional encoding amplify that by ~1e4 in fp32 on either side (their Legendre coefficients
     # reach 1e5); the tight checks of the kernel pair itself are in test_shade_encode_kernels_vs_float64.
@@ -445,7 +442,8 @@ def test_shade_encode_kernels_vs_float64(gpu, sphere, pos_freq, rf):
     OL, IL, IW, RL, nov, SD = O.shade_encode(eng, *ins, sphere, pos_freq, rf)
     # ---- float64 reference ----
     xd, nd, vd, md = (t.double().requires_grad_(True) for t in (x, nrm, view, m_raw))
-    mt, lt, mat = G._ide_tables(torch.device('cpu'))
+    from oracle.stage1_oracle import _IDE_ML, _IDE_MAT        # (m, l) list and coefficient matrix of the IDE (ref_utils.py:7-79)
+    mt, lt, mat = torch.from_numpy(_IDE_ML[:, 0]).long(), torch.from_numpy(_IDE_ML[:, 1]), torch.from_numpy(_IDE_MAT)
 
     def ide64(d, kinv):
         xx, yy, zz = d[..., 0:1], d[..., 1:2], d[..., 2:3]
