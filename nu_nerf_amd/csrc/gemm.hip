@@ -1394,6 +1394,11 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(NuGemmTN g) {
     const int b_off = (wc * 64 + li) * NT_LDS + 4 * lh;
     const int ah_off = (wr * 64 + li) * NT_LDSH + 8 * lh;
     const int bh_off = (wc * 64 + li) * NT_LDSH + 8 * lh;
+    // which of the wave's four 32 x 32 blocks hold at least one real output (wave-uniform)
+    const int wr_u = __builtin_amdgcn_readfirstlane(wr), wc_u = __builtin_amdgcn_readfirstlane(wc);
+    const bool vr0 = n1_0 + wr_u * 64 < g.N1, vr1 = n1_0 + wr_u * 64 + 32 < g.N1;
+    const bool vc0 = n2_0 + wc_u * 64 < g.N2, vc1 = n2_0 + wc_u * 64 + 32 < g.N2;
+    const bool v00 = vr0 && vc0, v01 = vr0 && vc1, v10 = vr1 && vc0, v11 = vr1 && vc1;
     for (int t = 0; t < total; ++t) {
         if (t + 1 < total) load_tile(t + 1);
         if (SPLIT) {
@@ -1442,12 +1447,14 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(NuGemmTN g) {
                 const f32x4 a1 = *reinterpret_cast<const f32x4*>(&As[a_off + 32 * NT_LDS + kk * 8]);
                 const f32x4 b0 = *reinterpret_cast<const f32x4*>(&Bs[b_off + kk * 8]);
                 const f32x4 b1 = *reinterpret_cast<const f32x4*>(&Bs[b_off + 32 * NT_LDS + kk * 8]);
+                // (32 x 32 blocks that lie wholly in the padding of N1 / N2 -- 288 = 2 x 128 + 32, 96, 217, 257 = 2 x 128 + 1 -- are
+                // skipped, wave-uniformly: their slab entries are never read)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b0[e], acc[0][0], 0, 0, 0);
-                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b1[e], acc[0][1], 0, 0, 0);
-                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b0[e], acc[1][0], 0, 0, 0);
-                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b1[e], acc[1][1], 0, 0, 0);
+                    if (v00) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b0[e], acc[0][0], 0, 0, 0);
+                    if (v01) acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b1[e], acc[0][1], 0, 0, 0);
+                    if (v10) acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b0[e], acc[1][0], 0, 0, 0);
+                    if (v11) acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b1[e], acc[1][1], 0, 0, 0);
                 }
             }
         }

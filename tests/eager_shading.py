@@ -8,6 +8,16 @@ from nu_nerf_amd import torch_glue as G
 from nu_nerf_amd.shading_glue import lights, sphere_point
 
 
+def embed_eager(x, n_freq):
+    """get_embedder(n_freq, d) (network/field.py:14-61) in plain torch ops, any device / dtype: the float64 reference of the tests."""
+    out = [x]
+    for k in range(n_freq):
+        f = float(2 ** k)
+        out.append(torch.sin(x * f))
+        out.append(torch.cos(x * f))
+    return torch.cat(out, -1)
+
+
 def raw_lights(nets, points, n, refl, rough, sphere=False, pos_freq=6):
     """Raw (pre-activation) heads of the light predictors, row-batched as `lights` does: outer_light [3P,3], inner_light [2P,3],
     inner_weight [P,1]."""

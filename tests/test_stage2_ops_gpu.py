@@ -466,10 +466,11 @@ def test_shade_encode_kernels_vs_float64(gpu, sphere, pos_freq, rf):
         sn, sr = SG.sphere_point(xd, n), SG.sphere_point(xd, refl)
         enc = [torch.cat([enc[0], ide64(sn, one)], -1), torch.cat([enc[1], ide64(sr, rho)], -1), torch.cat([enc[2], ide64(sr, rho)], -1)]
     OL_r = torch.cat(enc, 0)
-    pe = G.embed(xd, pos_freq)
+    from eager_shading import embed_eager
+    pe = embed_eager(xd, pos_freq)
     IL_r = torch.cat([torch.cat([pe, ide64(refl, rho)], -1), torch.cat([pe, ide64(refl, zero)], -1)], 0)
-    IW_r = torch.cat([pe, G.embed(refl, 6)], -1)
-    RL_r = torch.cat([G.embed(xd, rf), G.embed(v, rf)], -1) if rf >= 0 else None
+    IW_r = torch.cat([pe, embed_eager(refl, 6)], -1)
+    RL_r = torch.cat([embed_eager(xd, rf), embed_eager(v, rf)], -1) if rf >= 0 else None
     # fp32 Horner evaluation of a term's polynomial in z carries eps * sum_k |c_k| of absolute error: the degree-16 terms have
     # coefficient sums up to 1e5, so their columns are compared (and, below, differentiated) with that conditioning in mind
     kappa = mat.double().abs().sum(0)                                       # [36] per term
