@@ -46,7 +46,8 @@ __device__ unsigned long long nu_dbg_clk[2];
 #define NU_LAB_TILES 6
 __device__ unsigned long long nu_lab_trace[1024][NU_LAB_TILES][3];   // [wg][tile]{main-loop start, main-loop end, epilogue end} 100 MHz
 __device__ unsigned nu_lab_hwid[1024][2];
-__device__ int nu_lab_skip_epi;      // 1: store nothing in the epilogue (pure main loop + tile switch)
+__device__ int nu_lab_stagger_ticks; // > 0: the second half of the grid starts this many 10 ns ticks late (gen 2)
+__device__ int nu_lab_skip_epi;      // epilogue ablation: 1 scratch writes only, 2 no global stores, 3 nothing, 4 stores to an L2-resident region
 static int nu_lab_grid = 0;          // persistent grid size override (0: default)
 static int nu_lab_v1 = 0;            // 1: first-generation fp32 NT kernel
 static int nu_lab_small = -1;        // 64-row tiles: -1 library rule, 0 never, 1 always (gen 2)
@@ -141,7 +142,7 @@ static __device__ inline unsigned long long* nt_mask_words(const NtEpiArgs<EPI>&
 template <int EPI, int NBH, bool H16 = false, int TMN = 2>
 static __device__ __forceinline__ void nt_epilogue(const NuGemmNT& g, const NtEpiArgs<EPI>& ea, f32x16 (&acc)[TMN][2], float* scr,
                                                    int m0, int n0, unsigned long long* mwave, unsigned mlo, unsigned mhi,
-                                                   int lane, int wid, bool lab_skip, int tm0 = 0) {
+                                                   int lane, int wid, int lab_skip, int tm0 = 0) {
     typedef NtEpiArgs<EPI> E;
     constexpr bool kMaskW = E::kMaskW, kMaskR = E::kMaskR, kNeedH = E::kNeedH, kNeedD = E::kNeedD, kNeedAdd = E::kNeedAdd, kBias = E::kBias;
     float* const C = ea.C; float* const C2 = ea.C2;
@@ -182,12 +183,16 @@ static __device__ __forceinline__ void nt_epilogue(const NuGemmNT& g, const NtEp
 #pragma unroll
     for (int tt = 0; tt < TMN; ++tt) {
         const int tm = tm0 + tt;
+        if (lab_skip == 3) {                                           // lab: not even the scratch writes
+            if (acc[tt][0][0] == 123.456f) C[0] = acc[tt][1][3];
+            continue;
+        }
 #pragma unroll
         for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 scr[((r & 3) + 8 * (r >> 2) + 4 * lh) * EPI_LDS + tn * 32 + li] = acc[tt][tn][r];
-        if (lab_skip) {
+        if (lab_skip == 1) {
             if (acc[tt][0][0] == 123.456f) C[0] = acc[tt][1][3];      // keeps the accumulators live
         } else if (slab_full) {
             // wave-uniform fast path (every interior tile): straight-line code, no per-lane guards; the auxiliary loads of
@@ -208,7 +213,7 @@ static __device__ __forceinline__ void nt_epilogue(const NuGemmNT& g, const NtEp
 #pragma unroll
                 for (int ii = 0; ii < NB; ++ii) {
                     const int i = hb * NB + ii;
-                    const long long roff = (long long)(tm * 32 + i * 4);
+                    const long long roff = (long long)((lab_skip == 4 ? 0 : tm * 32) + i * 4);    // lab 4: a small, cache-resident target
                     f32x4 o4, o24;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -223,8 +228,12 @@ static __device__ __forceinline__ void nt_epilogue(const NuGemmNT& g, const NtEp
                                                                    (kNeedAdd && !slab_plain) ? c4v[ii][e] : 0.f, o2);
                         o24[e] = o2;
                     }
-                    nt_st4<H16>(Cu + roff * g.ldc * ec + oC, o4, c16);
-                    if (kNeedD) nt_st4<H16>(C2u + roff * g.ldc2 * ec + oC2, o24, c16);
+                    if (lab_skip == 2) {                               // lab: scratch round trip and math, no global store
+                        if (o4[0] == 123.456f && o24[1] == 3.f) C[0] = o4[1];
+                    } else {
+                        nt_st4<H16>(Cu + roff * g.ldc * ec + oC, o4, c16);
+                        if (kNeedD) nt_st4<H16>(C2u + roff * g.ldc2 * ec + oC2, o24, c16);
+                    }
                     if (kMaskW && mwave) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
@@ -529,9 +538,9 @@ __global__ __launch_bounds__(256, PREC == 2 ? 2 : NT_WPC) void gemm_nt_kernel(Nu
 
 #ifdef NU_LAB
         if (tid == 0 && blockIdx.x < 1024 && lab_tile < NU_LAB_TILES) nu_lab_trace[blockIdx.x][lab_tile][1] = wall_clock64();
-        const bool lab_skip = nu_lab_skip_epi != 0;
+        const int lab_skip = nu_lab_skip_epi;
 #else
-        constexpr bool lab_skip = false;
+        constexpr int lab_skip = 0;
 #endif
         // ---- epilogue ----
         nt_epilogue<EPI, 2>(g, ea, acc, &smem[0][0] + wid * (32 * EPI_LDS), m0, n0, mwave, mlo, mhi, lane, wid, lab_skip);
@@ -682,6 +691,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt2_kernel(NuGemmNT g) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) load_piece(i);
     advance();
+#ifdef NU_LAB
+    if (nu_lab_stagger_ticks > 0 && blockIdx.x >= (gridDim.x >> 1)) {      // lab only: phase-shift the second half of the grid
+        const unsigned long long t0 = wall_clock64();
+        while (wall_clock64() - t0 < (unsigned long long)nu_lab_stagger_ticks) __builtin_amdgcn_s_sleep(64);
+    }
+#endif
     __syncthreads();
     Frag F0, F1;
     read_frag(F0, 0, 0);
@@ -776,12 +791,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt2_kernel(NuGemmNT g) {
 #undef NT2_MFMA8
 #ifdef NU_LAB
         if (tid == 0 && blockIdx.x < 1024 && lab_tile < NU_LAB_TILES) nu_lab_trace[blockIdx.x][lab_tile][1] = wall_clock64();
-        const bool lab_skip = nu_lab_skip_epi != 0;
+        const int lab_skip = nu_lab_skip_epi;
 #else
-        constexpr bool lab_skip = false;
+        constexpr int lab_skip = 0;
 #endif
         // ---- epilogue: the stage consumed last (cur ^ 1 after the flip) is free until the next chunk's hand-over ----
-        nt_epilogue<EPI, 4, false, TMN>(g, ea, acc, &smem[(cur ^ 1) * NT2_STAGE] + wid * (32 * EPI_LDS), m0, n0, mwave, mlo, mhi, lane, slab, lab_skip, tm0);
+        nt_epilogue<EPI, 4, false, TMN>(g, ea, acc, &smem[(cur ^ 1) * NT2_STAGE] + wid * (32 * EPI_LDS), lab_skip == 4 ? (int)(blockIdx.x >> 1) * TBM : m0, n0, mwave, mlo, mhi, lane, slab, lab_skip, tm0);
 #ifdef NU_LAB
         if (tid == 0 && blockIdx.x < 1024 && lab_tile < NU_LAB_TILES) nu_lab_trace[blockIdx.x][lab_tile][2] = wall_clock64();
         ++lab_tile;

@@ -133,6 +133,78 @@ int main(int argc, char** argv) {
         }
         nu_lab_grid = 0; nu_lab_v1 = 0;
         set_int(nu_lab_skip_epi, 0);
+    } else if (!strcmp(mode, "levels")) {
+        // which part of the epilogue costs the launch its 11-14 %?  0: all of it; 2: scratch round trip + math, no global stores;
+        // 1: scratch writes only; 3: nothing; 4: all of it, but every workgroup stores to (and reads its auxiliary operands from) one
+        // small region that stays in L2
+        for (int i = 0; i < 3; ++i) time_nt(b256, NU_EPI_PLAIN, 10);
+        for (int pass = 0; pass < 2; ++pass)
+        for (int gen : {2})
+        for (int lvl : {0, 4, 2, 1, 3}) {
+            set_int(nu_lab_skip_epi, lvl);
+            double r[10];
+            int i = 0;
+            for (int epi : {NU_EPI_PLAIN, NU_EPI_BIAS_RELU, NU_EPI_BIAS_SOFTPLUS, NU_EPI_MUL_DSP, NU_EPI_Q_SP}) r[i++] = tf(b256, time_nt(b256, epi, 20));
+            r[i++] = tf(b1024, time_nt(b1024, NU_EPI_PLAIN, 20));
+            printf("gen %d skip level %d : M=540k K=256 plain %6.1f relu %6.1f softplus %6.1f dsp %6.1f q_sp %6.1f | K=1024 %6.1f\n",
+                   gen, lvl, r[0], r[1], r[2], r[3], r[4], r[5]);
+        }
+        set_int(nu_lab_skip_epi, 0);
+    } else if (!strcmp(mode, "msweep")) {
+        // 128- against 64-row tiles of the second-generation kernel by row count, K = 256 (the 16-deep-stage, three-workgroups-per-CU
+        // kernel of profiles/r03/gen4_16deep_3wg_nt_kernel.patch was the third column of profiles/r03/lab_row_count_sweep_*.txt)
+        for (int i = 0; i < 3; ++i) time_nt(b256, NU_EPI_PLAIN, 10);
+        for (int pass = 0; pass < 2; ++pass)
+        for (int m : {8192, 16384, 32768, 49152, 67456, 90112, 114048, 135168, 163840, 200704, 270336, 540672}) {
+            Bufs b = b256;
+            b.M = m;
+            double r[2][3];
+            for (int v = 0; v < 2; ++v) {
+                nu_lab_small = v;
+                int i = 0;
+                for (int epi : {NU_EPI_BIAS_RELU, NU_EPI_BIAS_SOFTPLUS, NU_EPI_MUL_DSP}) r[v][i++] = tf(b, time_nt(b, epi, m < 100000 ? 80 : 30));
+            }
+            printf("M %7d : relu / softplus / dsp   128-row %6.1f %6.1f %6.1f | 64-row %6.1f %6.1f %6.1f\n", m,
+                   r[0][0], r[0][1], r[0][2], r[1][0], r[1][1], r[1][2]);
+        }
+        nu_lab_small = -1;
+    } else if (!strcmp(mode, "pairs")) {
+        // do the two workgroups of a CU run their epilogues at the same time?  Phase stamps (100 MHz) of co-resident pairs
+        // (blocks b and b + 256), relative to the launch's first stamp, with and without a start-up stagger
+        static unsigned long long tr[1024][NU_LAB_TILES][3];
+        for (int stag : {0, 1800}) {
+            set_int(nu_lab_stagger_ticks, stag);
+            nu_lab_grid = 512;
+            for (int epi : {NU_EPI_PLAIN, NU_EPI_BIAS_SOFTPLUS}) {
+                const double ms = time_nt(b256, epi, 3);
+                CK(hipMemcpyFromSymbol(tr, HIP_SYMBOL(nu_lab_trace), sizeof(tr)));
+                unsigned long long t0 = ~0ull;
+                for (int w = 0; w < 512; ++w) t0 = tr[w][0][0] < t0 ? tr[w][0][0] : t0;
+                printf("stagger %d ticks, epi %d: %.1f TFLOP/s\n", stag, epi, tf(b256, ms));
+                double both = 0, either = 0;
+                for (int b = 0; b < 256; ++b) {
+                    // overlap of the two workgroups' epilogue intervals over tiles 1..5, as a share of their epilogue time
+                    for (int t = 1; t < NU_LAB_TILES; ++t)
+                        for (int u = 1; u < NU_LAB_TILES; ++u) {
+                            const double a0 = (double)(tr[b][t][1] - t0), a1 = (double)(tr[b][t][2] - t0);
+                            const double c0 = (double)(tr[b + 256][u][1] - t0), c1 = (double)(tr[b + 256][u][2] - t0);
+                            const double lo = a0 > c0 ? a0 : c0, hi = a1 < c1 ? a1 : c1;
+                            if (hi > lo) both += hi - lo;
+                        }
+                    for (int t = 1; t < NU_LAB_TILES; ++t) either += (double)(tr[b][t][2] - tr[b][t][1]);
+                }
+                printf("  epilogue time of a workgroup that coincides with its CU partner's epilogue: %.1f %%\n", 100.0 * both / either);
+                for (int b : {0, 1, 37}) {
+                    printf("  pair (%d, %d) us since launch [main start, main end, epilogue end] per tile:\n", b, b + 256);
+                    for (int w : {b, b + 256}) {
+                        printf("    block %3d:", w);
+                        for (int t = 0; t < NU_LAB_TILES; ++t) printf("  %6.1f %6.1f %6.1f |", (tr[w][t][0] - t0) * 0.01, (tr[w][t][1] - t0) * 0.01, (tr[w][t][2] - t0) * 0.01);
+                        printf("\n");
+                    }
+                }
+            }
+        }
+        set_int(nu_lab_stagger_ticks, 0); nu_lab_grid = 0;
     } else if (!strcmp(mode, "small")) {
         // 64-row tiles (gen 2, TMN = 1) against 128-row tiles on point sets that do not fill the chip
         for (int i = 0; i < 3; ++i) time_nt(b256, NU_EPI_PLAIN, 10);
@@ -231,6 +303,9 @@ int main(int argc, char** argv) {
     } else {
         // traced launches: mean main-loop / epilogue duration per tile (tiles 1..5 of every workgroup), by grid size and epilogue
         static unsigned long long tr[1024][NU_LAB_TILES][3];
+        const int lvl = argc > 2 ? atoi(argv[2]) : 0;
+        set_int(nu_lab_skip_epi, lvl);
+        printf("epilogue ablation level %d\n", lvl);
         for (int grid : {256, 512}) {
             for (int epi : {NU_EPI_PLAIN, NU_EPI_BIAS_SOFTPLUS, NU_EPI_MUL_DSP, NU_EPI_Q_SP}) {
                 nu_lab_grid = grid;
