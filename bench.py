@@ -379,7 +379,7 @@ def stage1_leg(args, dist_ctx):
     bracketed = []
     if not args.no_kernel_timing:
         bracketed = [args.steps // 2] if args.time_every <= 0 else [i for i in range(args.steps) if i % args.time_every == 0]
-        eng.begin_kernel_timing(reserve=2 * 200 * len(bracketed))
+        eng.begin_kernel_timing(reserve=2 * 360 * len(bracketed), py_reserve=2 * 40 * len(bracketed))
     gc.collect()
     gc.disable()          # no collector pause inside the timed region (a full collection stalls the launch thread)
     t0 = time.perf_counter()

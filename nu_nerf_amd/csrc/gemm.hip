@@ -696,6 +696,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt2_kernel(NuGemmNT g) {
         const unsigned long long t0 = wall_clock64();
         while (wall_clock64() - t0 < (unsigned long long)nu_lab_stagger_ticks) __builtin_amdgcn_s_sleep(64);
     }
+    if (nu_lab_stagger_ticks < 0) {      // lab only: 16 start-up phases across the CUs of an XCD (workgroups b and b + 8 land on one XCD)
+        const unsigned long long t0 = wall_clock64(), d = (unsigned long long)(-nu_lab_stagger_ticks) * ((blockIdx.x >> 3) & 15);
+        while (wall_clock64() - t0 < d) __builtin_amdgcn_s_sleep(16);
+    }
 #endif
     __syncthreads();
     Frag F0, F1;

@@ -168,6 +168,18 @@ int main(int argc, char** argv) {
                    r[0][0], r[0][1], r[0][2], r[1][0], r[1][1], r[1][2]);
         }
         nu_lab_small = -1;
+    } else if (!strcmp(mode, "custagger")) {
+        // all 256 first-dispatched workgroups reach their epilogues together: does spreading the store bursts over a tile time help?
+        for (int i = 0; i < 3; ++i) time_nt(b256, NU_EPI_PLAIN, 10);
+        for (int pass = 0; pass < 2; ++pass)
+        for (int stag : {0, -60, -120, -225, -450}) {
+            set_int(nu_lab_stagger_ticks, stag);
+            double r[8];
+            int i = 0;
+            for (int epi : {NU_EPI_PLAIN, NU_EPI_BIAS_RELU, NU_EPI_BIAS_SOFTPLUS, NU_EPI_MUL_DSP}) r[i++] = tf(b256, time_nt(b256, epi, 20));
+            printf("16 phases of %4d ticks (10 ns): M=540k K=256 plain %6.1f relu %6.1f softplus %6.1f dsp %6.1f\n", -stag, r[0], r[1], r[2], r[3]);
+        }
+        set_int(nu_lab_stagger_ticks, 0);
     } else if (!strcmp(mode, "pairs")) {
         // do the two workgroups of a CU run their epilogues at the same time?  Phase stamps (100 MHz) of co-resident pairs
         // (blocks b and b + 256), relative to the launch's first stamp, with and without a start-up stagger
