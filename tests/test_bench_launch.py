@@ -27,3 +27,30 @@ def test_bare_multi_gpu_request_without_enough_devices_is_refused():
         pytest.skip("box has >= 2 GPUs: the bare launch would really run")
     r = _run(['--gpus', '2', '--steps', '1', '--warmup', '0'], {})
     assert r.returncode == 2 and 'needs 2 visible GPUs' in r.stderr and '"metric"' not in r.stdout
+
+
+def test_sum_rule_raises_when_gemm_time_exceeds_the_bracketed_step():
+    """bench.py's consistency rule: launch times bracketed on the launch stream may not add up to more than the wall
+    time of the step they were taken in."""
+    import pytest
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    ok = bench.check_sum_rule("leg", 0.0400, 45.0)
+    assert ok["ok"] and abs(ok["gemm_ms_in_bracketed_step"] - 40.0) < 1e-9
+    with pytest.raises(bench.SumRuleError):
+        bench.check_sum_rule("leg", 0.0460, 45.0)
+
+
+def test_traffic_is_quoted_only_for_a_matching_profile():
+    """roofline.traffic comes from a committed PMC pass only when that pass recorded this workload: same configuration, mean
+    point counts within 5 %."""
+    import json
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    rec = json.load(open(os.path.join(bench.ROOT, 'profiles', 'r03', 'traffic_pmc.json')))['workload_record']
+    pi, po = rec['mean_inner_points'], rec['mean_outer_points']
+    nt, tn, src = bench.find_traffic_profile(rec['rays'], 1, rec['real_capture'], rec['mlp_dtype'], False, rec['bf16_storage'], pi * 1.03, po * 0.98)
+    assert nt and tn and src.endswith('traffic_pmc.json')
+    assert bench.find_traffic_profile(rec['rays'], 1, rec['real_capture'], rec['mlp_dtype'], False, rec['bf16_storage'], pi * 1.08, po) == (None, None, None)
+    assert bench.find_traffic_profile(rec['rays'], 2, rec['real_capture'], rec['mlp_dtype'], False, rec['bf16_storage'], pi, po) == (None, None, None)
+    assert bench.find_traffic_profile(512, 1, rec['real_capture'], rec['mlp_dtype'], False, rec['bf16_storage'], pi, po) == (None, None, None)
