@@ -46,7 +46,7 @@ def tn(P, N1, N2, pairs, S):
     print(f"TN  P={P:7d} N1={N1:4d} N2={N2:4d} pairs={pairs} S={S:4d}: {ms*1e3:8.1f} us  {2.0*P*N1*N2*pairs/ms/1e9:6.1f} TFLOP/s")
 
 
-if __name__ == "__main__":
+if __name__ == "__main__":  # noqa
     for epi in (7, 0, 1, 2, 3, 4, 5, 6):
         nt(262144, 256, 256, epi)
     nt(262144, 256, 1024, 7)
