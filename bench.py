@@ -284,10 +284,9 @@ def find_traffic_profile(R, world, real_capture, mlp_dtype, object_rays, h16, p_
     prof = os.path.join(ROOT, 'profiles')
     cands = []
     for rnd in sorted(os.listdir(prof), reverse=True) if os.path.isdir(prof) else []:
-        for name in ('traffic_pmc.json', 'traffic_pmc_config4.json'):
-            f = os.path.join(prof, rnd, name)
-            if os.path.exists(f):
-                cands.append(f)
+        for name in sorted(os.listdir(os.path.join(prof, rnd))) if os.path.isdir(os.path.join(prof, rnd)) else []:
+            if name.startswith('traffic_pmc') and name.endswith('.json'):
+                cands.append(os.path.join(prof, rnd, name))
     for f in cands:
         try:
             d = json.load(open(f))
