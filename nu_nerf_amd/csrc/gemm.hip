@@ -2130,7 +2130,10 @@ static bool nu_tn_big_tile(int N1, int N2, int groups, int prec, int S) {
 // The split both launch paths use: enough workgroups for the chip, as few and as large slabs as possible.
 extern "C" int nu_wgrad_pick_split(int P, int N1, int N2, int groups, int prec) {
     if (groups < 1) groups = 1;
-    const int cap = (P + 255) / 256 > 0 ? (P + 255) / 256 : 1;
+    // at least 256 reduced rows per split -- 128 for the few-thousand-row point sets of the small batches, where the launch is
+    // latency-bound and twice the workgroups are worth the extra slabs (7 168 rows: 31.8 -> 25.0 us, profiles/r03/bench_tn_small.txt)
+    const int rows_min = P <= 8192 ? 128 : 256;
+    const int cap = (P + rows_min - 1) / rows_min > 0 ? (P + rows_min - 1) / rows_min : 1;
     if ((N1 % 256) == 0 && (N2 % 256) == 0) {
         int S = 256 / ((N1 / 256) * (N2 / 256) * groups);
         if (S < 1) S = 1;
