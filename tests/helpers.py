@@ -111,3 +111,13 @@ def sample_pdf_det(bins, weights, n):
 def cumprod_excl(alpha):
     ones = torch.ones_like(alpha[..., :1])
     return torch.cumprod(torch.cat([ones, 1. - alpha + 1e-7], -1), -1)
+
+
+import os as _os
+import pytest as _pytest
+
+# Properties asserted for the exact-fp32 arithmetic (bit identity across sequencing paths / batch composition, summation-tree
+# tolerances calibrated on fp32 MFMA products).  NU_MLP_DTYPE=bf16x6|bf16 runs the whole suite in another arithmetic mode
+# (scripts/README.md): the reference-golden comparisons still apply there, these do not.
+exact_fp32_only = _pytest.mark.skipif(_os.environ.get('NU_MLP_DTYPE', 'fp32') != 'fp32',
+                                      reason='property of the exact-fp32 arithmetic; NU_MLP_DTYPE selects another mode')

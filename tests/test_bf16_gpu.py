@@ -3,11 +3,14 @@
 The reference has no bf16 mode, so there is no reference vector to pin this against: the checker is the same step on the
 exact-fp32 HIP path (itself pinned against the reference's golden vectors in test_stage1_gpu.py), with the tolerance
 SURVEY 8(d) proposes for this config declared here: per-ray RGB within 2e-2 absolute."""
+import os
 import numpy as np
 import pytest
 import torch
 
-pytestmark = pytest.mark.gpu
+# bf16 storage exists in the network-level C entries only (the default path); a whole-suite run with NU_PY_SEQ=1 skips this file
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(os.environ.get('NU_PY_SEQ') == '1', reason='launch-by-launch sequencing has no bf16-storage mode')]
 
 
 def _step(gpu, mlp_dtype, R=512, step=20000):

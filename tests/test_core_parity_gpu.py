@@ -5,11 +5,12 @@ oracle/gen_golden_r2.py from the reference's own run of the three golden train s
 REFERENCE's z_vals, so the inverse-CDF sampler's last-bit sensitivity (tests/test_stage1_gpu.py::test_sampler_matches_oracle)
 is out of the picture and every per-sample output -- and the gradients -- can be held to 1e-4.
 """
+import os
 import numpy as np
 import pytest
 import torch
 
-from helpers import golden, parity_params, rel_err
+from helpers import golden, parity_params, rel_err, exact_fp32_only
 from oracle import stage1_oracle as O
 from test_stage1_gpu import CFG, make_net
 
@@ -123,6 +124,7 @@ def test_occ_loss_subsample_branch_vs_reference(gpu):
     np.testing.assert_allclose(float(out3['loss_occ'].detach()), float(g['out_loss_occ']), rtol=5e-2)
 
 
+@exact_fp32_only
 def test_full_size_backward_sub_batch_property_and_oracle_spot_check(gpu):
     """BASELINE configs[1] size (4096 rays x 160 samples), BACKWARD: the gradient of a loss that only looks at 100 rays of the
     full batch equals the gradient of the same loss on those 100 rays rendered alone (exercises the 2 GiB slab arena, the
@@ -239,7 +241,10 @@ def test_fused_loss_kernels_equal_the_loss_registry(gpu, std):
     for (n, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
         assert (p.grad is None) == (q.grad is None), n
         if p.grad is not None:
-            assert rel_err(q.grad, p.grad) < 1e-5, (n, rel_err(q.grad, p.grad))
+            # (the two assemblies round the upstream gradients differently; a whole-suite run with NU_MLP_DTYPE=bf16x6 sees that
+            # difference through the split products too: 1.6e-5 on one NeRF++ weight)
+            tol = 4e-5 if os.environ.get('NU_MLP_DTYPE') == 'bf16x6' else 1e-5
+            assert rel_err(q.grad, p.grad) < tol, (n, rel_err(q.grad, p.grad))
 
 
 def test_material_regularisers_have_a_gradient_path(gpu):
@@ -320,6 +325,7 @@ def test_fused_loss_with_the_data_parallel_point_weight(gpu):
             assert rel_err(q.grad, p.grad) < 1e-5, (n, rel_err(q.grad, p.grad))
 
 
+@exact_fp32_only
 @pytest.mark.parametrize("py_seq", [False, True])
 def test_full_arena_flushes_in_one_stream_mode_and_fails_closed_when_forked(gpu, monkeypatch, py_seq):
     """The split-reduction arena is shared by everything an engine enqueues.  When it (or the descriptor table) fills in the
@@ -377,6 +383,7 @@ def test_full_arena_flushes_in_one_stream_mode_and_fails_closed_when_forked(gpu,
     torch.cuda.synchronize()
 
 
+@exact_fp32_only
 def test_network_level_c_entries_equal_launch_by_launch_sequencing(gpu):
     """nu_sdf_mlp_*, nu_nerfpp_mlp_*, nu_shading_stack_* sequence the same kernels in the same order as the
     launch-by-launch Python path (engine.py_seq): outputs and every gradient are bit-identical."""
@@ -399,7 +406,8 @@ def test_network_level_c_entries_equal_launch_by_launch_sequencing(gpu):
         assert torch.equal(res[0][2][n], res[1][2][n]), n
 
 
-@pytest.mark.parametrize("mlp_dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("mlp_dtype", ["fp32", pytest.param("bf16", marks=pytest.mark.skipif(
+    os.environ.get('NU_PY_SEQ') == '1', reason='launch-by-launch sequencing has no bf16-storage mode'))])
 def test_gradients_are_bitwise_reproducible(gpu, mlp_dtype):
     """No float atomics anywhere on the path: two evaluations of one step give bit-identical outputs and gradients for every
     parameter, incl. d variance (a sum over all inner points: per-block partials added in index order by the block that finishes

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import golden, rel_err
+from helpers import golden, rel_err, exact_fp32_only
 
 pytestmark = pytest.mark.gpu
 
@@ -151,6 +151,7 @@ def test_stage2_validation_render_vs_reference_golden(gpu):
     assert ev['ray_rgb'].shape == (24, 24, 3) and ev['normal'].shape == (576, 3) and torch.isfinite(ev['ray_rgb']).all()
 
 
+@exact_fp32_only
 @pytest.mark.parametrize("thick", [False, True])
 def test_stage2_full_size_config3_properties(gpu, thick):
     """BASELINE.json configs[2] at its full size -- 4096 rays against a 20 480-face mesh, both stage-2 models: thousands of rays
