@@ -269,8 +269,7 @@ def stage2_leg(args):
     us = 1e3 * e0.elapsed_time(e1) / 20
     res["lbvh_trace"] = {"rays": R, "faces": int(net.scene.bvh.n_faces), "us_per_launch": us, "rays_per_s": R / us * 1e6,
                          "algorithmic_GBps": R * 32 / us / 1e3, "hit_fraction": float(hit.mean()),
-                         "note": "at 4096 rays the launch is latency-bound (one wave per 64 rays on 256 CUs); scripts/bench_lbvh.py "
-                                 "reports 1.8-4.2 G rays/s at 2^20 rays"}
+                         "note": "closest hit with four lanes per ray over 4-wide records (lbvh_trace_quad_kernel); a launch lasts as long as its longest chain of dependent record fetches (profiles/r03/lbvh_bench.txt: 2.7-5.0 G rays/s at 2^20 rays)"}
     return res
 
 

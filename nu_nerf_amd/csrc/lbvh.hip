@@ -5,8 +5,9 @@
 //   raygen: one closest-hit trace per ray, tmin = 0, tmax = 1e16, no face culling
 //   miss  : (hit, index) = (0.0, 10000000)      closesthit: (1.0, primitive index)
 // Build = Morton codes of triangle centroids -> sort -> Karras 2012 radix-tree hierarchy -> bottom-up
-// AABB refit.  Traversal = one ray per lane, per-lane stack kept in LDS (wavefront-interleaved so a push/pop
-// is conflict-free), near child first.
+// AABB refit -> 4-wide records (each node's grandchildren).  Traversal = four lanes per ray over the 4-wide records, one
+// stack per ray in LDS, nearest entry first (lbvh_trace_quad_kernel); the one-ray-per-lane kernel over the binary nodes
+// (per-lane stack in LDS, wavefront-interleaved) is kept behind NU_LBVH_QUAD=0.
 //
 // Hit indices are defined bit-exactly against the brute-force oracle (oracle/lbvh_oracle.py): the
 // ray/triangle test below is written with explicit single-rounding fp32 operations in a fixed order, ties in t go
@@ -36,8 +37,16 @@ struct NuBvhHeader {
 
 // ---- memory layout inside the caller's buffer -------------------------------------------------
 static __host__ __device__ inline long long nu_align256(long long x) { return (x + 255) / 256 * 256; }
+// 4-wide view of the same tree (one record per binary internal node: its grandchildren, or a child that is a leaf), traversed
+// by the small-batch kernel with four lanes per ray.  Entry = 32 bytes: box, child reference.
+#define NU_WIDE_EMPTY ((int)0x80000000)
+struct NuBvhWideEntry {
+    float bmin[3], bmax[3];
+    int ref;                 // >= 0: internal node index (its wide record); < 0: leaf, sorted position = -1 - value; NU_WIDE_EMPTY: unused
+    int pad;
+};
 struct NuBvhLayout {
-    long long header, keys, nodes, leaf_parent, counters, tris, ids, bounds_i, total;
+    long long header, keys, nodes, leaf_parent, counters, tris, ids, bounds_i, wide, total;
 };
 static __host__ __device__ inline NuBvhLayout nu_bvh_layout(int n) {
     int npad = 1;
@@ -52,6 +61,7 @@ static __host__ __device__ inline NuBvhLayout nu_bvh_layout(int n) {
     L.tris = o; o = nu_align256(o + (long long)n * 48);      // 3 vertices x (x,y,z,pad)
     L.ids = o; o = nu_align256(o + (long long)n * 4);
     L.bounds_i = o; o = nu_align256(o + 32);
+    L.wide = o; o = nu_align256(o + (long long)(n > 1 ? n - 1 : 1) * 4 * sizeof(NuBvhWideEntry));
     L.total = o;
     return L;
 }
@@ -243,6 +253,37 @@ __global__ __launch_bounds__(256) void lbvh_bitonic_local_kernel(unsigned long l
     for (int t = threadIdx.x; t < tile; t += 256) keys[base + t] = sk[t];
 }
 
+// 4-wide records: node i -> the children of its two children (a child that is a leaf stands for itself); after the refit
+__global__ void lbvh_widen_kernel(int n, char* buf, NuBvhLayout L) {
+    const NuBvhNode* nodes = (const NuBvhNode*)(buf + L.nodes);
+    NuBvhWideEntry* wide = (NuBvhWideEntry*)(buf + L.wide);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1) return;
+    const NuBvhNode nd = nodes[i];
+    NuBvhWideEntry e[4];
+    int ne = 0;
+    auto put = [&](const float* bmin, const float* bmax, int ref) {
+        for (int k = 0; k < 3; ++k) { e[ne].bmin[k] = bmin[k]; e[ne].bmax[k] = bmax[k]; }
+        e[ne].ref = ref; e[ne].pad = 0;
+        ++ne;
+    };
+    for (int side = 0; side < 2; ++side) {
+        const int c = side ? nd.right : nd.left;
+        if (c < 0) {
+            put(side ? nd.rmin : nd.lmin, side ? nd.rmax : nd.lmax, c);
+        } else {
+            const NuBvhNode nc = nodes[c];
+            put(nc.lmin, nc.lmax, nc.left);
+            put(nc.rmin, nc.rmax, nc.right);
+        }
+    }
+    for (; ne < 4; ) {
+        const float lo[3] = {1e30f, 1e30f, 1e30f}, hi[3] = {-1e30f, -1e30f, -1e30f};
+        put(lo, hi, NU_WIDE_EMPTY);
+    }
+    for (int k = 0; k < 4; ++k) wide[i * 4LL + k] = e[k];
+}
+
 extern "C" int nu_lbvh_build(const float* V, int n_verts, const int* F, int n_faces, void* bvh, long long bvh_bytes,
                              hipStream_t stream) {
     if (n_faces <= 0 || n_verts <= 0) return NU_ERR_ARG;
@@ -271,6 +312,7 @@ extern "C" int nu_lbvh_build(const float* V, int n_verts, const int* F, int n_fa
     if (n_faces > 1) {
         hipLaunchKernelGGL(lbvh_hierarchy_kernel, dim3(nu_cdiv(n_faces - 1, T)), dim3(T), 0, stream, n_faces, buf, L);
         hipLaunchKernelGGL(lbvh_refit_kernel, dim3(nu_cdiv(n_faces, T)), dim3(T), 0, stream, n_faces, buf, L);
+        hipLaunchKernelGGL(lbvh_widen_kernel, dim3(nu_cdiv(n_faces - 1, T)), dim3(T), 0, stream, n_faces, buf, L);
     }
     return nu_launch_status();
 }
@@ -359,7 +401,13 @@ __global__ __launch_bounds__(RPW == 64 ? 256 : 64) void lbvh_trace_kernel(const 
     } else {
         int sp = 0;
         int node = 0;
+#ifdef NU_LBVH_STATS
+        int steps = 0;
+#endif
         while (true) {
+#ifdef NU_LBVH_STATS
+            ++steps;
+#endif
             const NuBvhNode nd = nodes[node];
             float tl, tr;
             // inclusive in best_t: an equal-t hit with a lower face id must still be found
@@ -385,6 +433,9 @@ __global__ __launch_bounds__(RPW == 64 ? 256 : 64) void lbvh_trace_kernel(const 
             }
             node = next;
         }
+#ifdef NU_LBVH_STATS
+        best_t = (float)steps; found = true;
+#endif
     }
     if (overflow && STACK < NU_STACK) { hit[r] = -1.0f; return; }      // incomplete: the second pass re-traces this ray
     hit[r] = found ? 1.0f : 0.0f;
@@ -392,10 +443,149 @@ __global__ __launch_bounds__(RPW == 64 ? 256 : 64) void lbvh_trace_kernel(const 
     if (tout) tout[r] = found ? best_t : 0.0f;
 }
 
+// ------------------------------------------------------------------------------------------------
+// FOUR lanes per ray over the 4-wide records (16 rays per single-wave workgroup).  A traversal is a chain of dependent fetches --
+// a launch of 4 096 rays lasts as long as its longest chain (56 records at ~0.7 us; the average ray visits 13) -- so the lever
+// is fewer and shorter links: the four lanes of a ray test the four entries of a wide record at once
+// (two binary levels per fetch), leaf entries are intersected by the lanes that hold them, the hits are ordered inside the
+// quad with DPP quad permutes and the ray's stack (one per quad, in LDS) takes the farther ones.  Closest hit, ties in t to the
+// lowest face id, the same box and triangle tests as the one-lane-per-ray kernel: identical (hit, index, t).
+// ------------------------------------------------------------------------------------------------
+#define NU_WSTACK 96            // <= 3 pushes per wide level, <= 31 wide levels (a Morton tree over 62-bit keys)
+template <int CTRL> static __device__ __forceinline__ int nu_quad_i(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false);
+}
+template <int CTRL> static __device__ __forceinline__ float nu_quad_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+#define NU_QP_XOR1 0xB1         // quad_perm:[1,0,3,2]
+#define NU_QP_XOR2 0x4E         // quad_perm:[2,3,0,1]
+#define NU_QP_XOR3 0x1B         // quad_perm:[3,2,1,0]
+__global__ __launch_bounds__(64) void lbvh_trace_quad_kernel(const char* __restrict__ buf, NuBvhLayout L, const float* __restrict__ rays,
+                                                             int N, float tmin, float tmax, float* __restrict__ hit,
+                                                             int* __restrict__ idx, float* __restrict__ tout) {
+    __shared__ int stack[NU_WSTACK][16];
+    const int lane = threadIdx.x & 63, sub = lane & 3, q = lane >> 2;
+    const int r = blockIdx.x * 16 + q;
+    if (r >= N) return;                                    // whole quads leave together
+    const NuBvhHeader* h = (const NuBvhHeader*)(buf + L.header);
+    const NuBvhWideEntry* wide = (const NuBvhWideEntry*)(buf + L.wide);
+    const float* tris = (const float*)(buf + L.tris);
+    const int* ids = (const int*)(buf + L.ids);
+    const int n = h->n_faces;
+    float o[3], d[3], invd[3];
+    for (int k = 0; k < 3; ++k) { o[k] = rays[r * 6LL + k]; d[k] = rays[r * 6LL + 3 + k]; invd[k] = 1.0f / d[k]; }
+    float best_t = tmax;
+    int best_id = NU_MISS_INDEX;
+    int found = 0;
+
+    // candidate of this lane -> best of the quad -> the ray's running best (every lane of the quad holds the same triple)
+    auto merge = [&](int cf, float ct, int ci) {
+#define NU_BETTER(f2, t2, i2) ((f2) && (!cf || (t2) < ct || ((t2) == ct && (i2) < ci)))
+        { const int f2 = nu_quad_i<NU_QP_XOR1>(cf); const float t2 = nu_quad_f<NU_QP_XOR1>(ct); const int i2 = nu_quad_i<NU_QP_XOR1>(ci);
+          if (NU_BETTER(f2, t2, i2)) { cf = 1; ct = t2; ci = i2; } }
+        { const int f2 = nu_quad_i<NU_QP_XOR2>(cf); const float t2 = nu_quad_f<NU_QP_XOR2>(ct); const int i2 = nu_quad_i<NU_QP_XOR2>(ci);
+          if (NU_BETTER(f2, t2, i2)) { cf = 1; ct = t2; ci = i2; } }
+#undef NU_BETTER
+        if (cf && (!found || ct < best_t || (ct == best_t && ci < best_id))) { best_t = ct; best_id = ci; found = 1; }
+    };
+    auto test_leaf = [&](int pos, int& cf, float& ct, int& ci) {
+        const float* tp = tris + pos * 12LL;
+        float t;
+        if (nu_ray_tri(o, d, tp, tp + 4, tp + 8, tmin, tmax, t)) { cf = 1; ct = t; ci = ids[pos]; }
+    };
+
+    if (n == 1) {
+        int cf = 0, ci = NU_MISS_INDEX;
+        float ct = 0.f;
+        if (sub == 0) test_leaf(0, cf, ct, ci);
+        merge(cf, ct, ci);
+    } else {
+        int sp = 0;
+#ifdef NU_LBVH_STATS
+        int steps = 0;
+#endif
+        // The loop is arranged so that the two fetches of a step -- the triangle of a leaf entry that was hit, the next record --
+        // are in flight TOGETHER: the triangle is requested, the next record is chosen (that needs the box distances only) and
+        // requested, and only then is the triangle intersected.  The running best it may improve prunes from the next record on.
+        NuBvhWideEntry e = wide[sub];
+        while (true) {
+#ifdef NU_LBVH_STATS
+            ++steps;
+#endif
+            float tn;
+            // inclusive in best_t: an equal-t hit with a lower face id must still be found
+            const bool hb = e.ref != NU_WIDE_EMPTY && nu_ray_box(o, invd, e.bmin, e.bmax, tmin, best_t, tn);
+            const bool leaf = hb && e.ref < 0;
+            const int pos = leaf ? -1 - e.ref : 0;
+            float tv[9];
+            int tid = NU_MISS_INDEX;
+            if (leaf) {
+#pragma unroll
+                for (int v = 0; v < 3; ++v)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) tv[v * 3 + k] = tris[pos * 12LL + v * 4 + k];
+                tid = ids[pos];
+            }
+            // internal entries that were hit: nearest first, the others on the ray's stack (farthest deepest)
+            const int want = (hb && e.ref >= 0) ? 1 : 0;
+            int rank = 0, cnt = want;
+            { const int w2 = nu_quad_i<NU_QP_XOR1>(want); const float t2 = nu_quad_f<NU_QP_XOR1>(tn); const int s2 = sub ^ 1;
+              cnt += w2; rank += (w2 && (t2 < tn || (t2 == tn && s2 < sub))) ? 1 : 0; }
+            { const int w2 = nu_quad_i<NU_QP_XOR2>(want); const float t2 = nu_quad_f<NU_QP_XOR2>(tn); const int s2 = sub ^ 2;
+              cnt += w2; rank += (w2 && (t2 < tn || (t2 == tn && s2 < sub))) ? 1 : 0; }
+            { const int w2 = nu_quad_i<NU_QP_XOR3>(want); const float t2 = nu_quad_f<NU_QP_XOR3>(tn); const int s2 = sub ^ 3;
+              cnt += w2; rank += (w2 && (t2 < tn || (t2 == tn && s2 < sub))) ? 1 : 0; }
+            int next = (want && rank == 0) ? e.ref : -1;
+            next = max(next, nu_quad_i<NU_QP_XOR1>(next));
+            next = max(next, nu_quad_i<NU_QP_XOR2>(next));
+            if (want && rank > 0) stack[sp + (cnt - 1 - rank)][q] = e.ref;
+            sp += cnt > 0 ? cnt - 1 : 0;
+            bool done = false;
+            if (cnt == 0) {
+                // (measured and dropped: keeping the box distance beside each stacked record and skipping, at the pop, what the
+                // running best has overtaken -- 12.9 -> 11.2 records per ray on average, but the longest chain of a batch, which
+                // is what a launch waits for, stays at 56 records and the pop loop costs more than it saves: 38.8 -> 44.1 us)
+                if (sp == 0) done = true;
+                else next = stack[--sp][q];
+            }
+            NuBvhWideEntry e2 = e;
+            if (!done) e2 = wide[next * 4LL + sub];
+            // the leaf entries of THIS record
+            int cf = 0, ci = NU_MISS_INDEX;
+            float ct = 0.f;
+            if (leaf) {
+                float t;
+                if (nu_ray_tri(o, d, tv, tv + 3, tv + 6, tmin, tmax, t)) { cf = 1; ct = t; ci = tid; }
+            }
+            merge(cf, ct, ci);
+            if (done) break;
+            e = e2;
+        }
+#ifdef NU_LBVH_STATS
+        best_t = (float)steps; found = 1;                  // development build: t_out reports the number of records visited
+#endif
+    }
+    if (sub == 0) {
+        hit[r] = found ? 1.0f : 0.0f;
+        idx[r] = best_id;
+        if (tout) tout[r] = found ? best_t : 0.0f;
+    }
+}
+
 extern "C" int nu_lbvh_trace(const void* bvh, int n_faces, const float* rays, int N, float tmin, float tmax, float* hit,
                              int* idx, float* t_out, hipStream_t stream) {
     if (N <= 0) return NU_OK;
     const NuBvhLayout L = nu_bvh_layout(n_faces);
+    // the four-lanes-per-ray kernel is the default at every batch size (4 096 rays: 75 -> 39 us object-aimed, 49 -> 32 us camera rays;
+    // 2^20 rays: 1.82 -> 2.67 and 4.22 -> 4.96 G rays/s; profiles/r03/lbvh_bench.txt); NU_LBVH_QUAD=0 selects the one-lane-per-ray
+    // kernels below (development A/B)
+    static const int quad_env = getenv("NU_LBVH_QUAD") ? atoi(getenv("NU_LBVH_QUAD")) : 1;
+    if (quad_env != 0) {
+        hipLaunchKernelGGL(lbvh_trace_quad_kernel, dim3(nu_cdiv(N, 16)), dim3(64), 0, stream, (const char*)bvh, L, rays, N, tmin, tmax,
+                           hit, idx, t_out);
+        return nu_launch_status();
+    }
     static const int full_only = getenv("NU_LBVH_FULL_STACK") ? atoi(getenv("NU_LBVH_FULL_STACK")) : 0;   // development A/B
     if (full_only) {
         hipLaunchKernelGGL((lbvh_trace_kernel<NU_STACK, false>), dim3(nu_cdiv(N, 256)), dim3(256), 0, stream, (const char*)bvh, L, rays, N,

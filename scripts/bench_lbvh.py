@@ -51,4 +51,4 @@ for n in (1024, 4096, 8192, 16384, 65536):
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / 50 * 1e3
-        print(f"small batch: faces {F.shape[0]}  {name:13s} rays {n:6d}: {us:7.1f} us per trace (NU_LBVH_RPW={os.environ.get('NU_LBVH_RPW', 'rule')})  {n/us:7.1f} Mrays/s")
+        print(f"small batch: faces {F.shape[0]}  {name:13s} rays {n:6d}: {us:7.1f} us per trace (NU_LBVH_QUAD={os.environ.get('NU_LBVH_QUAD', 'rule')}, NU_LBVH_RPW={os.environ.get('NU_LBVH_RPW', 'rule')})  {n/us:7.1f} Mrays/s")
