@@ -11,7 +11,8 @@ A step = ray fetch (device-resident pool) -> sampler -> render_core forward -> l
   extra_workloads : (default N = 1 run only) short legs of the other BASELINE.json configs, timed AFTER the headline's timed
                  region in the same process, each {workload, dtype, ms_per_step, rays_per_s, roofline{...}}: config 3 (stage 2,
                  4096 rays, and the non-zero-thickness model at its real batch of 1024), config 4 (real-capture path, 8192
-                 rays, bf16 storage) and the reference's default stage-1 batch of 512 rays.  The headline fields never change.
+                 rays, bf16 storage), the reference's default stage-1 batch of 512 rays, and the headline workload in the opt-in
+                 `bf16x6` mode (fp32-equivalent products on the bf16 pipe).  The headline fields never change.
   roofline     : the fp32-MFMA GEMM kernels (gemm_nt_kernel*, the dominant kernel): algorithmic FLOPs of every
                  launch / summed launch durations (HIP events on the launch stream, on one step in the middle of
                  the timed region by default: the ~330 event pairs cost that step a few ms) vs the 157.3 TFLOP/s fp32-MFMA peak
@@ -500,6 +501,8 @@ EXTRA_LEGS = (
     ("stage2_thick_1024", 'stage2', dict(rays=1024, steps=20, warmup=5, thick=True)),
     ("config4_bf16", 'stage1', dict(rays=8192, steps=10, warmup=4, real_capture=True, mlp_dtype='bf16')),
     ("stage1_512rays", 'stage1', dict(rays=512, steps=30, warmup=6)),
+    # the headline workload in the opt-in split-product mode (dtype says what it is): reported BESIDE the exact-fp32 headline, never instead
+    ("headline_workload_bf16x6", 'stage1', dict(rays=4096, steps=12, warmup=4, mlp_dtype='bf16x6')),
 )
 
 
