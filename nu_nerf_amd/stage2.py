@@ -333,6 +333,32 @@ class Stage2Renderer(nn.Module):
         res.update(self._inner_occ_loss(n2, x_in, y[:, 0], grads, d_in, aux, step))
         return res
 
+    def _shade_surfaces(self, n1, s1c, segs):
+        """(sRGB surface colour, transmitted share) of the surface at the end of every segment that has continuing rays
+        (renderer_zerothick.py:1940-1975), all segments in one pass of the network ops.  A surface seen from inside the object
+        contributes no colour (`is_internal`: AppShadingNetwork_S2 multiplies it by 0, field.py:1005): its rows are zeroed here."""
+        live = [b for b, sg in enumerate(segs) if sg['n_cont'] > 0]
+        if not live:
+            return {}
+        pts, nrm, view = [], [], []
+        for b in live:
+            sg, cont = segs[b], segs[b]['cont_idx']
+            pts.append(sg['start'].index_select(0, cont) + sg['v'].index_select(0, cont) * sg['z'].index_select(0, cont)[:, -1:])
+            nrm.append(sg['normal'])
+            view.append(-sg['dirs'].index_select(0, cont))
+        one = len(live) == 1
+        hit_pt, normal, v = (pts[0], nrm[0], view[0]) if one else (torch.cat(pts, 0), torch.cat(nrm, 0), torch.cat(view, 0))
+        y, _ = n1.sdf(hit_pt)
+        surf, through = self._shading(n1, s1c.cfg, s1c.FG_LUT, hit_pt, normal, v, y[:, 1:], s2=True, is_internal=False)
+        counts = [segs[b]['n_cont'] for b in live]
+        surf_b, through_b = (surf,), (through,)
+        if not one:
+            surf_b, through_b = torch.split(surf, counts, 0), torch.split(through, counts, 0)
+        res = {}
+        for k, b in enumerate(live):
+            res[b] = (surf_b[k] * 0 if segs[b]['inside'] else surf_b[k], through_b[k])
+        return res
+
     @staticmethod
     def path_points(seg):
         return seg['start'][:, None, :] + seg['v'][:, None, :] * seg['z'][..., None]
@@ -373,6 +399,12 @@ class Stage2Renderer(nn.Module):
                     if torch.is_tensor(t):
                         t.record_stream(main)
         outer = O.outer_segments(n1, [(sg['start'], sg['v'], sg['z'], sg['dirs']) for sg in segs])
+        # The surfaces the continuing rays cross (stage-1 materials at the hit point, AppShadingNetwork_S2) do not depend on each
+        # other or on the transmittance: in training they are shaded in ONE pass over the hit points of all segments -- the rows of
+        # a network op are independent, so every value is the one the per-segment calls give, and at the batch sizes of stage 2
+        # (10^2-10^3 hit points per segment) the per-segment calls are launch-latency-bound: a third of the launches for the same
+        # rows.  Validation keeps the per-segment calls (the first surface also returns its intermediate images).
+        surfaces = self._shade_surfaces(n1, s1c, segs) if is_train else None
         for b, sg in enumerate(segs):
             N, cont = sg['start'].shape[0], sg['cont_idx']
             alpha, col = outer[b]
@@ -390,6 +422,12 @@ class Stage2Renderer(nn.Module):
                 colors.append(light)
                 break
             # the surface the continuing rays cross: stage-1 materials at the hit point, AppShadingNetwork_S2
+            if surfaces is not None:
+                surf, through = surfaces[b]
+                T_c = T.index_select(0, cont)
+                colors.append(light.index_add(0, cont, G.srgb_to_linear(surf) * T_c))
+                T = T_c * through
+                continue
             hit_pt = sg['start'].index_select(0, cont) + sg['v'].index_select(0, cont) * sg['z'].index_select(0, cont)[:, -1:]
             y, _ = n1.sdf(hit_pt)
             if b == 0 and not is_train:
