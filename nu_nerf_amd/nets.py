@@ -11,6 +11,8 @@ per-bounce bookkeeping of stage 2 can stay in torch while every GEMM runs in the
   StackFn     X[rows, K]            -> raw[rows, n_out]   one make_predictor stack          (field.py:371-408)
   MaterialsFn feat[P,256], x[P,3]   -> raw[P,6] (metallic, roughness, albedo(3), transmission; pre-sigmoid)
 """
+import os
+
 import torch
 
 from .engine import addr
@@ -280,6 +282,80 @@ class IorFn(torch.autograd.Function):
         return None, None, dX[:, :ctx.K], None, _token_grad(eng, flat, ctx.names)
 
 
+class IorPairFn(torch.autograd.Function):
+    """Two networks of IorFn's shape on the SAME input (the non-zero-thickness model evaluates IoR and thickness at every hit
+    point, renderer.py:1725-1734) as grouped launches: each GEMM of the pair is one launch of two independent problems at
+    constant strides (the pair's weight tables, biases, activations), so the pair costs the launches of one network -- at the
+    10^2-10^3 hit points of a stage-2 bounce these launches are latency-bound.  Same kernels, same per-row arithmetic as two
+    IorFn calls."""
+
+    @staticmethod
+    def forward(ctx, eng, la, lb, X, names, token):
+        from .engine import EPI_BIAS_NONE, EPI_BIAS_RELU
+        rows, K = X.shape
+        Xp = eng.zeros(rows, 64)
+        Xp[:, :K] = X.detach()
+        H = [eng.empty(2, rows, 256) for _ in range(3)]
+        sH = rows * 256
+
+        def st(pa, pb):             # element stride between the two networks' copies of one table (separate allocations)
+            return (pb - pa) // 4
+        for k, (src, lds, Kd, sA, epi) in enumerate(((Xp, 64, 64, 0, EPI_BIAS_RELU), (H[0], 256, 256, sH, EPI_BIAS_RELU),
+                                                      (H[1], 256, 256, sH, EPI_BIAS_NONE))):
+            eng.nt(addr(src), lds, addr(*la[k].Wp), Kd, rows, 256, Kd, addr(H[k]), 256, epi, bias=addr(la[k].b), groups=2, sA=sA,
+                   sB=st(addr(*la[k].Wp), addr(*lb[k].Wp)), sC=sH, sBias=st(addr(la[k].b), addr(lb[k].b)))
+        out = eng.empty(2, rows, 1)
+        for z, ls in enumerate((la, lb)):
+            eng.skinny_fwd(addr(H[2], z * sH), 256, rows, 256, addr(*ls[3].Wp), 256, addr(ls[3].b), 1, addr(out, z * rows), 1)
+        ctx.eng, ctx.la, ctx.lb, ctx.names, ctx.Xp, ctx.H, ctx.K = eng, la, lb, names, Xp, H, K
+        ctx.set_materialize_grads(False)
+        return out[0, :, 0].clone(), out[1, :, 0].clone()
+
+    @staticmethod
+    def backward(ctx, da, db):
+        from .engine import EPI_MUL_DRELU, EPI_PLAIN
+        eng, la, lb, Xp, H = ctx.eng, ctx.la, ctx.lb, ctx.Xp, ctx.H
+        eng.op_begin()
+        rows = Xp.shape[0]
+        sH = rows * 256
+        flat = eng.zeros(eng.n_grad)
+        dy = eng.zeros(2, rows, 1)
+        if da is not None:
+            dy[0, :, 0] = da
+        if db is not None:
+            dy[1, :, 0] = db
+
+        def st(pa, pb):
+            return (pb - pa) // 4
+        d2 = eng.empty(2, rows, 256)
+        for z, ls in enumerate((la, lb)):
+            eng.skinny_bwd(addr(dy, z * rows), 1, addr(H[2], z * sH), 256, rows, 256, addr(*ls[3].Wp), 256, 1, addr(d2, z * sH), 256, 0, 0,
+                           addr(*ls[3].dWp), ls[3].ldd, addr(flat, ls[3].db_off))
+        d_prev = d2
+        for k in (2, 1):
+            eng.wgrad(addr(d_prev), 256, addr(H[k - 1]), 256, rows, 256, 256, addr(*la[k].dWp), la[k].ldd, addr(flat, la[k].db_off),
+                      groups=2, sA0=sH, sB0=sH, sW=st(addr(*la[k].dWp), addr(*lb[k].dWp)), sDb=lb[k].db_off - la[k].db_off)
+            d_next = eng.empty(2, rows, 256)
+            eng.nt(addr(d_prev), 256, addr(*la[k].WpT), la[k].ldT, rows, 256, 256, addr(d_next), 256, EPI_MUL_DRELU, H=addr(H[k - 1]), ldh=256,
+                   groups=2, sA=sH, sB=st(addr(*la[k].WpT), addr(*lb[k].WpT)), sC=sH, sH=sH)
+            d_prev = d_next
+        eng.wgrad(addr(d_prev), 256, addr(Xp), 64, rows, 256, 64, addr(*la[0].dWp), la[0].ldd, addr(flat, la[0].db_off),
+                  groups=2, sA0=sH, sB0=0, sW=st(addr(*la[0].dWp), addr(*lb[0].dWp)), sDb=lb[0].db_off - la[0].db_off)
+        dX = eng.empty(2, rows, 64)
+        eng.nt(addr(d_prev), 256, addr(*la[0].WpT), la[0].ldT, rows, 64, 256, addr(dX), 64, EPI_PLAIN,
+               groups=2, sA=sH, sB=st(addr(*la[0].WpT), addr(*lb[0].WpT)), sC=rows * 64)
+        eng.unpack_grads(flat, la)
+        eng.unpack_grads(flat, lb)
+        eng.op_end()
+        ctx.H = ctx.Xp = None
+        return None, None, None, (dX[0] + dX[1])[:, :ctx.K], None, _token_grad(eng, flat, ctx.names)
+
+
+def _same_shape_pair(la, lb):
+    return len(la) == len(lb) == 4 and all(a.N == b.N and a.K == b.K and a.Kp == b.Kp and a.ldT == b.ldT and a.ldd == b.ldd
+                                           for a, b in zip(la, lb))
+
+
 class Stage1Nets:
     """Differentiable callables over one Stage1Engine (SDF, variance, NeRF++, the shading predictors)."""
 
@@ -343,6 +419,15 @@ class Stage1Nets:
         if X.shape[0] == 0:
             return X.new_zeros(0)
         return IorFn.apply(self.eng, self.eng.small['thickness_network'], X, self.thick_names, self.token())
+
+    def ior_and_thickness(self, X):
+        """(raw IoR, raw thickness) on encoded points X [rows, 39]: the two networks as grouped launches (IorPairFn)."""
+        if X.shape[0] == 0:
+            return X.new_zeros(0), X.new_zeros(0)
+        la, lb = self.eng.small['ior_network'], self.eng.small['thickness_network']
+        if not _same_shape_pair(la, lb) or os.environ.get('NU_S2_IOR_PAIR') == '0':
+            return self.ior(X), self.thickness(X)
+        return IorPairFn.apply(self.eng, la, lb, X, self.ior_names + self.thick_names, self.token())
 
     def predictor(self, name, X):
         layers, names, params = self.stack[name]

@@ -134,8 +134,9 @@ class Stage2Renderer(_ZeroThickStage2):
             N = start.shape[0]
             point = inter['point']
             pe = G.embed(point, 6)
+            ior_raw, thick_raw = n2.ior_and_thickness(pe)     # the two networks as grouped launches
             refracts, tir_ok, eta, normal, p_end, next_start, next_dir = O.shell_refract(
-                n1.eng, d_hit, inter['n'], point, n2.ior(pe), inter['g_k'], n2.thickness(pe), inside)
+                n1.eng, d_hit, inter['n'], point, ior_raw, inter['g_k'], thick_raw, inside)
             keep = refracts.nonzero().flatten()
             cont_idx = hit_idx.index_select(0, keep)
             root_hit = root.index_select(0, hit_idx)

@@ -194,3 +194,29 @@ def test_stage2_thick_train_step_in_the_split_bf16_mode(gpu):
     np.testing.assert_allclose(out['ray_rgb'].detach().cpu().numpy(), g['out_ray_rgb'], rtol=1e-4, atol=1e-5)
     np.testing.assert_allclose(float(total.detach()), float(g['total_loss']), rtol=5e-5)
     _check_gradient_norms(net, g, rtol=5e-3, atol=2e-8)
+
+
+def test_ior_and_thickness_as_grouped_launches_equal_the_two_networks(gpu):
+    """nets.IorPairFn (the IoR and thickness networks of renderer.py:1725-1734 as grouped launches on one input) against two IorFn
+    calls: same kernels and per-row arithmetic -> identical values; input and parameter gradients agree to summation order."""
+    g = golden("stage2_thick_step6000_r24.npz")
+    net, _ = build_thick(gpu, g)
+    _, n2 = net.nets()
+    n2.eng.pack()
+    torch.manual_seed(5)
+    X0 = torch.randn(777, 39, device=gpu)
+    wa, wb = torch.randn(777, device=gpu), torch.randn(777, device=gpu)
+    res = []
+    for pair in (True, False):
+        net.zero_grad()
+        n2.begin_pass()
+        X = X0.clone().requires_grad_(True)
+        a, b = n2.ior_and_thickness(X) if pair else (n2.ior(X), n2.thickness(X))
+        ((a * wa).sum() + (b * wb).sum()).backward()
+        grads = {n: n2.named[n].grad.detach().clone() for n in n2.ior_names + n2.thick_names if n2.named[n].grad is not None}
+        res.append((a.detach().clone(), b.detach().clone(), X.grad.detach().clone(), grads))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    torch.testing.assert_close(res[0][2], res[1][2], rtol=1e-5, atol=1e-6)
+    assert set(res[0][3]) == set(res[1][3]) and len(res[0][3]) >= 16
+    for n in res[0][3]:
+        torch.testing.assert_close(res[0][3][n], res[1][3][n], rtol=2e-5, atol=1e-6, msg=n)
