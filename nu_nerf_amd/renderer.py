@@ -103,6 +103,42 @@ def _predictor(in_dim, out_dim):
                          WNLinear(256, out_dim), nn.Identity())
 
 
+def imgs_info_downsample(imgs_info, ratio):
+    """renderer_zerothick.py:71-87 for tensors on any device: every image is blurred with the Gaussian of
+    utils/base_utils.py:131-137 (sigma = 1 / (3 ratio), odd kernel size from OpenCV's rule, BORDER_REFLECT101) and resized to
+    (int(ratio h), int(ratio w)) bilinearly with pixel centres at half-integers (cv2.INTER_LINEAR on float images), and the
+    intrinsics are scaled by diag(dw / w, dh / h, 1).  'depths' / 'masks', when the caller's test store carries them, are
+    resized like the reference resizes gt_depth / gt_mask (nearest, :402-408).  OpenCV is not available offline: restated from
+    its documented definitions, parity with cv2's own output unpinned (it only affects the ground-truth side of validation)."""
+    import math
+    imgs = imgs_info['imgs'].float()
+    b, c, h, w = imgs.shape
+    dh, dw = int(ratio * h), int(ratio * w)
+    sigma = (1.0 / ratio) / 3.0
+    ksize = int(math.ceil(((sigma - 0.8) / 0.3 + 1) * 2 + 1))
+    ksize = ksize + 1 if ksize % 2 == 0 else ksize
+    out = imgs
+    if ksize > 1:
+        x = torch.arange(ksize, dtype=torch.float32, device=imgs.device) - (ksize - 1) * 0.5
+        k1 = torch.exp(-(x * x) / (2.0 * sigma * sigma))
+        k1 = k1 / k1.sum()
+        pad = ksize // 2
+        out = F.pad(out, (pad, pad, pad, pad), mode='reflect')                       # BORDER_REFLECT101
+        out = F.conv2d(out, k1.view(1, 1, 1, ksize).expand(c, 1, 1, ksize), groups=c)
+        out = F.conv2d(out, k1.view(1, 1, ksize, 1).expand(c, 1, ksize, 1), groups=c)
+    out = F.interpolate(out, size=(dh, dw), mode='bilinear', align_corners=False)
+    res = {k: v for k, v in imgs_info.items()}
+    res['imgs'] = out
+    scale = torch.diag(torch.tensor([dw / w, dh / h, 1.0], dtype=torch.float32, device=imgs_info['Ks'].device))
+    res['Ks'] = scale[None] @ imgs_info['Ks'].float()
+    for k in ('depths', 'masks'):
+        if k in imgs_info:
+            v = imgs_info[k]
+            v4 = v.reshape(b, 1, h, w).float()
+            res[k] = F.interpolate(v4, size=(dh, dw), mode='nearest').reshape(v.shape[:-2] + (dh, dw)).to(v.dtype)
+    return res
+
+
 class AppShadingNetwork(nn.Module):
     default_cfg = {'human_light': False, 'sphere_direction': False, 'light_pos_freq': 6, 'inner_init': -0.95,
                    'roughness_init': 0.0, 'metallic_init': 0.0, 'light_exp_max': 3.0, 'refrac_freq': 6}
@@ -582,8 +618,8 @@ class NeROShapeRenderer(nn.Module):
         if self.test_imgs_info is not None:
             info = {k: v[index:index + 1] for k, v in self.test_imgs_info.items()}
             if self.cfg['test_downsample_ratio'] and float(self.cfg['downsample_ratio']) != 1.0:
-                raise NotImplementedError("test_downsample_ratio with an image store: down-sample the test images before "
-                                          "set_ray_store (imgs_info_downsample resizes with OpenCV, outside this build)")
+                info = imgs_info_downsample({k: (v if torch.is_tensor(v) else torch.as_tensor(v)) for k, v in info.items()},
+                                            float(self.cfg['downsample_ratio']))
             if self.is_nerf:
                 batch, poses, rn, h, w = self._construct_nerf_ray_batch(info, dev, is_train=False)
             else:

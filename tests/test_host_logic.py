@@ -251,6 +251,54 @@ def test_ray_store_construction_vs_reference_fixture_and_unmodified_yaml_names()
     assert sorted(real.train_batch) == ['dirs', 'idxs', 'rgbs'] and real.train_poses.shape == (3, 3, 4)
 
 
+def test_imgs_info_downsample_follows_the_opencv_definitions():
+    """renderer_zerothick.py:71-87 restated for tensors (OpenCV is absent offline, so cv2's own output cannot pin it): Gaussian blur
+    with sigma = 1 / (3 ratio) and the odd kernel size of utils/base_utils.py:131-137 under BORDER_REFLECT101, bilinear resize
+    with half-integer pixel centres, intrinsics scaled by diag(dw / w, dh / h, 1) -- checked against a direct numpy evaluation of
+    those definitions, plus the invariants (constant image, shapes, nearest resize of depth / mask)."""
+    from nu_nerf_amd.renderer import imgs_info_downsample
+    rng = np.random.default_rng(3)
+    n, h, w = 2, 11, 14
+    img = rng.random((n, 3, h, w)).astype(np.float32)
+    K = np.tile(np.array([[500.0, 0, 7.0], [0, 510.0, 5.5], [0, 0, 1]], np.float32), (n, 1, 1))
+    depth = rng.random((n, h, w)).astype(np.float32)
+    for ratio in (0.5, 0.25):
+        out = imgs_info_downsample({'imgs': torch.from_numpy(img), 'Ks': torch.from_numpy(K), 'depths': torch.from_numpy(depth),
+                                    'poses': torch.zeros(n, 3, 4)}, ratio)
+        dh, dw = int(ratio * h), int(ratio * w)
+        assert out['imgs'].shape == (n, 3, dh, dw) and out['depths'].shape == (n, dh, dw) and out['poses'].shape == (n, 3, 4)
+        sigma = (1 / ratio) / 3
+        ks = int(np.ceil(((sigma - 0.8) / 0.3 + 1) * 2 + 1))
+        ks += 1 if ks % 2 == 0 else 0
+        xs = np.arange(ks) - (ks - 1) / 2
+        k1 = np.exp(-xs ** 2 / (2 * sigma ** 2)); k1 /= k1.sum()
+        r = ks // 2
+
+        def refl(i, m):                       # BORDER_REFLECT101: gfedcb|abcdefgh|gfedcba
+            return -i if i < 0 else (2 * (m - 1) - i if i >= m else i)
+        blur = np.zeros_like(img, dtype=np.float64)
+        for y in range(h):
+            for x in range(w):
+                acc = 0.0
+                for dy in range(-r, r + 1):
+                    for dx in range(-r, r + 1):
+                        acc = acc + k1[dy + r] * k1[dx + r] * img[:, :, refl(y + dy, h), refl(x + dx, w)]
+                blur[:, :, y, x] = acc
+        ref = np.zeros((n, 3, dh, dw))
+        for y in range(dh):
+            fy = min(max((y + 0.5) * h / dh - 0.5, 0.0), h - 1.0); y0 = int(np.floor(fy)); y1 = min(y0 + 1, h - 1); ty = fy - y0
+            for x in range(dw):
+                fx = min(max((x + 0.5) * w / dw - 0.5, 0.0), w - 1.0); x0 = int(np.floor(fx)); x1 = min(x0 + 1, w - 1); tx = fx - x0
+                ref[:, :, y, x] = ((1 - ty) * ((1 - tx) * blur[:, :, y0, x0] + tx * blur[:, :, y0, x1])
+                                   + ty * ((1 - tx) * blur[:, :, y1, x0] + tx * blur[:, :, y1, x1]))
+        np.testing.assert_allclose(out['imgs'].numpy(), ref, rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(out['Ks'].numpy(), np.diag([dw / w, dh / h, 1.0]).astype(np.float32)[None] @ K, rtol=1e-6)
+        ys, xs2 = (np.arange(dh) * h // dh), (np.arange(dw) * w // dw)
+        np.testing.assert_array_equal(out['depths'].numpy(), depth[:, ys][:, :, xs2])
+        const = imgs_info_downsample({'imgs': torch.full((1, 3, h, w), 0.37), 'Ks': torch.from_numpy(K[:1])}, ratio)
+        np.testing.assert_allclose(const['imgs'].numpy(), 0.37, rtol=1e-6)
+
+
 def test_forward_routes_eval_requests_to_test_step_cpu_side():
     """forward({'index','eval','step'}) is the ValidationEvaluator's call (train/train_valid.py:25-29), first made at step 0
     (trainer_zero.py:174): it must reach test_step, not raise.  (The render itself needs the GPU: tests/test_eval_gpu.py.)"""

@@ -329,8 +329,8 @@ def test_ray_store_from_loaded_images_on_the_device(gpu):
     from helpers import check_ray_store_against_reference_fixture
     from nu_nerf_amd.renderer import name2renderer
     info = check_ray_store_against_reference_fixture(gpu)
-    small = {'n_samples': 16, 'n_importance': 16, 'n_bg_samples': 8, 'train_ray_num': 32, 'test_ray_num': 20,
-             'test_downsample_ratio': False}      # (down-sampling test images is image preprocessing: the caller's, before set_ray_store)
+    small = {'n_samples': 16, 'n_importance': 16, 'n_bg_samples': 8, 'train_ray_num': 32, 'test_ray_num': 20}
+    # (test_downsample_ratio stays at the reference's default True: test_step blurs and halves the 6 x 5 test image on the device)
     for is_nerf, name in ((True, 'nerf/spherepot'), (False, 'real/bear')):
         net = name2renderer['shape'](dict(small, database_name=name, is_nerf=is_nerf), training=True).to(gpu)
         poses = info['poses'].clone()
@@ -344,5 +344,7 @@ def test_ray_store_from_loaded_images_on_the_device(gpu):
         out['loss_rgb'].mean().backward()
         with torch.no_grad():
             ev = net({'index': 1, 'eval': True, 'step': 0})
-        assert ev['ray_rgb'].shape == (6, 5, 3) and ev['gt_rgb'].shape == (6, 5, 3) and ev['gt_mask'].shape == (6, 5, 1)
-        np.testing.assert_allclose(ev['gt_rgb'].cpu().numpy(), info['imgs'][1].permute(1, 2, 0).cpu().numpy(), rtol=0, atol=0)
+        from nu_nerf_amd.renderer import imgs_info_downsample
+        assert ev['ray_rgb'].shape == (3, 2, 3) and ev['gt_rgb'].shape == (3, 2, 3) and ev['gt_mask'].shape == (3, 2, 1)
+        half = imgs_info_downsample({'imgs': info['imgs'][1:2], 'Ks': info['Ks'][1:2]}, 0.5)['imgs'][0]
+        np.testing.assert_allclose(ev['gt_rgb'].cpu().numpy(), half.permute(1, 2, 0).cpu().numpy(), rtol=0, atol=1e-7)
