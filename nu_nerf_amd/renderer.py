@@ -421,7 +421,7 @@ class NeROShapeRenderer(nn.Module):
         """renderer_zerothick.py:329-345 / renderer.py:329-345 (only consumed by human_light, which is off in every config)."""
         pn = poses.shape[0]
         cam_cen = (-poses[:, :, :3].permute(0, 2, 1) @ poses[:, :, 3:])[..., 0]
-        if not self.cfg['fixed_camera']:
+        if not self.cfg.get('fixed_camera', False):
             cam_cen = cam_cen.clone()
             cam_cen[..., 2] = 0
         Y = torch.zeros(pn, 3, device=poses.device)
@@ -605,6 +605,24 @@ class NeROShapeRenderer(nn.Module):
             return self.test_step(index, step)
         return self.train_step(step)
 
+    def _test_batch_from_store(self, index, dev):
+        """Rays, size and ground truth of test image `index` of the image store (renderer_zerothick.py:397-410): the slice of
+        test_imgs_info, down-sampled when cfg says so, through the ray construction of the data convention."""
+        info = {k: v[index:index + 1] for k, v in self.test_imgs_info.items()}
+        if self.cfg['test_downsample_ratio'] and float(self.cfg['downsample_ratio']) != 1.0:
+            info = imgs_info_downsample({k: (v if torch.is_tensor(v) else torch.as_tensor(v)) for k, v in info.items()},
+                                        float(self.cfg['downsample_ratio']))
+        if self.is_nerf:
+            batch, poses, rn, h, w = self._construct_nerf_ray_batch(info, dev, is_train=False)
+        else:
+            batch, poses, rn, h, w = self._construct_ray_batch(info, dev)
+            ro, rd, _, _, _ = self._process_ray_batch(batch, poses.float().to(dev))
+            batch = {'rays_o': ro, 'rays_d': rd, 'rgbs': batch['rgbs']}
+        batch = {k: v for k, v in batch.items() if k in ('rays_o', 'rays_d', 'rgbs')}
+        depth = info['depths'][0].reshape(h, w, 1).float().cpu() if 'depths' in info else torch.zeros(h, w, 1)
+        mask = (info['masks'][0].reshape(h, w, 1) > 0).to(torch.int32).cpu() if 'masks' in info else torch.zeros(h, w, 1, dtype=torch.int32)
+        return batch, h, w, depth, mask
+
     def test_step(self, index, step):
         """Full-image validation render of camera `index` (renderer_zerothick.py:397-445): chunks of cfg['test_ray_num'] rays, no
         jitter, cos_anneal 0, is_train=False; same output keys and image shapes as the reference.  The rays come from the
@@ -616,20 +634,8 @@ class NeROShapeRenderer(nn.Module):
         from .validation import render_eval
         dev = self.deviation_network.variance.device
         if self.test_imgs_info is not None:
-            info = {k: v[index:index + 1] for k, v in self.test_imgs_info.items()}
-            if self.cfg['test_downsample_ratio'] and float(self.cfg['downsample_ratio']) != 1.0:
-                info = imgs_info_downsample({k: (v if torch.is_tensor(v) else torch.as_tensor(v)) for k, v in info.items()},
-                                            float(self.cfg['downsample_ratio']))
-            if self.is_nerf:
-                batch, poses, rn, h, w = self._construct_nerf_ray_batch(info, dev, is_train=False)
-            else:
-                batch, poses, rn, h, w = self._construct_ray_batch(info, dev)
-                ro, rd, _, _, _ = self._process_ray_batch(batch, poses.float().to(dev))
-                batch = {'rays_o': ro, 'rays_d': rd, 'rgbs': batch['rgbs']}
-            batch = {k: v for k, v in batch.items() if k in ('rays_o', 'rays_d', 'rgbs')}
+            batch, h, w, depth, mask = self._test_batch_from_store(index, dev)
             outputs = render_eval(self, batch, step)
-            depth = info['depths'][0].reshape(h, w, 1).float().cpu() if 'depths' in info else torch.zeros(h, w, 1)
-            mask = (info['masks'][0].reshape(h, w, 1) > 0).to(torch.int32).cpu() if 'masks' in info else torch.zeros(h, w, 1, dtype=torch.int32)
         else:
             hw = int(self.cfg.get('synthetic_hw', 800))
             ratio = float(self.cfg['downsample_ratio']) if self.cfg['test_downsample_ratio'] else 1.0

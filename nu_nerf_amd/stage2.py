@@ -124,9 +124,13 @@ class Stage2Renderer(nn.Module):
     _init_dataset = NeROShapeRenderer._init_dataset
     _shuffle_train_batch = NeROShapeRenderer._shuffle_train_batch
     # an image database loaded by the caller: the same device-resident ray store as stage 1 (renderer.set_ray_store)
-    _construct_ray_batch = NeROShapeRenderer._construct_ray_batch
-    _construct_nerf_ray_batch = NeROShapeRenderer._construct_nerf_ray_batch
+    _construct_ray_batch = staticmethod(NeROShapeRenderer._construct_ray_batch)
+    _construct_nerf_ray_batch = staticmethod(NeROShapeRenderer._construct_nerf_ray_batch)
     set_ray_store = NeROShapeRenderer.set_ray_store
+    _test_batch_from_store = NeROShapeRenderer._test_batch_from_store
+    _process_ray_batch = NeROShapeRenderer._process_ray_batch
+    near_far_from_sphere = staticmethod(NeROShapeRenderer.near_far_from_sphere)
+    get_human_coordinate_poses = NeROShapeRenderer.get_human_coordinate_poses
 
     # ---- construction helpers ---------------------------------------------------------------------
     def _load_stage1_cfg(self):
@@ -532,21 +536,26 @@ class Stage2Renderer(nn.Module):
         return outs
 
     def test_step(self, index, step):
-        """Full-image validation render of camera `index` (renderer_zerothick.py:1209-1257) for the ray-pool datasets of this
-        build (every pixel of the down-sampled synthetic camera; gt_depth / gt_mask are the empty scene's zeros)."""
+        """Full-image validation render of camera `index` (renderer_zerothick.py:1209-1257): the test image of the image store
+        handed to set_ray_store (down-sampled as cfg says, its 'depths' / 'masks' as gt_depth / gt_mask), or every pixel of the
+        down-sampled synthetic camera (gt_depth / gt_mask: the empty scene's zeros)."""
         from . import synthetic
-        hw = int(self.cfg.get('synthetic_hw', 800))
-        ratio = float(self.cfg['downsample_ratio']) if self.cfg['test_downsample_ratio'] else 1.0
-        rays, h, w = synthetic.make_image_rays(index, hw=hw, seed=int(self.cfg.get('ray_seed', 6033)), downsample=ratio)
         dev = self.IORs.device
-        batch = {k: torch.from_numpy(v).to(dev) for k, v in rays.items()}
+        if getattr(self, 'test_imgs_info', None) is not None:
+            batch, h, w, depth, mask = self._test_batch_from_store(index, dev)
+        else:
+            hw = int(self.cfg.get('synthetic_hw', 800))
+            ratio = float(self.cfg['downsample_ratio']) if self.cfg['test_downsample_ratio'] else 1.0
+            rays, h, w = synthetic.make_image_rays(index, hw=hw, seed=int(self.cfg.get('ray_seed', 6033)), downsample=ratio)
+            batch = {k: torch.from_numpy(v).to(dev) for k, v in rays.items()}
+            depth, mask = torch.zeros(h, w, 1), torch.zeros(h, w, 1, dtype=torch.int32)
         with torch.no_grad():
             outputs = self.render_eval(batch, step)
         tm = outputs['tir_mask'].float()
         outputs['gt_rgb'] = (batch['rgbs'] * tm).reshape(h, w, 3)
         outputs['ray_rgb'] = (outputs['ray_rgb'] * tm).reshape(h, w, 3)
-        outputs['gt_depth'] = torch.zeros(h, w, 1)
-        outputs['gt_mask'] = torch.zeros(h, w, 1, dtype=torch.int32)
+        outputs['gt_depth'] = depth
+        outputs['gt_mask'] = mask
         self.zero_grad()
         return outputs
 

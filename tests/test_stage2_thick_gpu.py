@@ -220,3 +220,31 @@ def test_ior_and_thickness_as_grouped_launches_equal_the_two_networks(gpu):
     assert set(res[0][3]) == set(res[1][3]) and len(res[0][3]) >= 16
     for n in res[0][3]:
         torch.testing.assert_close(res[0][3][n], res[1][3][n], rtol=2e-5, atol=1e-6, msg=n)
+
+
+def test_stage2_thick_renders_a_test_image_of_an_image_store(gpu):
+    """set_ray_store(train_imgs_info, test_imgs_info) on the stage-2 module (the second half of _init_dataset,
+    renderer.py:1160-1190): forward({'step'}) trains on the store and forward({'index','eval','step'}) renders test image
+    `index` from it, down-sampled as the default cfg says (renderer.py:1209-1220), for both data conventions."""
+    from helpers import check_ray_store_against_reference_fixture
+    from nu_nerf_amd.stage2_thick import name2renderer
+    from nu_nerf_amd.lbvh import icosphere
+    info = check_ray_store_against_reference_fixture(gpu)
+    shader = {'sphere_direction': True, 'human_light': False, 'light_exp_max': 5.0}
+    for is_nerf, name in ((True, 'nerf/spherepot'), (False, 'real/bear')):
+        cfg = {'name': 's2t', 'network': 'stage2', 'get_mask': False, 'database_name': name, 'is_nerf': is_nerf,
+               'shader_config': shader, 'train_ray_num': 24, 'test_ray_num': 16, 'downsample_ratio': 0.5,     # (renderer.py's default is 1.0)
+               'stage1_cfg': {'name': 's1', 'network': 'shape', 'get_mask': False, 'is_nerf': is_nerf, 'shader_config': shader},
+               'stage1_mesh_arrays': icosphere(2, 0.5)}
+        net = name2renderer['stage2'](cfg, training=True).to(gpu)
+        poses = info['poses'].clone()
+        if not is_nerf:       # world -> camera poses looking at the origin from 3 units away
+            poses[:, :, :3] = torch.eye(3, device=gpu)
+            poses[:, :, 3] = torch.tensor([0.0, 0.0, 3.0], device=gpu)
+        net.set_ray_store(dict(info, poses=poses), test_imgs_info=dict(info, poses=poses))
+        out = net({'step': 6000})
+        assert out['ray_rgb'].shape == (24, 3) and bool(torch.isfinite(out['ray_rgb']).all())
+        with torch.no_grad():
+            ev = net({'index': 1, 'eval': True, 'step': 0})
+        assert ev['ray_rgb'].shape == (3, 2, 3) and ev['gt_rgb'].shape == (3, 2, 3) and ev['gt_mask'].shape == (3, 2, 1)
+        assert bool(torch.isfinite(ev['ray_rgb']).all())
