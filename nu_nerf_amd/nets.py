@@ -81,13 +81,15 @@ class ParamHubFn(torch.autograd.Function):
 
 class SdfFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, eng, x, names, token):
+    def forward(ctx, eng, x, names, token, need_normal=True):
         x = x.detach().contiguous()
         P = x.shape[0]
         a = eng.sdf_forward(addr(x), 3, P, keep=True, want_feat=True)
-        n = eng.sdf_normal(a)
         ctx.eng, ctx.a, ctx.names = eng, a, names
         ctx.set_materialize_grads(False)
+        if not need_normal:                  # value and feature only (the surface points of stage 2): no reverse sweep
+            return a['YX'][:, :257].clone(), None
+        n = eng.sdf_normal(a)
         return a['YX'][:, :257].clone(), n.clone()
 
     @staticmethod
@@ -105,7 +107,7 @@ class SdfFn(torch.autograd.Function):
         eng.unpack_grads(flat, eng.sdf)
         eng.op_end()
         ctx.a = None
-        return None, dx, None, _token_grad(eng, flat, ctx.names)
+        return None, dx, None, _token_grad(eng, flat, ctx.names), None
 
 
 class NerfFn(torch.autograd.Function):
@@ -399,8 +401,9 @@ class Stage1Nets:
             self._token = tok
         return self._token
 
-    def sdf(self, x):
-        return SdfFn.apply(self.eng, x, self.sdf_names, self.token())
+    def sdf(self, x, need_normal=True):
+        """(sdf | feature [P,257], normal [P,3]); need_normal=False returns (.., None) and skips the normal's reverse sweep."""
+        return SdfFn.apply(self.eng, x, self.sdf_names, self.token(), need_normal)
 
     def nerf(self, x, d):
         return NerfFn.apply(self.eng, x, d, self.nerf_names, self.token())

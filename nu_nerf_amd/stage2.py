@@ -352,7 +352,7 @@ class Stage2Renderer(nn.Module):
             view.append(-sg['dirs'].index_select(0, cont))
         one = len(live) == 1
         hit_pt, normal, v = (pts[0], nrm[0], view[0]) if one else (torch.cat(pts, 0), torch.cat(nrm, 0), torch.cat(view, 0))
-        y, _ = n1.sdf(hit_pt)
+        y, _ = n1.sdf(hit_pt, need_normal=False)
         surf, through = self._shading(n1, s1c.cfg, s1c.FG_LUT, hit_pt, normal, v, y[:, 1:], s2=True, is_internal=False)
         counts = [segs[b]['n_cont'] for b in live]
         surf_b, through_b = (surf,), (through,)
@@ -433,7 +433,7 @@ class Stage2Renderer(nn.Module):
                 T = T_c * through
                 continue
             hit_pt = sg['start'].index_select(0, cont) + sg['v'].index_select(0, cont) * sg['z'].index_select(0, cont)[:, -1:]
-            y, _ = n1.sdf(hit_pt)
+            y, _ = n1.sdf(hit_pt, need_normal=False)
             if b == 0 and not is_train:
                 # validation images of the first surface (renderer_zerothick.py:1952-1962 / renderer.py:2274-2289): shading normal
                 # mapped to [0,1], specular terms of AppShadingNetwork_S2's intermediate results, scattered to the camera rays
