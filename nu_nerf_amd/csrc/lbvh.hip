@@ -547,7 +547,10 @@ __global__ __launch_bounds__(64) void lbvh_trace_quad_kernel(const char* __restr
                 // running best has overtaken -- 12.9 -> 11.2 records per ray on average, but the longest chain of a batch, which
                 // is what a launch waits for, stays at 56 records and the pop loop costs more than it saves: 38.8 -> 44.1 us;
                 // subtrees of up to four triangles as ONE entry whose triangles are fetched together -- longest chain 56 -> 42
-                // records, but every step then carries four triangle fetches: 39 -> 44 us at 4 096 rays, 2.7 -> 1.0 G rays/s at 2^20)
+                // records, but every step then carries four triangle fetches: 39 -> 44 us at 4 096 rays, 2.7 -> 1.0 G rays/s at 2^20;
+                // eight lanes per ray over 8-wide records -- three binary levels per fetch, profiles/r03/lbvh_eight_lanes_per_ray.patch --
+                // bit-exact too, 37 / 32 us against 42 / 31 at 4 096 rays and 1.65 against 2.67 G rays/s at 2^20: a link costs
+                // ~0.55 us whatever the mesh size (320 .. 81 920 faces), and the longest chain shrinks less than the fan-out grows)
                 if (sp == 0) done = true;
                 else next = stack[--sp][q];
             }
