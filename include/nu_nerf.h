@@ -77,7 +77,9 @@ typedef struct NuGemmNT {      /* C[M,N] = epi(A[M,K] . B[N,K]^T);  K % 32 == 0,
      * 128x128 tile in place of 64 KB of activations.  Layout is private to the kernel (wave ballots per 4-row group):
      * cdiv(M,128) * mask_nct * 256 words, mask_nct = column tiles of the activation matrix as the WRITER saw it
      * (groups * cdiv(N,128)); reader and writer must tile the same [M, columns] matrix. */
-    unsigned long long* mask; int mask_nct; int pad_;
+    unsigned long long* mask; int mask_nct;
+    int mask_ct0;              /* first column tile of this problem in the sign-bit matrix: a problem that is one column group of a
+                                  wider activation matrix (the four material predictors side by side) when it is launched on its own */
 } NuGemmNT;
 
 typedef struct NuGemmTN {      /* dW[N1,N2] = A0^T B0 (+ A1^T B1), reduced over P rows in S deterministic splits */
@@ -110,6 +112,11 @@ int nu_slab_reduce_batched(const NuReduceDesc* descs_host, int n, hipStream_t st
 int nu_gemm_nt_size(void);      /* sizeof(NuGemmNT) / sizeof(NuGemmTN) as compiled: binding-side ABI check */
 int nu_gemm_tn_size(void);
 int nu_gemm_nt_ex(const NuGemmNT* g, hipStream_t stream);
+/* n independent problems (HOST array; own M, N, K, pointers and epilogue arguments) in as few persistent launches as possible: runs
+ * of problems with one epilogue kind share ONE tile list -- the four light predictors of AppShadingNetwork.forward (field.py:636-682),
+ * the IoR / thickness pair of stage 2 (field.py:1046-1087).  Results are bit-identical to n calls of nu_gemm_nt_ex. */
+#define NU_NT_BATCH_MAX 8
+int nu_gemm_nt_batch(const NuGemmNT* problems_host, int n, hipStream_t stream);
 long long nu_wgrad_workspace_bytes(int N1, int N2, int S, int groups);
 /* the split (number of deterministic partial slabs) the library's own sequencing uses for a weight gradient of this shape */
 int nu_wgrad_pick_split(int P, int N1, int N2, int groups, int prec);
@@ -309,6 +316,17 @@ typedef struct NuLin {
  *   shading  M[0..2], dM[0..2];  hidden [0..2], tmp[0], tmp[1] and dH3 of every light predictor
  * Optional per-launch timing: when `ev` is set, every GEMM launch is bracketed by hipEventRecord on ev[nev], ev[nev + 1]
  * and described in ev_meta[nev / 2] = {kind (0 NT, 1 TN), algorithmic flops, algorithmic bytes} until ev_cap is reached. */
+/* One queued weight gradient of a backward pass (nu_wgrad_defer): the problem, where its result goes, and its algorithmic cost
+ * (roofline accounting of the launch that ends up carrying it). */
+#define NU_WGRAD_QUEUE_MAX 32
+typedef struct NuWgradItem {
+    NuGemmTN g;
+    float* dW; int ldw, pad_; long long sW;
+    float* db; long long sDb;
+    double flops, bytes;
+} NuWgradItem;
+int nu_wgrad_item_size(void);
+
 typedef struct NuOpCtx {
     int prec, h16;                        /* NuGemmNT.bf16 arithmetic mode of every GEMM; bf16 storage */
     float* flat;                          /* flat gradient buffer of the current backward */
@@ -318,9 +336,20 @@ typedef struct NuOpCtx {
     int forked, pad_;                     /* != 0 while ops of this context are in flight on MORE THAN ONE stream: a forced
                                              mid-step flush would reduce slabs another stream still writes and hand their space
                                              out again, so the entries return NU_ERR_WORKSPACE instead (fail closed) */
+    NuWgradItem* pend; int npend, pend_cap;   /* HOST array: the weight gradients of the current pass, queued by nu_wgrad_defer and
+                                             launched together by nu_wgrad_flush (NULL: every weight gradient launches at once) */
 } NuOpCtx;
 int nu_op_ctx_size(void);
+/* launches the queued weight gradients, then the batched reductions of everything enqueued so far; resets the arena */
 int nu_ctx_flush(NuOpCtx* ctx, hipStream_t stream);
+/* the reductions only (queued weight gradients stay queued): frees the arena in the middle of a pass */
+int nu_ctx_reduce(NuOpCtx* ctx, hipStream_t stream);
+/* The weight gradients of a backward pass are independent of each other: a pass queues them and ONE launch per tile class carries
+ * the whole queue (splits chosen for the queue as a whole; see csrc/gemm_tn.hip).  Operands must stay valid and unmodified until
+ * the flush; every network-level entry below flushes before it returns.  flops / bytes: algorithmic cost for the event record. */
+int nu_wgrad_defer(NuOpCtx* ctx, const NuGemmTN* g, float* dW, int ldw, long long sW, float* db, long long sDb, double flops,
+                   double bytes, hipStream_t stream);
+int nu_wgrad_flush(NuOpCtx* ctx, hipStream_t stream);
 
 typedef struct NuSdfNet { NuLin lin[9]; } NuSdfNet;
 typedef struct NuSdfBufs {

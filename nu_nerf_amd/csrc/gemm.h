@@ -19,7 +19,13 @@
 #include "nu_nerf.h"
 
 int nu_gemm_nt_launch(const NuGemmNT& g, hipStream_t stream);
+int nu_gemm_nt_batch_launch(const NuGemmNT* probs, int n, hipStream_t stream);
 int nu_gemm_tn_launch(const NuGemmTN& g, hipStream_t stream);
 // append one reduction problem (see NuReduceDesc) to a host-side list
 int nu_reduce_push(NuReduceDesc* descs, int* ndesc, int cap, const float* slab, int S, int N1, int N2, int rs,
                    long long ss, float* out, int ldo, float alpha, int accumulate);
+
+// context services (gemm_tn.hip): slab space from the deferred-reduction arena, per-launch events
+int nu_ctx_take(NuOpCtx* c, long long nbytes, int ndesc_needed, hipStream_t stream, float** out, long long* out_bytes);
+void nu_ctx_ev_begin(NuOpCtx* c, hipStream_t stream);
+void nu_ctx_ev_end(NuOpCtx* c, hipStream_t stream, double kind, double flops, double bytes);

@@ -34,29 +34,8 @@ static inline int rup_i(int a, int b) { return (a + b - 1) / b * b; }
 // ---------------------------------------------------------------------------------------------------------
 extern "C" int nu_op_ctx_size(void) { return (int)sizeof(NuOpCtx); }
 
-extern "C" int nu_ctx_flush(NuOpCtx* c, hipStream_t stream) {
-    if (c->ndesc > 0) {
-        CHK(nu_slab_reduce_batched(c->descs, c->ndesc, stream));
-        c->ndesc = 0;
-    }
-    c->arena_off = 0;
-    return NU_OK;
-}
-
-// `nbytes` of slab space that stays untouched until the next flush (stream order makes reuse after a flush safe)
-static int ctx_take(NuOpCtx* c, long long nbytes, int ndesc_needed, hipStream_t stream, float** out, long long* out_bytes) {
-    const long long n = (nbytes + 255) / 256 * 64;          // floats, 256-byte granules
-    if (n > c->arena_floats) return NU_ERR_WORKSPACE;
-    if (c->arena_off + n > c->arena_floats || c->ndesc + ndesc_needed > c->cap) {
-        // a flush on THIS stream reduces every slab taken so far and hands their space out again: only safe when every producer
-        // is ordered before it, i.e. not while a second stream feeds the same arena (engine.py _fork / _join)
-        if (c->forked) return NU_ERR_WORKSPACE;
-        CHK(nu_ctx_flush(c, stream));
-    }
-    *out = c->arena + c->arena_off;
-    *out_bytes = n * 4;
-    c->arena_off += n;
-    return NU_OK;
+static inline int ctx_take(NuOpCtx* c, long long nbytes, int ndesc_needed, hipStream_t stream, float** out, long long* out_bytes) {
+    return nu_ctx_take(c, nbytes, ndesc_needed, stream, out, out_bytes);      // (arena, queue and events: gemm_tn.hip)
 }
 
 // storage flags of one launch under NuOpCtx.h16 (ignored otherwise): which of A, {C, C2}, {H, D, Cadd} are bf16
@@ -66,17 +45,8 @@ static int ctx_take(NuOpCtx* c, long long nbytes, int ndesc_needed, hipStream_t 
 typedef unsigned short h16_t;
 static inline const float* w16(const void* tbl, long long elem_off) { return reinterpret_cast<const float*>(static_cast<const h16_t*>(tbl) + elem_off); }
 
-static void ev_begin(NuOpCtx* c, hipStream_t stream) {
-    if (c->ev && c->nev + 2 <= c->ev_cap) (void)hipEventRecord(static_cast<hipEvent_t>(c->ev[c->nev]), stream);
-}
-static void ev_end(NuOpCtx* c, hipStream_t stream, double kind, double flops, double bytes) {
-    if (c->ev && c->nev + 2 <= c->ev_cap) {
-        (void)hipEventRecord(static_cast<hipEvent_t>(c->ev[c->nev + 1]), stream);
-        double* m = c->ev_meta + 3 * (c->nev / 2);
-        m[0] = kind; m[1] = flops; m[2] = bytes;
-        c->nev += 2;
-    }
-}
+static inline void ev_begin(NuOpCtx* c, hipStream_t stream) { nu_ctx_ev_begin(c, stream); }
+static inline void ev_end(NuOpCtx* c, hipStream_t stream, double kind, double flops, double bytes) { nu_ctx_ev_end(c, stream, kind, flops, bytes); }
 
 struct NtArgs {
     const float* A; int lda; const float* B; int ldb; int M, N, K; float* C; int ldc; int epi;
@@ -87,52 +57,74 @@ struct NtArgs {
     int st = 0;                     // A16 | C16 | X16 (h16)
     int ktrue = 0;                  // unpadded reduction extent (roofline accounting only)
 };
-static int nt(NuOpCtx* c, const NtArgs& a, hipStream_t stream) {
-    if (a.M <= 0) return NU_OK;
+static int nt_fill(const NuOpCtx* c, const NtArgs& a, NuGemmNT& g) {
     const bool h16 = c->h16 != 0;
     if (h16 && (c->prec != 1 || a.B16 == nullptr)) return NU_ERR_ARG;
-    NuGemmNT g = {};
+    g = NuGemmNT{};
     g.A = a.A; g.lda = a.lda; g.B = h16 ? a.B16 : a.B; g.ldb = a.ldb; g.M = a.M; g.N = a.N; g.K = a.K; g.C = a.C; g.ldc = a.ldc; g.C2 = a.C2;
     g.ldc2 = a.ldc2; g.bias = a.bias; g.H = a.H; g.ldh = a.ldh; g.D = a.D; g.ldd = a.ldd; g.Cadd = a.Cadd; g.ldadd = a.ldadd;
     g.zero_to = a.zero_to; g.act_cols = a.act_cols; g.alpha = 1.0f; g.groups = a.groups; g.sA = a.sA; g.sB = a.sB; g.sC = a.sC;
     g.sBias = a.sBias; g.sH = a.sH; g.epi = a.epi; g.bf16 = h16 ? (1 | NU_GEMM_B16 | a.st) : c->prec; g.mask = a.mask;
     g.mask_nct = a.mask ? a.mask_nct : 0;
+    return NU_OK;
+}
+// algorithmic FLOPs and bytes of one launch at the widths its matrices are stored in (roofline accounting)
+static void nt_cost(const NuOpCtx* c, const NtArgs& a, double* flops, double* bytes) {
+    const bool h16 = c->h16 != 0;
+    const double eA = h16 && (a.st & A16) ? 2 : 4, eB = h16 ? 2 : 4, eC = h16 && (a.st & C16) ? 2 : 4, eX = h16 && (a.st & X16) ? 2 : 4;
+    const bool mask_r = a.mask && (a.epi == NU_EPI_MUL_DRELU || a.epi == NU_EPI_B_RELU);      // sign bits replace H
+    const double K = a.ktrue ? a.ktrue : a.K, M = a.M, N = a.N;
+    *bytes += a.groups * (M * K * eA + N * K * eB + M * N * (eC * (1 + (a.C2 ? 1 : 0)) +
+                          eX * ((a.H && !mask_r ? 1 : 0) + (a.D ? 1 : 0) + (a.Cadd ? 1 : 0))));
+    *flops += 2.0 * M * N * K * a.groups;
+}
+static int nt(NuOpCtx* c, const NtArgs& a, hipStream_t stream) {
+    if (a.M <= 0) return NU_OK;
+    NuGemmNT g;
+    CHK(nt_fill(c, a, g));
     ev_begin(c, stream);
     const int rc = nu_gemm_nt_launch(g, stream);
     if (c->ev) {
-        const double eA = h16 && (a.st & A16) ? 2 : 4, eB = h16 ? 2 : 4, eC = h16 && (a.st & C16) ? 2 : 4, eX = h16 && (a.st & X16) ? 2 : 4;
-        const bool mask_r = a.mask && (a.epi == NU_EPI_MUL_DRELU || a.epi == NU_EPI_B_RELU);      // sign bits replace H
-        const double K = a.ktrue ? a.ktrue : a.K, M = a.M, N = a.N;
-        const double bytes = a.groups * (M * K * eA + N * K * eB + M * N * (eC * (1 + (a.C2 ? 1 : 0)) +
-                                         eX * ((a.H && !mask_r ? 1 : 0) + (a.D ? 1 : 0) + (a.Cadd ? 1 : 0))));
-        ev_end(c, stream, 0.0, 2.0 * M * N * K * a.groups, bytes);
+        double flops = 0, bytes = 0;
+        nt_cost(c, a, &flops, &bytes);
+        ev_end(c, stream, 0.0, flops, bytes);
     }
     return rc;
 }
+// n independent problems: one tile list per run of equal epilogue kinds (nu_gemm_nt_batch_launch); timed as ONE launch
+static int nt_batch(NuOpCtx* c, const NtArgs* a, int n, hipStream_t stream) {
+    NuGemmNT g[16];
+    if (n > 16) return NU_ERR_ARG;
+    int m = 0;
+    double flops = 0, bytes = 0;
+    for (int i = 0; i < n; ++i) {
+        if (a[i].M <= 0) continue;
+        CHK(nt_fill(c, a[i], g[m++]));
+        nt_cost(c, a[i], &flops, &bytes);
+    }
+    if (m == 0) return NU_OK;
+    ev_begin(c, stream);
+    const int rc = nu_gemm_nt_batch_launch(g, m, stream);
+    if (c->ev) ev_end(c, stream, 0.0, flops, bytes);
+    return rc;
+}
 
-// dW[N1, N2] = A0^T B0 (+ A1^T B1), db = column sums of A0; split: nu_wgrad_pick_split.  st16: NU_TN_*_16 flags (h16)
+// dW[N1, N2] = A0^T B0 (+ A1^T B1), db = column sums of A0.  QUEUED (nu_wgrad_defer): every entry below ends with wgrad_flush, which
+// launches the pass's weight gradients together.  st16: NU_TN_*_16 flags (h16)
 static int wgrad(NuOpCtx* c, const float* A0, int lda0, const float* B0, int ldb0, int P, int N1, int N2, float* dW, int ldw, float* db,
                  hipStream_t stream, int st16 = 0, const float* A1 = nullptr, int lda1 = 0, const float* B1 = nullptr, int ldb1 = 0,
                  int groups = 1, long long sA0 = 0, long long sB0 = 0, long long sW = 0, long long sDb = 0) {
     if (P <= 0) return NU_OK;
-    const int S = nu_wgrad_pick_split(P, N1, N2, groups, c->prec);
-    float* ws;
-    long long nb;
-    CHK(ctx_take(c, nu_wgrad_workspace_bytes(N1, N2, S, groups), 2 * groups, stream, &ws, &nb));
     const int st = c->h16 ? st16 : 0;
     NuGemmTN g = {};
     g.A0 = A0; g.lda0 = lda0; g.B0 = B0; g.ldb0 = ldb0; g.A1 = A1; g.lda1 = lda1; g.B1 = B1; g.ldb1 = ldb1; g.P = P; g.N1 = N1;
-    g.N2 = N2; g.S = S; g.groups = groups; g.sA0 = sA0; g.sB0 = sB0; g.bf16 = c->prec | st;
-    ev_begin(c, stream);
-    const int rc = nu_wgrad_enqueue(&g, dW, ldw, sW, db, sDb, ws, nb, c->descs, &c->ndesc, c->cap, stream);
-    if (c->ev) {
-        const double p = P, n1 = N1, n2 = N2;
-        double bytes = p * (n1 * (st & NU_TN_A0_16 ? 2 : 4) + n2 * (st & NU_TN_B0_16 ? 2 : 4)) + 4.0 * n1 * n2;
-        if (A1) bytes += p * (n1 * (st & NU_TN_A1_16 ? 2 : 4) + n2 * (st & NU_TN_B1_16 ? 2 : 4));
-        ev_end(c, stream, 1.0, 2.0 * p * n1 * n2 * groups * (A1 ? 2 : 1), bytes * groups);
-    }
-    return rc;
+    g.N2 = N2; g.S = 1; g.groups = groups; g.sA0 = sA0; g.sB0 = sB0; g.bf16 = c->prec | st;
+    const double p = P, n1 = N1, n2 = N2;
+    double bytes = p * (n1 * (st & NU_TN_A0_16 ? 2 : 4) + n2 * (st & NU_TN_B0_16 ? 2 : 4)) + 4.0 * n1 * n2;
+    if (A1) bytes += p * (n1 * (st & NU_TN_A1_16 ? 2 : 4) + n2 * (st & NU_TN_B1_16 ? 2 : 4));
+    return nu_wgrad_defer(c, &g, dW, ldw, sW, db, sDb, 2.0 * p * n1 * n2 * groups * (A1 ? 2 : 1), bytes * groups, stream);
 }
+static inline int wgrad_flush(NuOpCtx* c, hipStream_t stream) { return nu_wgrad_flush(c, stream); }
 
 // h16: the hidden rows H and the dH written are bf16 under NuOpCtx.h16 (the last hidden layer in front of a skinny head)
 static int skinny_bwd(NuOpCtx* c, const float* dy, int ldy, const float* H, int ldh, int P, int K, const float* Ws, int ldw, int NO,
@@ -255,7 +247,8 @@ extern "C" int nu_sdf_mlp_bwd(NuOpCtx* c, const NuSdfNet* net, NuSdfBufs* a, con
         else CHK(wgrad(c, A[l], 256, u, ldu, P, ls[l].N, ls[l].Kp, ls[l].dWp, ls[l].ldd, c->flat + ls[l].db_off, stream, st));
     }
     CHK(wgrad(c, dYX, 288, a->H[8], 256, P, 257, 256, ls[8].dWp, 256, c->flat + ls[8].db_off, stream));
-    if (second) {          // d W8[sdf row] += sum_p q_8
+    if (second) {          // d W8[sdf row] += sum_p q_8: an ACCUMULATING reduction, so the reduction that writes dW8 must be queued first
+        CHK(wgrad_flush(c, stream));
         float* ws; long long nb;
         CHK(ctx_take(c, nu_colsum_workspace_bytes(256), 1, stream, &ws, &nb));
         CHK(nu_colsum_enqueue(a->Q[8], 256, P, 256, ls[8].dWp, 1, ws, nb, c->descs, &c->ndesc, c->cap, stream));
@@ -267,48 +260,63 @@ extern "C" int nu_sdf_mlp_bwd(NuOpCtx* c, const NuSdfNet* net, NuSdfBufs* a, con
         CHK(nu_embed_jt2(a->E, a->dE0, 64, A[3] + 217, 256, second ? a->G0 : nullptr, 64, second ? a->D[3] + 217 : nullptr, 256,
                          second ? nbar : nullptr, P, dx, 0, stream));
     }
-    return NU_OK;
+    return wgrad_flush(c, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // make_predictor stacks (field.py:371-408): 3 hidden ReLU layers + a 1..3-wide head
 // h16: the hidden activations [0..2], the backward scratch tmp[0], tmp[1] and dH3 are bf16 (the skinny head kernels read / write bf16)
 // ---------------------------------------------------------------------------------------------------------
-static int relu_stack_fwd(NuOpCtx* c, const NuLin* ls, const float* X, int ldx, int rows, float* const* Hs, unsigned long long* const* masks,
-                          int nct, hipStream_t stream) {
-    const float* src = X;
-    int lds = ldx;
+// One make_predictor stack of a pass: layers, input, rows, hidden activations + their sign bits; backward: cotangent of the raw head,
+// scratch, optional input gradient.
+struct Stack {
+    const NuLin* ls; const float* X; int ldx, rows; float* const* Hs; unsigned long long* const* masks;
+    const float* dy = nullptr; int ldy = 0, no = 0; float* dH3 = nullptr; float* const* tmp = nullptr; float* dX = nullptr; int lddx = 0, dxc = 0;
+};
+// The stacks of one pass are independent of each other, so level j of ALL of them is one launch (one tile list, nt_batch): the four
+// light predictors of AppShadingNetwork.forward are 3 launches instead of 12.
+static int relu_stacks_fwd(NuOpCtx* c, const Stack* st, int n, int nct, hipStream_t stream) {
+    NtArgs g[8];
+    if (n > 8) return NU_ERR_ARG;
     for (int j = 0; j < 3; ++j) {
-        NtArgs g = {src, lds, ls[j].Wp, ls[j].Kp, rows, 256, ls[j].Kp, Hs[j], 256, NU_EPI_BIAS_RELU};
-        g.bias = ls[j].bias; g.mask = masks[j]; g.mask_nct = nct;
-        g.B16 = w16(ls[j].Wp16, 0); g.st = (j > 0 ? A16 : 0) | C16;
-        CHK(nt(c, g, stream));
-        src = Hs[j]; lds = 256;
+        for (int k = 0; k < n; ++k) {
+            const NuLin* ls = st[k].ls;
+            g[k] = NtArgs{j == 0 ? st[k].X : st[k].Hs[j - 1], j == 0 ? st[k].ldx : 256, ls[j].Wp, ls[j].Kp, st[k].rows, 256, ls[j].Kp, st[k].Hs[j], 256,
+                          NU_EPI_BIAS_RELU};
+            g[k].bias = ls[j].bias; g[k].mask = st[k].masks[j]; g[k].mask_nct = nct;
+            g[k].B16 = w16(ls[j].Wp16, 0); g[k].st = (j > 0 ? A16 : 0) | C16;
+        }
+        CHK(nt_batch(c, g, n, stream));
     }
     return NU_OK;
 }
-// dH3: gradient w.r.t. the pre-activation of layer 2; tmp[2]: [rows,256] scratch; dX (optional): input gradient
-static int relu_stack_bwd(NuOpCtx* c, const NuLin* ls, const float* X, int ldx, int rows, float* const* Hs,
-                          unsigned long long* const* masks, int nct, const float* dH3, float* const* tmp, float* dX, int lddx, int dx_cols,
-                          hipStream_t stream) {
-    const float* dA = dH3;
+// dH3: gradient w.r.t. the pre-activation of layer 2 (written by the skinny head's backward); tmp[2]: [rows,256] scratch; dX
+// (optional): input gradient.  h16: dH3 and tmp[] are bf16.
+static int relu_stacks_bwd(NuOpCtx* c, const Stack* st, int n, int nct, hipStream_t stream) {
+    NtArgs g[8];
+    if (n > 8) return NU_ERR_ARG;
     for (int j = 2; j >= 0; --j) {
-        const float* u = j == 0 ? X : Hs[j - 1];
-        const int ldu = j == 0 ? ldx : 256;
-        const int a16 = 1;                          // dA: dH3 (written by the skinny head's backward) or tmp[j], bf16 both
-        CHK(wgrad(c, dA, 256, u, ldu, rows, 256, ls[j].Kp, ls[j].dWp, ls[j].ldd, c->flat + ls[j].db_off, stream,
-                  (a16 ? NU_TN_A0_16 : 0) | (j > 0 ? NU_TN_B0_16 : 0)));
-        if (j > 0) {
-            NtArgs g = {dA, 256, ls[j].WpT, ls[j].ldT, rows, 256, 256, tmp[j - 1], 256, NU_EPI_MUL_DRELU};
-            g.H = Hs[j - 1]; g.ldh = 256; g.mask = masks[j - 1]; g.mask_nct = nct;
-            g.B16 = w16(ls[j].WpT16, 0); g.st = (a16 ? A16 : 0) | C16 | X16;
-            CHK(nt(c, g, stream));
-            dA = tmp[j - 1];
-        } else if (dX != nullptr) {
-            NtArgs g = {dA, 256, ls[j].WpT, ls[j].ldT, rows, dx_cols, 256, dX, lddx, NU_EPI_PLAIN};
-            g.B16 = w16(ls[j].WpT16, 0); g.st = A16;
-            CHK(nt(c, g, stream));
+        int m = 0;
+        for (int k = 0; k < n; ++k) {
+            const Stack& s = st[k];
+            const NuLin* ls = s.ls;
+            const float* dA = j == 2 ? s.dH3 : s.tmp[j];
+            const float* u = j == 0 ? s.X : s.Hs[j - 1];
+            const int ldu = j == 0 ? s.ldx : 256;
+            CHK(wgrad(c, dA, 256, u, ldu, s.rows, 256, ls[j].Kp, ls[j].dWp, ls[j].ldd, c->flat + ls[j].db_off, stream,
+                      NU_TN_A0_16 | (j > 0 ? NU_TN_B0_16 : 0)));
+            if (j > 0) {
+                g[m] = NtArgs{dA, 256, ls[j].WpT, ls[j].ldT, s.rows, 256, 256, s.tmp[j - 1], 256, NU_EPI_MUL_DRELU};
+                g[m].H = s.Hs[j - 1]; g[m].ldh = 256; g[m].mask = s.masks[j - 1]; g[m].mask_nct = nct;
+                g[m].B16 = w16(ls[j].WpT16, 0); g[m].st = A16 | C16 | X16;
+                ++m;
+            } else if (s.dX != nullptr) {
+                g[m] = NtArgs{dA, 256, ls[j].WpT, ls[j].ldT, s.rows, s.dxc, 256, s.dX, s.lddx, NU_EPI_PLAIN};
+                g[m].B16 = w16(ls[j].WpT16, 0); g[m].st = A16;
+                ++m;
+            }
         }
+        CHK(nt_batch(c, g, m, stream));
     }
     return NU_OK;
 }
@@ -400,7 +408,7 @@ extern "C" int nu_nerfpp_mlp_bwd(NuOpCtx* c, const NuNerfNet* net, const float* 
             CHK(nu_nerf_embed_bwd(pt, pt_ld, b->H[0], b->V, b->dE4, 96, dskip + 256, 352, b->dF + 256, ldf, P, b->dx, b->ddir, stream));
         }
     }
-    return NU_OK;
+    return wgrad_flush(c, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -430,10 +438,11 @@ extern "C" int nu_shading_stack_fwd(NuOpCtx* c, const NuShadeNet* net, NuShadeBu
                             s->RLin, s->SD, stream));
     if (R > 0) CHK(nu_spec_encode(s->extra_dirs, s->extra_pts, R, s->extra_pts ? net->sphere : 0, s->OLin + (long long)3 * P * net->ld_ol,
                                   net->ld_ol, stream));
-    CHK(relu_stack_fwd(c, net->outer_light, s->OLin, net->ld_ol, rows_ol, s->OLh, s->maskOL, 2, stream));
-    CHK(relu_stack_fwd(c, net->inner_light, s->ILin, 128, 2 * P, s->ILh, s->maskIL, 2, stream));
-    CHK(relu_stack_fwd(c, net->inner_weight, s->IWin, 96, P, s->IWh, s->maskIW, 2, stream));
-    CHK(relu_stack_fwd(c, net->refrac_light, s->RLin, net->ld_rl, P, s->RLh, s->maskRL, 2, stream));
+    const Stack stacks[4] = {{net->outer_light, s->OLin, net->ld_ol, rows_ol, s->OLh, s->maskOL},
+                             {net->inner_light, s->ILin, 128, 2 * P, s->ILh, s->maskIL},
+                             {net->inner_weight, s->IWin, 96, P, s->IWh, s->maskIW},
+                             {net->refrac_light, s->RLin, net->ld_rl, P, s->RLh, s->maskRL}};
+    CHK(relu_stacks_fwd(c, stacks, 4, 2, stream));
     CHK(skinny_fwd(c, s->OLh[2], 256, rows_ol, 256, net->outer_light[3].Wp, 256, net->outer_light[3].bias, 3, s->OLo, 4, stream, true));
     CHK(skinny_fwd(c, s->ILh[2], 256, 2 * P, 256, net->inner_light[3].Wp, 256, net->inner_light[3].bias, 3, s->ILo, 4, stream, true));
     CHK(skinny_fwd(c, s->IWh[2], 256, P, 256, net->inner_weight[3].Wp, 256, net->inner_weight[3].bias, 1, s->IWo, 1, stream, true));
@@ -452,19 +461,17 @@ extern "C" int nu_shading_stack_bwd(NuOpCtx* c, const NuShadeNet* net, NuShadeBu
     if (stage == 0)
         return nu_shade_combine_bwd(s->Mraw, 8, s->OLo, s->ILo, s->IWo, s->RLo, s->SD, net->lut, idx, P, net->exp_max, dcolor_rm, s->dMraw,
                                     s->dOLo, s->dILo, s->dIWo, s->dRLo, s->dNoV, stream);
-    struct Pred { const NuLin* ls; float* const* Hs; unsigned long long* const* masks; const float* dy; int ldy, rows, no; const float* X;
-                  int ldx; float* dX; int lddx, dxc; float* dH3; float* const* tmp; };
-    const Pred preds[4] = {
-        {net->outer_light, s->OLh, s->maskOL, s->dOLo, 4, rows_ol, 3, s->OLin, net->ld_ol, s->dOLin, net->ld_ol, net->ld_ol, s->dH3[0], s->tmpOL},
-        {net->inner_light, s->ILh, s->maskIL, s->dILo, 4, 2 * P, 3, s->ILin, 128, s->dILin, 128, 128, s->dH3[1], s->tmpIL},
-        {net->inner_weight, s->IWh, s->maskIW, s->dIWo, 1, P, 1, s->IWin, 96, nullptr, 0, 0, s->dH3[2], s->tmpIW},
-        {net->refrac_light, s->RLh, s->maskRL, s->dRLo, 4, P, 3, s->RLin, net->ld_rl, nullptr, 0, 0, s->dH3[3], s->tmpRL}};
-    for (const Pred& p : preds) {
+    const Stack stacks[4] = {
+        {net->outer_light, s->OLin, net->ld_ol, rows_ol, s->OLh, s->maskOL, s->dOLo, 4, 3, s->dH3[0], s->tmpOL, s->dOLin, net->ld_ol, net->ld_ol},
+        {net->inner_light, s->ILin, 128, 2 * P, s->ILh, s->maskIL, s->dILo, 4, 3, s->dH3[1], s->tmpIL, s->dILin, 128, 128},
+        {net->inner_weight, s->IWin, 96, P, s->IWh, s->maskIW, s->dIWo, 1, 1, s->dH3[2], s->tmpIW, nullptr, 0, 0},
+        {net->refrac_light, s->RLin, net->ld_rl, P, s->RLh, s->maskRL, s->dRLo, 4, 3, s->dH3[3], s->tmpRL, nullptr, 0, 0}};
+    for (const Stack& p : stacks) {
         const NuLin& head = p.ls[3];
         CHK(skinny_bwd(c, p.dy, p.ldy, p.Hs[2], 256, p.rows, 256, head.Wp, 256, p.no, p.dH3, 256, 1, head.dWp, head.ldd, c->flat + head.db_off, stream,
                        true));
-        CHK(relu_stack_bwd(c, p.ls, p.X, p.ldx, p.rows, p.Hs, p.masks, 2, p.dH3, p.tmp, p.dX, p.lddx, p.dxc, stream));
     }
+    CHK(relu_stacks_bwd(c, stacks, 4, 2, stream));
     CHK(nu_shade_encode_bwd(nrm, pt, 8, s->SD, s->dOLin, net->ld_ol, net->sphere, s->dILin, s->dNoV, P, s->dn, s->dMraw, 8, stream));
     // materials backward
     CHK(skinny_bwd(c, s->dMraw, 8, s->M[2], 1024, P, 1024, net->Ws6, 1024, 6, s->dM[2], 1024, 1, net->dWs6, 1024, c->flat + net->db6_off, stream,
@@ -483,5 +490,6 @@ extern "C" int nu_shading_stack_bwd(NuOpCtx* c, const NuShadeNet* net, NuShadeBu
     CHK(wgrad(c, dA, 1024, YX, 288, P, 1024, 288, net->dWpM0, 288, c->flat + net->dbM_off[0], stream, NU_TN_A0_16));
     NtArgs gy = {dA, 1024, net->WpTM0, 1024, P, 288, 1024, s->dYX, 288, NU_EPI_PLAIN};
     gy.B16 = w16(net->WpTM0_16, 0); gy.st = A16;
-    return nt(c, gy, stream);
+    CHK(nt(c, gy, stream));
+    return wgrad_flush(c, stream);
 }

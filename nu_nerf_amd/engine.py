@@ -38,7 +38,7 @@ class GemmNT(ctypes.Structure):
                 ("D", c_p), ("ldd", c_int), ("Cadd", c_p), ("ldadd", c_int), ("zero_to", c_int), ("act_cols", c_int),
                 ("alpha", c_f), ("groups", c_int), ("sA", c_ll), ("sB", c_ll), ("sC", c_ll), ("sC2", c_ll),
                 ("sBias", c_ll), ("sH", c_ll), ("sD", c_ll), ("sCadd", c_ll), ("epi", c_int), ("bf16", c_int),
-                ("mask", c_p), ("mask_nct", c_int), ("pad_", c_int)]
+                ("mask", c_p), ("mask_nct", c_int), ("mask_ct0", c_int)]
 
 
 class GemmTN(ctypes.Structure):
@@ -67,11 +67,18 @@ class Lin(ctypes.Structure):
                 ("ldT", c_int), ("ldd", c_int), ("pad_", c_int), ("Wp16", c_p), ("WpT16", c_p)]
 
 
+class WgradItem(ctypes.Structure):
+    """Mirror of NuWgradItem: one queued weight gradient of a backward pass."""
+    _fields_ = [("g", GemmTN), ("dW", c_p), ("ldw", c_int), ("pad_", c_int), ("sW", c_ll), ("db", c_p), ("sDb", c_ll),
+                ("flops", ctypes.c_double), ("bytes", ctypes.c_double)]
+
+
 class OpCtx(ctypes.Structure):
-    """Mirror of NuOpCtx: arithmetic mode, flat gradient buffer, deferred-reduction arena (shared by the Python-sequenced path)."""
+    """Mirror of NuOpCtx: arithmetic mode, flat gradient buffer, deferred-reduction arena (shared by the Python-sequenced path),
+    the queue of a pass's weight gradients."""
     _fields_ = [("prec", c_int), ("h16", c_int), ("flat", c_p), ("arena", c_p), ("arena_floats", c_ll), ("arena_off", c_ll),
                 ("descs", c_p), ("ndesc", c_int), ("cap", c_int), ("ev", c_p), ("ev_meta", c_p), ("nev", c_int), ("ev_cap", c_int),
-                ("forked", c_int), ("pad_", c_int)]
+                ("forked", c_int), ("pad_", c_int), ("pend", c_p), ("npend", c_int), ("pend_cap", c_int)]
 
 
 class SdfNet(ctypes.Structure):
@@ -179,9 +186,13 @@ class Stage1Engine:
         self._arena = None
         # one context for both sequencing paths (network-level C entries and the launch-by-launch Python path below): the
         # descriptor count and the arena offset live in the struct
+        # the weight gradients of a backward pass are queued and launched together (include/nu_nerf.h: nu_wgrad_defer / _flush)
+        assert lib.nu_wgrad_item_size() == ctypes.sizeof(WgradItem), "WgradItem ABI mismatch"
+        self._pend = (WgradItem * 32)()
         self._ctx = OpCtx(prec=self.bf16, h16=1 if self.h16 else 0, flat=0, arena=0, arena_floats=0, arena_off=0,
                           descs=ctypes.cast(self._rd, c_p).value, ndesc=0, cap=self._rd_cap, ev=0, ev_meta=0, nev=0, ev_cap=0,
-                          forked=0, pad_=0)
+                          forked=0, pad_=0, pend=ctypes.cast(self._pend, c_p).value, npend=0, pend_cap=32)
+        self._wg_depth, self._wg_held = 0, []
         self._ndesc_p = ctypes.cast(ctypes.addressof(self._ctx) + OpCtx.ndesc.offset, ctypes.POINTER(c_int))
         for fn, st in (("nu_op_ctx_size", OpCtx), ("nu_sdf_net_size", SdfNet), ("nu_sdf_bufs_size", SdfBufs), ("nu_nerf_net_size", NerfNet),
                        ("nu_nerf_bufs_size", NerfBufs), ("nu_shade_net_size", ShadeNet), ("nu_shade_bufs_size", ShadeBufs)):
@@ -331,7 +342,9 @@ class Stage1Engine:
         if self._ctx.forked:
             raise L.NuNerfLibraryError("split-reduction arena (or descriptor table) full while two streams share it: raise "
                                        "NU_ARENA_FLOATS or lower NU_TWO_STREAM_SAMPLES (NU_ERR_WORKSPACE)")
-        self.flush_reductions()
+        # reductions only: the weight gradients still queued keep waiting for the end of their pass (their split must not
+        # depend on when the arena happened to fill)
+        L.check(self.lib.nu_ctx_reduce(ctypes.byref(self._ctx), self.stream()), "nu_ctx_reduce")
 
     # ------------------------------------------------------------------ layer tables
     def _build_layers(self):
@@ -689,7 +702,7 @@ class Stage1Engine:
 
     def wgrad(self, A0, lda0, B0, ldb0, P, N1, N2, dW, ldw, db, *, A1=0, lda1=0, B1=0, ldb1=0, groups=1, sA0=0, sB0=0,
               sA1=0, sB1=0, sW=0, sDb=0, n2true=None):
-        kt = self._ktime if self.ktime_on else None
+        kt = self._ktime if (self.ktime_on and self._wg_depth == 0 and self._ctx.ev == 0) else None     # (queued launches: timed by the library)
         if kt is not None:
             e0, e1 = self._event_pair()
             e0.record()
@@ -701,13 +714,47 @@ class Stage1Engine:
                              4.0 * groups * (npair * P * (N1 + (n2true or N2)) + N1 * N2)))
 
     def _wgrad(self, A0, lda0, B0, ldb0, P, N1, N2, dW, ldw, db, A1, lda1, B1, ldb1, groups, sA0, sB0, sA1, sB1, sW, sDb):
-        S = self.lib.nu_wgrad_pick_split(P, N1, N2, groups, self.bf16)     # the rule the network-level C entries use too
-        if self._ctx.ndesc + 2 * groups > self._rd_cap:
-            self._forced_flush()
-        ws, nb = self._arena_take(self.lib.nu_wgrad_workspace_bytes(N1, N2, S, groups))
-        g = GemmTN(A0, lda0, B0, ldb0, A1, lda1, B1, ldb1, P, N1, N2, 0, 0, S, groups, sA0, sB0, sA1, sB1, 0, 0, self.bf16, 0)
-        L.check(self.lib.nu_wgrad_enqueue(ctypes.byref(g), c_p(dW), ldw, c_ll(sW), c_p(db), c_ll(sDb), c_p(ws), c_ll(nb),
-                                          self._rd, self._ndesc_p, self._rd_cap, self.stream()), "nu_wgrad_enqueue")
+        """Queue one weight gradient (nu_wgrad_defer).  Inside `with self.wgrad_batch():` the queue is launched when the block
+        exits -- the caller keeps every operand alive and unmodified until then; outside, at once."""
+        if P <= 0:
+            return
+        self._ensure_arena()
+        g = GemmTN(A0, lda0, B0, ldb0, A1, lda1, B1, ldb1, P, N1, N2, 0, 0, 1, groups, sA0, sB0, sA1, sB1, 0, 0, self.bf16, 0)
+        npair = 2 if A1 else 1
+        L.check(self.lib.nu_wgrad_defer(ctypes.byref(self._ctx), ctypes.byref(g), c_p(dW), ldw, c_ll(sW), c_p(db), c_ll(sDb),
+                                        ctypes.c_double(2.0 * P * N1 * N2 * groups * npair),
+                                        ctypes.c_double(4.0 * groups * (npair * P * (N1 + N2) + N1 * N2)), self.stream()), "nu_wgrad_defer")
+        if self._wg_depth == 0:
+            self.flush_wgrads()
+
+    def flush_wgrads(self):
+        L.check(self.lib.nu_wgrad_flush(ctypes.byref(self._ctx), self.stream()), "nu_wgrad_flush")
+
+    def wgrad_batch(self):
+        """Context of a backward pass sequenced from Python: weight gradients queued inside are launched together at the exit
+        (one launch per tile class, like the network-level C entries).  The caller must keep the operands of every queued weight
+        gradient referenced until the block ends (`keep(t)` on the returned object holds a tensor for it)."""
+        eng = self
+
+        class _Batch:
+            def keep(self, *ts):
+                eng._wg_held.extend(ts)             # (nested blocks share the list: it is dropped when the outermost one has flushed)
+                return ts[0] if len(ts) == 1 else ts
+
+            def __enter__(self):
+                eng._wg_depth += 1
+                return self
+
+            def __exit__(self, et, ev, tb):
+                eng._wg_depth -= 1
+                if eng._wg_depth == 0:
+                    if et is None:
+                        eng.flush_wgrads()
+                    else:
+                        eng._ctx.npend = 0          # an error is propagating: drop the queue instead of launching on dead buffers
+                    eng._wg_held = []
+                return False
+        return _Batch()
 
     def skinny_fwd(self, H, ldh, P, K, Ws, ldw, b, NO, out, ldo):
         L.check(self.lib.nu_skinny_fwd(c_p(H), ldh, P, K, c_p(Ws), ldw, c_p(b), NO, c_p(out), ldo, self.stream()),
@@ -888,16 +935,17 @@ class Stage1Engine:
             else:
                 self.nt(addr(srcA), lda, addr(*WT), ldT, P, N, K, addr(A[l]), 256, EPI_B_SP if second else EPI_MUL_DSP,
                         H=addr(H[l + 1]), ldh=256, Cadd=addr(Cb[l]) if second else 0, ldadd=256, zero_to=256)
-        # weight gradients
-        for l in range(8):
-            u, ldu = (E, 64) if l == 0 else (H[l], 256)
-            if second:
-                self.wgrad(addr(A[l]), 256, addr(u), ldu, P, ls[l].N, ls[l].Kp, addr(*ls[l].dWp), ls[l].ldd,
-                           addr(flat, ls[l].db_off), A1=addr(a['D'][l]), lda1=256, B1=addr(Q[l]), ldb1=64 if l == 0 else 256)
-            else:
-                self.wgrad(addr(A[l]), 256, addr(u), ldu, P, ls[l].N, ls[l].Kp, addr(*ls[l].dWp), ls[l].ldd,
-                           addr(flat, ls[l].db_off))
-        self.wgrad(addr(dYX), 288, addr(H[8]), 256, P, 257, 256, addr(*ls[8].dWp), 256, addr(flat, ls[8].db_off))
+        # weight gradients: one queue, launched together (every operand is held by the lists above until this method returns)
+        with self.wgrad_batch():
+            for l in range(8):
+                u, ldu = (E, 64) if l == 0 else (H[l], 256)
+                if second:
+                    self.wgrad(addr(A[l]), 256, addr(u), ldu, P, ls[l].N, ls[l].Kp, addr(*ls[l].dWp), ls[l].ldd,
+                               addr(flat, ls[l].db_off), A1=addr(a['D'][l]), lda1=256, B1=addr(Q[l]), ldb1=64 if l == 0 else 256)
+                else:
+                    self.wgrad(addr(A[l]), 256, addr(u), ldu, P, ls[l].N, ls[l].Kp, addr(*ls[l].dWp), ls[l].ldd,
+                               addr(flat, ls[l].db_off))
+            self.wgrad(addr(dYX), 288, addr(H[8]), 256, P, 257, 256, addr(*ls[8].dWp), 256, addr(flat, ls[8].db_off))
         if second:
             # d W8[sdf row] += sum_p q_8   (the reverse sweep starts from W8's sdf row)
             self.colsum(addr(Q[8]), 256, P, 256, addr(*ls[8].dWp), 1)
@@ -938,18 +986,19 @@ class Stage1Engine:
 
     def relu_stack_bwd(self, layers, X, ldx, rows, Hs, dH3, flat, dX=None, lddx=0, dx_cols=0):
         """dH3 = gradient w.r.t. post-ReLU H3 already masked by relu'(H3) (i.e. d pre-activation of layer 2)."""
-        dA = dH3
-        for j in (2, 1, 0):
-            lay = layers[j]
-            u, ldu = (X, ldx) if j == 0 else (Hs[j - 1], 256)
-            self.wgrad(addr(dA), 256, addr(u), ldu, rows, 256, lay.Kp, addr(*lay.dWp), lay.ldd, addr(flat, lay.db_off))
-            if j > 0:
-                nxt = self.empty(rows, 256)
-                self.nt(addr(dA), 256, addr(*lay.WpT), lay.ldT, rows, 256, 256, addr(nxt), 256, EPI_MUL_DRELU,
-                        H=addr(Hs[j - 1]), ldh=256, mask=getattr(Hs[j - 1], '_nu_mask', None))
-                dA = nxt
-            elif dX is not None:
-                self.nt(addr(dA), 256, addr(*lay.WpT), lay.ldT, rows, dx_cols, 256, addr(dX), lddx, EPI_PLAIN)
+        with self.wgrad_batch() as wb:        # (inside a caller's batch the queue is launched with the caller's)
+            dA = wb.keep(dH3)
+            for j in (2, 1, 0):
+                lay = layers[j]
+                u, ldu = (X, ldx) if j == 0 else (Hs[j - 1], 256)
+                self.wgrad(addr(dA), 256, addr(u), ldu, rows, 256, lay.Kp, addr(*lay.dWp), lay.ldd, addr(flat, lay.db_off))
+                if j > 0:
+                    nxt = wb.keep(self.empty(rows, 256))
+                    self.nt(addr(dA), 256, addr(*lay.WpT), lay.ldT, rows, 256, 256, addr(nxt), 256, EPI_MUL_DRELU,
+                            H=addr(Hs[j - 1]), ldh=256, mask=getattr(Hs[j - 1], '_nu_mask', None))
+                    dA = nxt
+                elif dX is not None:
+                    self.nt(addr(dA), 256, addr(*lay.WpT), lay.ldT, rows, dx_cols, 256, addr(dX), lddx, EPI_PLAIN)
 
     # ------------------------------------------------------------------ shading stack
     def shading_forward(self, a, pt, idx, P, color_rm, extra_dirs=None, extra_pts=None):
@@ -1096,39 +1145,40 @@ class Stage1Engine:
             dIWo += d_occ_raw
         if d_mat_raw is not None:
             dMraw += d_mat_raw
-        # heads + hidden stacks of the four light predictors
-        ld_ol, ld_rl = self.ld_ol, self.ld_rl
-        dOLin, dILin = e(rows_ol, ld_ol), e(2 * P, 128)
-        for layers, Hs, dy, ldy, rows, no, X, ldx, dX, lddx, dxc in (
-                (self.outer_light, s['OLh'], dOLo, 4, rows_ol, 3, s['OLin'], ld_ol, dOLin, ld_ol, ld_ol),
-                (self.inner_light, s['ILh'], dILo, 4, 2 * P, 3, s['ILin'], 128, dILin, 128, 128),
-                (self.inner_weight, s['IWh'], dIWo, 1, P, 1, s['IWin'], 96, None, 0, 0),
-                (self.refrac_light, s['RLh'], dRLo, 4, P, 3, s['RLin'], ld_rl, None, 0, 0)):
-            head = layers[3]
-            dH3 = e(rows, 256)
-            self.skinny_bwd(addr(dy), ldy, addr(Hs[2]), 256, rows, 256, addr(*head.Wp), 256, no, addr(dH3), 256, 1, 0,
-                            addr(*head.dWp), head.ldd, addr(flat, head.db_off))
-            self.relu_stack_bwd(layers, X, ldx, rows, Hs, dH3, flat, dX, lddx, dxc)
-        dn = e(P, 3)
-        L.check(lib.nu_shade_encode_bwd(c_p(addr(a['n'])), c_p(addr(pt)), 8, c_p(addr(s['SD'])), c_p(addr(dOLin)), ld_ol,
-                                        1 if self.sphere_direction else 0, c_p(addr(dILin)), c_p(addr(dNoV)), P,
-                                        c_p(addr(dn)), c_p(addr(dMraw)), 8, S), "nu_shade_encode_bwd")
-        # materials backward
-        db0, db12, db6 = self.mat_db
-        dM3 = e(P, 1024)
-        self.skinny_bwd(addr(dMraw), 8, addr(s['M3']), 1024, P, 1024, addr(self.Ws6), 1024, 6, addr(dM3), 1024, 1, 0,
-                        addr(self.dWs6), 1024, addr(flat, db6))
-        dA = dM3
-        for j, Hin in ((2, s['M2']), (1, s['M1'])):
-            self.wgrad(addr(dA), 1024, addr(Hin), 1024, P, 256, 256, addr(self.dWpM[j]), 256, addr(flat, db12[j]),
-                       groups=4, sA0=256, sB0=256, sW=65536, sDb=256)
-            nxt = e(P, 1024)
-            self.nt(addr(dA), 1024, addr(self.WpTM[j]), 256, P, 256, 256, addr(nxt), 1024, EPI_MUL_DRELU,
-                    H=addr(Hin), ldh=1024, groups=4, sA=256, sB=65536, sC=256, sH=256, mask=getattr(Hin, '_nu_mask', None))
-            dA = nxt
-        self.wgrad(addr(dA), 1024, addr(a['YX']), 288, P, 1024, 288, addr(self.dWpM0), 288, addr(flat, db0))
-        dYX = e(P, 288)
-        self.nt(addr(dA), 1024, addr(self.WpTM0), 1024, P, 288, 1024, addr(dYX), 288, EPI_PLAIN)
+        with self.wgrad_batch() as wb:        # the pass's weight gradients: one queue, launched together at the end of the block
+            # heads + hidden stacks of the four light predictors
+            ld_ol, ld_rl = self.ld_ol, self.ld_rl
+            dOLin, dILin = e(rows_ol, ld_ol), e(2 * P, 128)
+            for layers, Hs, dy, ldy, rows, no, X, ldx, dX, lddx, dxc in (
+                    (self.outer_light, s['OLh'], dOLo, 4, rows_ol, 3, s['OLin'], ld_ol, dOLin, ld_ol, ld_ol),
+                    (self.inner_light, s['ILh'], dILo, 4, 2 * P, 3, s['ILin'], 128, dILin, 128, 128),
+                    (self.inner_weight, s['IWh'], dIWo, 1, P, 1, s['IWin'], 96, None, 0, 0),
+                    (self.refrac_light, s['RLh'], dRLo, 4, P, 3, s['RLin'], ld_rl, None, 0, 0)):
+                head = layers[3]
+                dH3 = wb.keep(e(rows, 256))
+                self.skinny_bwd(addr(dy), ldy, addr(Hs[2]), 256, rows, 256, addr(*head.Wp), 256, no, addr(dH3), 256, 1, 0,
+                                addr(*head.dWp), head.ldd, addr(flat, head.db_off))
+                self.relu_stack_bwd(layers, X, ldx, rows, Hs, dH3, flat, dX, lddx, dxc)
+            dn = e(P, 3)
+            L.check(lib.nu_shade_encode_bwd(c_p(addr(a['n'])), c_p(addr(pt)), 8, c_p(addr(s['SD'])), c_p(addr(dOLin)), ld_ol,
+                                            1 if self.sphere_direction else 0, c_p(addr(dILin)), c_p(addr(dNoV)), P,
+                                            c_p(addr(dn)), c_p(addr(dMraw)), 8, S), "nu_shade_encode_bwd")
+            # materials backward
+            db0, db12, db6 = self.mat_db
+            dM3 = wb.keep(e(P, 1024))
+            self.skinny_bwd(addr(dMraw), 8, addr(s['M3']), 1024, P, 1024, addr(self.Ws6), 1024, 6, addr(dM3), 1024, 1, 0,
+                            addr(self.dWs6), 1024, addr(flat, db6))
+            dA = dM3
+            for j, Hin in ((2, s['M2']), (1, s['M1'])):
+                self.wgrad(addr(dA), 1024, addr(Hin), 1024, P, 256, 256, addr(self.dWpM[j]), 256, addr(flat, db12[j]),
+                           groups=4, sA0=256, sB0=256, sW=65536, sDb=256)
+                nxt = wb.keep(e(P, 1024))
+                self.nt(addr(dA), 1024, addr(self.WpTM[j]), 256, P, 256, 256, addr(nxt), 1024, EPI_MUL_DRELU,
+                        H=addr(Hin), ldh=1024, groups=4, sA=256, sB=65536, sC=256, sH=256, mask=getattr(Hin, '_nu_mask', None))
+                dA = nxt
+            self.wgrad(addr(dA), 1024, addr(a['YX']), 288, P, 1024, 288, addr(self.dWpM0), 288, addr(flat, db0))
+            dYX = e(P, 288)
+            self.nt(addr(dA), 1024, addr(self.WpTM0), 1024, P, 288, 1024, addr(dYX), 288, EPI_PLAIN)
         return dYX, dn
 
     # ------------------------------------------------------------------ NeRF++ background
@@ -1221,49 +1271,50 @@ class Stage1Engine:
             L.check(lib.nu_nerfpp_mlp_bwd(ctypes.byref(self._ctx), ctypes.byref(self._nerf_net), c_p(addr(pt)), pt.shape[1],
                                           ctypes.byref(cb), c_p(addr(dsig)), c_p(addr(drgb)), S), "nu_nerfpp_mlp_bwd")
             return
-        # rgb head -> view layer
-        dHV = e(P, 128)
-        self.skinny_bwd(addr(drgb), 4, addr(b['HV']), 128, P, 128, addr(*self.nerf_rgb.Wp), 128, 3, addr(dHV), 128, 1, 0,
-                        addr(*self.nerf_rgb.dWp), 128, addr(flat, self.nerf_rgb.db_off))
-        self.wgrad(addr(dHV), 128, addr(b['V']), 288, P, 128, 288, addr(*self.nerf_view.dWp), 288,
-                   addr(flat, self.nerf_view.db_off))
-        ldf = 288 if want_in else 256
-        dF = e(P, ldf)   # gradient w.r.t. V = feature_linear output (256) | view embedding (27, stage 2 only)
-        self.nt(addr(dHV), 128, addr(*self.nerf_view.WpT), self.nerf_view.ldT, P, ldf, 128, addr(dF), ldf, EPI_PLAIN)
-        self.wgrad(addr(dF), ldf, addr(H[8]), 256, P, 256, 256, addr(*self.nerf_feat.dWp), 256,
-                   addr(flat, self.nerf_feat.db_off))
-        # density head: dH8_alpha (masked by relu'(H8)), then add the feature path
-        dH8a = e(P, 256)
-        self.skinny_bwd(addr(dsig), 1, addr(H[8]), 256, P, 256, addr(*self.nerf_alpha.Wp), 256, 1, addr(dH8a), 256, 1, 0,
-                        addr(*self.nerf_alpha.dWp), 256, addr(flat, self.nerf_alpha.db_off))
-        dA = e(P, 256)
-        self.nt(addr(dF), ldf, addr(*self.nerf_feat.WpT), self.nerf_feat.ldT, P, 256, 256, addr(dA), 256, EPI_B_RELU,
-                H=addr(H[8]), ldh=256, Cadd=addr(dH8a), ldadd=256, mask=getattr(H[8], '_nu_mask', None))
-        # trunk, layers 7..0 ; dA = d pre-activation of layer i (row stride lda)
-        dskip, lda = None, 256
-        for i in range(7, -1, -1):
-            lay = self.nerf[i]
-            ldu = 96 if i == 0 else (352 if i == 5 else 256)
-            self.wgrad(addr(dA), lda, addr(H[i]), ldu, P, 256, lay.Kp, addr(*lay.dWp), lay.ldd, addr(flat, lay.db_off))
-            if i > 0:
-                if i == 5 and want_in:
-                    # columns 256..339 of the layer-5 input are the re-concatenated embedding: keep their plain gradient
-                    nxt = e(P, 352)
-                    self.nt(addr(dA), lda, addr(*lay.WpT), lay.ldT, P, 340, 256, addr(nxt), 352, EPI_MUL_DRELU,
-                            H=addr(H[i]), ldh=ldu, act_cols=256, zero_to=352, mask=getattr(H[i], '_nu_mask', None))
-                    dskip = nxt
-                    dA, lda = nxt, 352
-                else:
-                    nxt = e(P, 256)
-                    self.nt(addr(dA), lda, addr(*lay.WpT), lay.ldT, P, 256, 256, addr(nxt), 256, EPI_MUL_DRELU,
-                            H=addr(H[i]), ldh=ldu, mask=getattr(H[i], '_nu_mask', None))
-                    dA, lda = nxt, 256
-            elif want_in:
-                dE4 = e(P, 96)
-                self.nt(addr(dA), lda, addr(*lay.WpT), lay.ldT, P, 84, 256, addr(dE4), 96, EPI_PLAIN, zero_to=96)
-                L.check(lib.nu_nerf_embed_bwd(c_p(addr(pt)), pt.shape[1], c_p(addr(H[0])), c_p(addr(b['V'])), c_p(addr(dE4)), 96,
-                                              c_p(addr(dskip, 256)), 352, c_p(addr(dF, 256)), ldf, P, c_p(addr(dx)),
-                                              c_p(addr(ddir)), S), "nu_nerf_embed_bwd")
+        with self.wgrad_batch() as wb:        # the pass's weight gradients: one queue, launched together at the end of the block
+            # rgb head -> view layer
+            dHV = wb.keep(e(P, 128))
+            self.skinny_bwd(addr(drgb), 4, addr(b['HV']), 128, P, 128, addr(*self.nerf_rgb.Wp), 128, 3, addr(dHV), 128, 1, 0,
+                            addr(*self.nerf_rgb.dWp), 128, addr(flat, self.nerf_rgb.db_off))
+            self.wgrad(addr(dHV), 128, addr(b['V']), 288, P, 128, 288, addr(*self.nerf_view.dWp), 288,
+                       addr(flat, self.nerf_view.db_off))
+            ldf = 288 if want_in else 256
+            dF = wb.keep(e(P, ldf))   # gradient w.r.t. V = feature_linear output (256) | view embedding (27, stage 2 only)
+            self.nt(addr(dHV), 128, addr(*self.nerf_view.WpT), self.nerf_view.ldT, P, ldf, 128, addr(dF), ldf, EPI_PLAIN)
+            self.wgrad(addr(dF), ldf, addr(H[8]), 256, P, 256, 256, addr(*self.nerf_feat.dWp), 256,
+                       addr(flat, self.nerf_feat.db_off))
+            # density head: dH8_alpha (masked by relu'(H8)), then add the feature path
+            dH8a = wb.keep(e(P, 256))
+            self.skinny_bwd(addr(dsig), 1, addr(H[8]), 256, P, 256, addr(*self.nerf_alpha.Wp), 256, 1, addr(dH8a), 256, 1, 0,
+                            addr(*self.nerf_alpha.dWp), 256, addr(flat, self.nerf_alpha.db_off))
+            dA = wb.keep(e(P, 256))
+            self.nt(addr(dF), ldf, addr(*self.nerf_feat.WpT), self.nerf_feat.ldT, P, 256, 256, addr(dA), 256, EPI_B_RELU,
+                    H=addr(H[8]), ldh=256, Cadd=addr(dH8a), ldadd=256, mask=getattr(H[8], '_nu_mask', None))
+            # trunk, layers 7..0 ; dA = d pre-activation of layer i (row stride lda)
+            dskip, lda = None, 256
+            for i in range(7, -1, -1):
+                lay = self.nerf[i]
+                ldu = 96 if i == 0 else (352 if i == 5 else 256)
+                self.wgrad(addr(dA), lda, addr(H[i]), ldu, P, 256, lay.Kp, addr(*lay.dWp), lay.ldd, addr(flat, lay.db_off))
+                if i > 0:
+                    if i == 5 and want_in:
+                        # columns 256..339 of the layer-5 input are the re-concatenated embedding: keep their plain gradient
+                        nxt = wb.keep(e(P, 352))
+                        self.nt(addr(dA), lda, addr(*lay.WpT), lay.ldT, P, 340, 256, addr(nxt), 352, EPI_MUL_DRELU,
+                                H=addr(H[i]), ldh=ldu, act_cols=256, zero_to=352, mask=getattr(H[i], '_nu_mask', None))
+                        dskip = nxt
+                        dA, lda = nxt, 352
+                    else:
+                        nxt = wb.keep(e(P, 256))
+                        self.nt(addr(dA), lda, addr(*lay.WpT), lay.ldT, P, 256, 256, addr(nxt), 256, EPI_MUL_DRELU,
+                                H=addr(H[i]), ldh=ldu, mask=getattr(H[i], '_nu_mask', None))
+                        dA, lda = nxt, 256
+                elif want_in:
+                    dE4 = wb.keep(e(P, 96))
+                    self.nt(addr(dA), lda, addr(*lay.WpT), lay.ldT, P, 84, 256, addr(dE4), 96, EPI_PLAIN, zero_to=96)
+                    L.check(lib.nu_nerf_embed_bwd(c_p(addr(pt)), pt.shape[1], c_p(addr(H[0])), c_p(addr(b['V'])), c_p(addr(dE4)), 96,
+                                                  c_p(addr(dskip, 256)), 352, c_p(addr(dF, 256)), ldf, P, c_p(addr(dx)),
+                                                  c_p(addr(ddir)), S), "nu_nerf_embed_bwd")
 
     # ------------------------------------------------------------------ sampler (no grad)
     def _sampler_consts(self, Nc, Nbg, n_new):

@@ -194,6 +194,87 @@ def test_relu_sign_bits_replace_the_activation_in_the_backward_epilogues(gpu):
     torch.testing.assert_close(out3.double(), want, rtol=2e-5, atol=2e-5)
 
 
+def _gemm_struct(A, lda, B, ldb, M, N, K, C, ldc, epi, *, bias=None, H=None, ldh=0, mask=None, nct=0, ct0=0, groups=1, sA=0, sB=0, sC=0,
+                 sBias=0, sH=0, zero_to=0, act_cols=0):
+    from nu_nerf_amd.engine import GemmNT, addr
+    return GemmNT(addr(A), lda, addr(B), ldb, M, N, K, addr(C), ldc, 0, 0, addr(bias), addr(H), ldh, 0, 0, 0, 0, zero_to, act_cols, 1.0, groups,
+                  sA, sB, sC, 0, sBias, sH, 0, 0, epi, 0, mask.data_ptr() if mask is not None else 0, nct, ct0)
+
+
+@pytest.mark.parametrize("rows", [(40000, 23001, 11111, 11111), (3000, 2049, 1, 700), (128, 0, 64, 5000)])
+def test_nt_batch_is_bit_identical_to_one_launch_per_problem(gpu, rows):
+    """nu_gemm_nt_batch: several problems (own M, K, pointers, sign-bit buffers) in ONE persistent launch -- the four light predictors
+    of a pass, a grouped launch expanded into its groups.  Every output bit, zero-filled pad column and sign-bit word must equal what
+    one launch per problem writes (a tile's arithmetic does not depend on the launch it belongs to), for both tile heights."""
+    from nu_nerf_amd import _lib as L
+    from nu_nerf_amd.engine import GemmNT
+    lib = L.load()
+    torch.manual_seed(sum(rows))
+    Ks = (96, 128, 256, 160)
+
+    def run(batched):
+        torch.manual_seed(11)
+        outs, keep, probs = [], [], []
+        # level 0: BIAS_RELU with sign bits, differing K; one of the problems is a 2-group launch (columns of one 512-wide matrix)
+        for i, (M, K) in enumerate(zip(rows, Ks)):
+            Mq = max(M, 1)
+            grouped = i == 2
+            N = 256
+            A = torch.randn(Mq, K * (2 if grouped else 1), device=gpu)
+            W = torch.randn(2 if grouped else 1, N, K, device=gpu) / K ** 0.5
+            bias = torch.randn(2 if grouped else 1, N, device=gpu) * 0.3
+            ncol = N * (2 if grouped else 1)
+            C = torch.full((Mq, ncol + 32), float("nan"), device=gpu)
+            nct = ncol // 128
+            mask = torch.zeros(((Mq + 127) // 128) * nct * 256, dtype=torch.int64, device=gpu)
+            if grouped:
+                g = _gemm_struct(A, 2 * K, W, K, M, N, K, C, ncol + 32, 1, bias=bias, mask=mask, nct=nct, groups=2, sA=K, sB=N * K, sC=N, sBias=N)
+            else:
+                g = _gemm_struct(A, K, W, K, M, N, K, C, ncol + 32, 1, bias=bias, mask=mask, nct=nct, zero_to=N + 32)
+            probs.append(g)
+            outs += [C, mask]
+            keep += [A, W, bias]
+        # backward level: MUL_DRELU reading those sign bits (H poisoned), plain columns past act_cols on one problem
+        back = []
+        for i, M in enumerate(rows):
+            Mq = max(M, 1)
+            grouped = i == 2
+            ncol = 256 * (2 if grouped else 1)
+            dA = torch.randn(Mq, ncol, device=gpu)
+            WT = torch.randn(2 if grouped else 1, 384, 256, device=gpu) / 16
+            N = 340 if i == 0 else 256
+            out = torch.full((Mq, 352 * (2 if grouped else 1)), float("nan"), device=gpu)
+            poison = torch.full((Mq, ncol), float("nan"), device=gpu)
+            mask = outs[2 * i + 1]
+            if grouped:
+                g = _gemm_struct(dA, ncol, WT, 256, M, N, 256, out, 704, 3, H=poison, ldh=ncol, mask=mask, nct=4, groups=2, sA=256, sB=384 * 256,
+                                 sC=352, sH=256)
+            else:
+                g = _gemm_struct(dA, ncol, WT, 256, M, N, 256, out, 352, 3, H=poison, ldh=ncol, mask=mask, nct=2, zero_to=352 if i == 0 else 0,
+                                 act_cols=256 if i == 0 else 0)
+            back.append(g)
+            outs.append(out)
+            keep += [dA, WT, poison]
+        for level in (probs, back):
+            if batched:
+                arr = (GemmNT * len(level))(*level)
+                L.check(lib.nu_gemm_nt_batch(arr, len(level), L.stream()), "nu_gemm_nt_batch")
+            else:
+                for g in level:
+                    L.check(lib.nu_gemm_nt_ex(ctypes.byref(g), L.stream()), "nu_gemm_nt_ex")
+        torch.cuda.synchronize()
+        return [o.clone() for o in outs]
+
+    one = run(False)
+    many = run(True)
+    assert any(torch.isfinite(o.float()).any() for o in one if o.dtype == torch.float32)
+    for a, b in zip(one, many):
+        if a.dtype == torch.float32:
+            assert torch.equal(torch.nan_to_num(a, nan=12345.0), torch.nan_to_num(b, nan=12345.0))
+        else:
+            assert torch.equal(a, b)
+
+
 def _bf(x):
     return x.bfloat16().float()
 
