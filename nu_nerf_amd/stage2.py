@@ -43,11 +43,9 @@ class IoRNetwork(nn.Module):
                                      WNLinear(256, 1), nn.Sigmoid())
 
     def forward(self, x):
-        h = G.embed(x, 6)
-        h = F.relu(G.wn_linear(h, self.module0[0]))
-        h = F.relu(G.wn_linear(h, self.module0[2]))
-        h = G.wn_linear(h, self.module0[4])          # no activation between the last two linears (field.py:1056-1057)
-        return torch.sigmoid(G.wn_linear(h, self.module0[5]))
+        # a parameter holder, like SDFNetwork: the networks run on the HIP GEMMs of the owning renderer's engine (nets.IorFn /
+        # IorPairFn via Stage2Renderer.nets()); there is no eager evaluation of them in the package
+        raise RuntimeError("IoRNetwork is a parameter holder: evaluate it through its Stage2Renderer (nets().ior / .thickness)")
 
 
 class AppShadingNetworkS2(nn.Module):

@@ -131,9 +131,3 @@ def lut_bilinear_clamp(lut, uv):
     top = lut[y0, x0] * (1 - tx) + lut[y0, x1] * tx
     bot = lut[y1, x0] * (1 - tx) + lut[y1, x1] * tx
     return top * (1 - ty) + bot * ty
-
-
-def wn_linear(x, lin):
-    """Weight-normed linear on a parameter holder with weight_g / weight_v / bias (tiny IoR network only)."""
-    w = lin.weight_v * (lin.weight_g / lin.weight_v.norm(dim=1, keepdim=True))
-    return F.linear(x, w, lin.bias)

@@ -17,7 +17,21 @@ sys.path.insert(0, REPO)
 from oracle.gen_golden import install_shims, to_t, OUT   # noqa: E402
 
 
-def main():
+# The two shipped zero-thickness stage-2 combinations: configs/stage2/nerf/*.yaml (is_nerf, plain directional code) and
+# configs/stage2/real/eikonal_wineglass.yaml:5-13 (pose-based rays, `sphere_direction: true` -- the 144-d outer_light input --,
+# eikonal_weight 0.1, freeze_inv_s_step 15000).  AppShadingNetwork_S2 feeds its 144-d code to the STAGE-1 network's outer_light
+# (field.py:904), so the reference only runs this combination on a stage-1 network that was built with `sphere_direction: true`
+# as well (with configs/shape/real/eikonal_wineglass.yaml:7, which says false, the reference itself raises "mat1 and mat2 shapes
+# cannot be multiplied (15x144 and 72x256)"): the 'real' variant therefore writes the stage-1 config with the flag set, as the
+# ballstatue / popcorncup / real_bottle config pairs do.
+VARIANTS = {
+    'nerf': dict(is_nerf=True, sphere_direction=False, eikonal_weight=0.02, freeze_inv_s_step=5000, out="stage2_step6000_r24.npz"),
+    'real': dict(is_nerf=False, sphere_direction=True, eikonal_weight=0.1, freeze_inv_s_step=15000, out="stage2_real_step6000_r24.npz"),
+}
+
+
+def main(variant='nerf'):
+    var = VARIANTS[variant]
     install_shims()
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -56,15 +70,17 @@ def main():
 
     rz.Scene = FakeScene
     tmp = tempfile.mkdtemp()
-    s1 = randomize_for_parity(init_stage1_params(6033), seed=1)
+    s1 = randomize_for_parity(init_stage1_params(6033, sphere_direction=var['sphere_direction']), seed=1)
     torch.save({'network_state_dict': to_t(s1)}, os.path.join(tmp, 's1.pth'))
     s1cfg = {'name': 's1', 'network': 'shape', 'database_name': 'nerf/spherepot', 'is_nerf': True, 'apply_occ_loss': True,
              'occ_loss_step': 15000, 'freeze_inv_s_step': 15000, 'zero_thickness': True}
+    if var['sphere_direction']:
+        s1cfg['shader_config'] = {'sphere_direction': True, 'human_light': False}
     with open(os.path.join(tmp, 's1.yaml'), 'w') as fh:
         yaml.safe_dump(s1cfg, fh)
-    cfg = {'name': 'golden_s2', 'network': 'stage2', 'database_name': 'nerf/spherepot', 'is_nerf': True,
-           'shader_config': {'sphere_direction': False, 'human_light': False}, 'apply_occ_loss': True, 'occ_loss_step': 20000,
-           'loss': ['eikonal', 'std', 'nerf_render'], 'eikonal_weight': 0.02, 'freeze_inv_s_step': 5000,
+    cfg = {'name': 'golden_s2', 'network': 'stage2', 'database_name': 'nerf/spherepot', 'is_nerf': var['is_nerf'],
+           'shader_config': {'sphere_direction': var['sphere_direction'], 'human_light': False}, 'apply_occ_loss': True, 'occ_loss_step': 20000,
+           'loss': ['eikonal', 'std', 'nerf_render'], 'eikonal_weight': var['eikonal_weight'], 'freeze_inv_s_step': var['freeze_inv_s_step'],
            'stage1_ckpt_dir': os.path.join(tmp, 's1.pth'), 'stage1_cfg_dir': os.path.join(tmp, 's1.yaml'),
            'stage1_mesh_dir': 'unused.ply'}
     net = rz.Stage2Renderer(cfg, training=False)
@@ -89,7 +105,7 @@ def main():
     print("segments", len(pathes), "converged per bounce", [int(c.sum()) for c in converges], "rays per segment",
           [int(p.shape[0]) for p in pathes], "samples", [int(p.shape[1]) for p in pathes])
     net.zero_grad()
-    outputs = net.render(o, dn, None, None, None, -1, net.get_anneal_val(step), is_train=True, step=step, is_nerf=True)
+    outputs = net.render(o, dn, None, None, None, -1, net.get_anneal_val(step), is_train=True, step=step, is_nerf=var['is_nerf'])
     outputs['loss_rgb'] = net.compute_rgb_loss(outputs['ray_rgb'] * outputs['tir_mask'].detach(), rgbs * outputs['tir_mask'].detach())
     log = {}
     for ls in losses:
@@ -123,14 +139,14 @@ def main():
     res['state_dict_keys'] = np.asarray(keys)
     # the validation render of the same rays (test_step's call, renderer_zerothick.py:1238-1240: perturb 0, cos_anneal 0, is_train=False)
     with torch.no_grad():
-        ev = net.render(o, dn, None, None, None, 0, 0, is_train=False, step=step, is_nerf=True)
+        ev = net.render(o, dn, None, None, None, 0, 0, is_train=False, step=step, is_nerf=var['is_nerf'])
     for k in ('ray_rgb', 'normal', 'specular_color', 'specular_light', 'specular_ref', 'tir_mask'):
         res['eval_' + k] = ev[k].detach().numpy()
-    np.savez_compressed(os.path.join(OUT, "stage2_step6000_r24.npz"), **res)
+    np.savez_compressed(os.path.join(OUT, var['out']), **res)
     print("stage2 loss", float(total), {k: float(v) for k, v in res.items() if k.startswith('term_')},
           "tir", outputs['tir_mask'].flatten().tolist()[:8], "n grads", len(gn))
     print("params without grad:", sorted(set(n.split('.')[0] for n, p in net.named_parameters() if p.grad is None)))
 
 
 if __name__ == "__main__":
-    main()
+    main(sys.argv[1] if len(sys.argv) > 1 else 'nerf')

@@ -194,7 +194,9 @@ def ray_trace(params, cfg, scene, rays_o, rays_d):
 
 
 def shading_s2(params, cfg, points, normals, view_dirs, feats, is_internal):
-    """AppShadingNetwork_S2.forward on [H,3] inputs (field.py:909-1010), sphere_direction False, stage-1 predictors."""
+    """AppShadingNetwork_S2.forward on [H,3] inputs (field.py:909-1010) with the stage-1 predictors; `sphere_direction`
+    (field.py:831-836, :900-904): the direction code is followed by the code of the point where the query direction leaves the unit
+    sphere -- at the roughness of the query also for the mirror query -- (the 144-d outer_light input)."""
     p = S1 + 'color_network'
     exp_max = cfg['light_exp_max']
     n = F.normalize(normals, dim=-1)
@@ -207,13 +209,21 @@ def shading_s2(params, cfg, points, normals, view_dirs, feats, is_internal):
     albedo = O.predictor(params, f'{p}.albedo_predictor', fx, 'sigmoid')
     trans = O.predictor(params, f'{p}.transmisstion_weight', fx, 'sigmoid')
     ones = torch.ones_like(rough)
-    diffuse_light = O.predictor(params, f'{p}.outer_light', O.ide(n, ones), 'exp', exp_max)
+
+    def outer(enc_dir, rough_for_sph, direction):
+        if cfg.get('sphere_direction', False):
+            sp = O.offset_points_to_sphere(points)
+            sp = F.normalize(sp + direction * O.sphere_exit_distance(sp, direction), dim=-1)
+            enc_dir = torch.cat([enc_dir, O.ide(sp, rough_for_sph)], -1)
+        return O.predictor(params, f'{p}.outer_light', enc_dir, 'exp', exp_max)
+
+    diffuse_light = outer(O.ide(n, ones), ones, n)
     diffuse_color = (1 - metallic) * albedo * diffuse_light
     spec_albedo = 0.04 * (1 - metallic) + metallic * albedo
     enc_r, enc_r0 = O.ide(refl, rough), O.ide(refl, torch.zeros_like(rough))
     pe = O.embed(points, 6)
-    direct = O.predictor(params, f'{p}.outer_light', enc_r, 'exp', exp_max)
-    direct0 = O.predictor(params, f'{p}.outer_light', enc_r0, 'exp', exp_max)
+    direct = outer(enc_r, rough, refl)
+    direct0 = outer(enc_r0, rough, refl)
     indirect = O.predictor(params, f'{p}.inner_light', torch.cat([pe, enc_r], -1), 'exp', exp_max)
     indirect0 = O.predictor(params, f'{p}.inner_light', torch.cat([pe, enc_r0], -1), 'exp', exp_max)
     occ = O.predictor(params, f'{p}.inner_weight', torch.cat([pe.detach(), O.embed(refl, 6).detach()], -1), 'none') * 0.5 + 0.5

@@ -63,6 +63,22 @@ def test_product_path_fails_loudly_without_gpu():
         m.render(o, o + 1, torch.full((4, 1), 0.8), torch.full((4, 1), 4.5), step=0)
 
 
+def test_network_holders_have_no_eager_evaluation():
+    """The module objects that mirror the reference's networks only hold parameters; their arithmetic runs on the HIP kernels of the
+    owning renderer's engine.  A holder called on its own raises instead of quietly computing with torch (no rocBLAS path exists in
+    the package): SDFNetwork (field.py:133-170) and the IoR / thickness networks of stage 2 (field.py:1046-1087)."""
+    from nu_nerf_amd.renderer import SDFNetwork
+    from nu_nerf_amd.stage2 import IoRNetwork
+    import inspect
+    from nu_nerf_amd import torch_glue
+    x = torch.zeros(5, 3)
+    with pytest.raises(RuntimeError, match="parameter holder"):
+        IoRNetwork()(x)
+    with pytest.raises(RuntimeError, match="parameter holder"):
+        SDFNetwork()(x)
+    assert 'F.linear' not in inspect.getsource(torch_glue) and not hasattr(torch_glue, 'wn_linear')
+
+
 def test_synthetic_rays():
     from nu_nerf_amd.synthetic import make_rays, make_cameras
     a, b = make_rays(256, seed=5), make_rays(256, seed=5)

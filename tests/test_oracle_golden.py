@@ -110,6 +110,41 @@ def test_train_step(name, perturb):
             assert rel_err(params[k[6:]].grad, g[k]) < tol, k
 
 
+@pytest.mark.parametrize("name,sampling", [("train_default_sampling_step20000_r24.npz", (64, 64, 32)),
+                                           ("train_config0_step0_r256.npz", (32, 32, 32))])
+def test_train_step_at_the_default_sampling_and_at_baseline_config0_size(name, sampling):
+    """Round 4 (oracle/gen_golden_r4.py): a reference step at the DEFAULT sampling of renderer_zerothick.py:110-117 (64 + 64 + 32;
+    every other reference step is 32 + 32 + 16) and one at BASELINE.json configs[0]'s stated size -- 256 rays, 32 + 32 + 32
+    samples, PyTorch CPU -- against the oracle: per-ray outputs, every loss term, the total and all gradient norms."""
+    g = golden(name)
+    assert tuple(int(v) for v in g['sampling']) == sampling
+    params = parity_params(requires_grad=True)
+    cfg = oracle_cfg(n_samples=sampling[0], n_importance=sampling[1], n_bg_samples=sampling[2])
+    step = int(g['step'])
+    total, terms, out = O.train_step(params, cfg, torch.from_numpy(g['rays_o']), torch.from_numpy(g['rays_d']),
+                                     torch.from_numpy(g['rgbs']), step, rand=(torch.from_numpy(g['u1']), torch.from_numpy(g['u2'])))
+    assert out['z_vals'].shape == g['z_vals'].shape == (g['rays_o'].shape[0], sum(sampling))
+    dz = np.abs(out['z_vals'].numpy() - g['z_vals']) / np.maximum(1.0, np.abs(g['z_vals']))
+    # inverse-CDF sensitivity, see test_train_step; the extreme of 24 576 samples is larger than that of 3 840 (2.2e-3 on one ray)
+    assert (dz < 1e-5).mean() >= 0.98 and dz.max() < 5e-3, ((dz < 1e-5).mean(), dz.max())
+    assert out['gradient_error'].numel() == int(g['n_inner'])                                   # same inner / outer partition
+    for k in ('ray_rgb', 'acc', 'color_bkgr', 'color_spec'):
+        np.testing.assert_allclose(out[k].detach().numpy(), g['out_' + k], rtol=1e-4, atol=1e-5, err_msg=k)
+    np.testing.assert_allclose(float(out['gradient_error'].mean()), float(g['out_gradient_error_mean']), rtol=1e-4)
+    for k in g:
+        if k.startswith('term_'):
+            np.testing.assert_allclose(float(torch.mean(terms[k[5:]]).detach()), float(g[k]), rtol=1e-4, atol=1e-7, err_msg=k)
+    np.testing.assert_allclose(float(total), float(g['total_loss']), rtol=1e-5)
+    total.backward()
+    names = [str(n) for n in g['grad_names']]
+    for n, ref_norm in zip(names, g['grad_norms']):
+        assert params[n].grad is not None, n
+        assert abs(float(params[n].grad.double().norm()) - ref_norm) <= 1e-3 * ref_norm + 1e-9, (n, float(params[n].grad.norm()), ref_norm)
+    for k in g:
+        if k.startswith('grad__'):
+            assert rel_err(params[k[6:]].grad, g[k]) < 2e-3, k
+
+
 def test_train_step_standard_renderer_sphere_direction():
     """Non-zero-thickness stage-1 renderer (network/renderer.py) with sphere_direction=True, refrac_freq=3, real-capture
     near/far: loss_normal, candidate-ray colour_spec, 144-d outer_light."""

@@ -162,6 +162,40 @@ def test_full_train_step_vs_reference_golden(gpu, name, mlp_dtype):
             assert rel_err(named[k[6:]].grad.cpu(), g[k]) < tol, k
 
 
+def test_full_train_step_at_the_default_sampling_vs_reference_golden(gpu):
+    """A step of the reference's own NeROShapeRenderer at its DEFAULT sampling (64 + 64 + 32, renderer_zerothick.py:110-117; fixture
+    of oracle/gen_golden_r4.py, step 20000: occlusion + outer-regulariser losses on, inv_s trainable) replayed on the HIP path:
+    per-ray outputs 1e-4, total loss 1e-5, every gradient norm 2e-3 -- the tolerances of the 32 + 32 + 16 reference steps."""
+    from nu_nerf_amd.loss import name2loss, SPHEREPOT_LOSSES, total_loss
+    g = golden("train_default_sampling_step20000_r24.npz")
+    assert tuple(int(v) for v in g['sampling']) == (64, 64, 32)
+    cfg = dict(CFG, n_samples=64, n_importance=64, n_bg_samples=32)
+    step = int(g['step'])
+    net = make_net(gpu, cfg)
+    batch = {k: torch.from_numpy(g[k]).to(gpu) for k in ('rays_o', 'rays_d', 'rgbs')}
+    rand = (torch.from_numpy(g['u1']).to(gpu), torch.from_numpy(g['u2']).to(gpu))
+    out = net.train_step_rays(batch, step, rand=rand)
+    total, log = total_loss(out, [name2loss[n](cfg) for n in SPHEREPOT_LOSSES], step)
+    total.backward()
+    assert out['gradient_error'].numel() == int(g['n_inner'])             # same inner / outer partition
+    np.testing.assert_allclose(out['ray_rgb'].detach().cpu().numpy(), g['out_ray_rgb'], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(out['acc'].detach().cpu().numpy(), g['out_acc'], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(out['color_bkgr'].detach().cpu().numpy(), g['out_color_bkgr'], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(out['color_spec'].detach().cpu().numpy(), g['out_color_spec'], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(float(out['gradient_error'].mean()), float(g['out_gradient_error_mean']), rtol=2e-4)
+    for k in g:
+        if k.startswith('term_'):
+            np.testing.assert_allclose(float(torch.mean(log[k[5:]]).detach()), float(g[k]), rtol=2e-4, atol=1e-7, err_msg=k)
+    np.testing.assert_allclose(float(total.detach()), float(g['total_loss']), rtol=1e-5)
+    named = dict(net.named_parameters())
+    for n, ref_norm in zip([str(s) for s in g['grad_names']], g['grad_norms']):
+        assert named[n].grad is not None, n
+        assert abs(float(named[n].grad.double().norm()) - ref_norm) <= 2e-3 * ref_norm + 1e-9, (n, float(named[n].grad.norm()), ref_norm)
+    for k in g:
+        if k.startswith('grad__'):
+            assert rel_err(named[k[6:]].grad.cpu(), g[k]) < 3e-3, k
+
+
 def test_full_step_vs_oracle_default_sampling_and_init_weights(gpu):
     """Default 64+64+32 sampling, untouched geometric init (zero embedding columns, unit weight_g), step 200:
     exercises the init-SDF regulariser incl. the shell SDF op."""

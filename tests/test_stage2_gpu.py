@@ -10,18 +10,33 @@ from helpers import golden, rel_err, exact_fp32_only
 pytestmark = pytest.mark.gpu
 
 
-def build(gpu):
+# the two reference-generated fixtures (oracle/gen_golden_stage2.py VARIANTS): the synthetic configs (configs/stage2/nerf/*.yaml) and
+# the real-capture combination of configs/stage2/real/eikonal_wineglass.yaml:5-13 -- pose-based rays (is_nerf false), the 144-d
+# `sphere_direction` code, eikonal_weight 0.1, freeze_inv_s_step 15000 -- on a stage-1 network built with the same flag (the only
+# way the reference itself runs it: AppShadingNetwork_S2 feeds the code to the stage-1 outer_light, field.py:904)
+VARIANTS = {
+    'nerf': dict(is_nerf=True, sphere_direction=False, eikonal_weight=0.02, freeze_inv_s_step=5000, fixture="stage2_step6000_r24.npz"),
+    'real': dict(is_nerf=False, sphere_direction=True, eikonal_weight=0.1, freeze_inv_s_step=15000, fixture="stage2_real_step6000_r24.npz"),
+}
+
+
+def build(gpu, variant='nerf'):
     from nu_nerf_amd.stage2 import Stage2Renderer
     from nu_nerf_amd.params import init_stage1_params, init_stage2_params, randomize_for_parity
     from nu_nerf_amd.lbvh import icosphere
-    s1 = randomize_for_parity(init_stage1_params(6033), seed=1)
-    p2 = randomize_for_parity(init_stage2_params(6033, 7044, {'sphere_direction': False}), seed=3)
+    var = VARIANTS[variant]
+    sd = var['sphere_direction']
+    s1 = randomize_for_parity(init_stage1_params(6033, sphere_direction=sd), seed=1)
+    p2 = randomize_for_parity(init_stage2_params(6033, 7044, {'sphere_direction': sd}), seed=3)
     for k, v in s1.items():
         p2['stage1_network.' + k] = v
         p2['color_network.stage1_network.' + k] = v
-    cfg = {'name': 's2', 'network': 'stage2', 'is_nerf': True, 'shader_config': {'sphere_direction': False, 'human_light': False},
-           'eikonal_weight': 0.02, 'freeze_inv_s_step': 5000,
-           'stage1_cfg': {'is_nerf': True, 'apply_occ_loss': True, 'occ_loss_step': 15000, 'freeze_inv_s_step': 15000},
+    s1cfg = {'is_nerf': True, 'apply_occ_loss': True, 'occ_loss_step': 15000, 'freeze_inv_s_step': 15000}
+    if sd:
+        s1cfg['shader_config'] = {'sphere_direction': True, 'human_light': False}
+    cfg = {'name': 's2', 'network': 'stage2', 'is_nerf': var['is_nerf'], 'shader_config': {'sphere_direction': sd, 'human_light': False},
+           'eikonal_weight': var['eikonal_weight'], 'freeze_inv_s_step': var['freeze_inv_s_step'],
+           'stage1_cfg': s1cfg,
            'stage1_mesh_arrays': icosphere(3, 0.5)}
     net = Stage2Renderer(cfg, training=False)
     assert list(net.state_dict().keys()) == list(p2.keys())
@@ -29,10 +44,11 @@ def build(gpu):
     return net.to(gpu), cfg
 
 
-def test_stage2_train_step_vs_reference_golden(gpu):
+@pytest.mark.parametrize("variant", ["nerf", "real"])
+def test_stage2_train_step_vs_reference_golden(gpu, variant):
     from nu_nerf_amd.loss import name2loss, total_loss
-    g = golden("stage2_step6000_r24.npz")
-    net, cfg = build(gpu)
+    g = golden(VARIANTS[variant]['fixture'])
+    net, cfg = build(gpu, variant)
     assert [str(k) for k in g['state_dict_keys']] == list(net.state_dict().keys())
     step = int(g['step'])
     batch = {k: torch.from_numpy(g[k]).to(gpu) for k in ('rays_o', 'rays_d', 'rgbs')}
@@ -63,7 +79,8 @@ def test_stage2_train_step_vs_reference_golden(gpu):
             assert rel_err(named[k[6:]].grad.cpu(), g[k]) < 2e-2, k
 
 
-def test_stage2_train_step_at_the_reference_sample_placement(gpu, monkeypatch):
+@pytest.mark.parametrize("variant", ["nerf", "real"])
+def test_stage2_train_step_at_the_reference_sample_placement(gpu, monkeypatch, variant):
     """Second pass of the golden step with the sample placement of the REFERENCE run: the inner segment's 128 fractions are
     recovered from the fixture's `path1`, the far-ray importance nodes of the rays that leave the scene from `path0` / `path2`
     (both placements are no-gradient inverse-CDF draws, which amplify last-bit differences of the densities they are drawn from:
@@ -72,8 +89,8 @@ def test_stage2_train_step_at_the_reference_sample_placement(gpu, monkeypatch):
     import torch.nn.functional as F
     from nu_nerf_amd.loss import name2loss, total_loss
     from nu_nerf_amd import stage2_ops
-    g = golden("stage2_step6000_r24.npz")
-    net, cfg = build(gpu)
+    g = golden(VARIANTS[variant]['fixture'])
+    net, cfg = build(gpu, variant)
     step = int(g['step'])
     batch = {k: torch.from_numpy(g[k]).to(gpu) for k in ('rays_o', 'rays_d', 'rgbs')}
     P = [torch.from_numpy(g['path%d' % i]).to(gpu) for i in range(3)]
@@ -127,12 +144,13 @@ def test_stage2_train_step_at_the_reference_sample_placement(gpu, monkeypatch):
             assert rel_err(named[k[6:]].grad.cpu(), g[k]) < 5e-3, (k, rel_err(named[k[6:]].grad.cpu(), g[k]))
 
 
-def test_stage2_validation_render_vs_reference_golden(gpu):
+@pytest.mark.parametrize("variant", ["nerf", "real"])
+def test_stage2_validation_render_vs_reference_golden(gpu, variant):
     """render(..., is_train=False) -- test_step's per-chunk call (renderer_zerothick.py:1238-1240) -- against the reference's
     outputs on the fixture's rays: RGB, TIR mask and the validation images of the first surface; then the trainer protocol
     (forward({'step'}) / forward({'index','eval','step'})) on the module's own ray store."""
-    g = golden("stage2_step6000_r24.npz")
-    net, cfg = build(gpu)
+    g = golden(VARIANTS[variant]['fixture'])
+    net, cfg = build(gpu, variant)
     batch = {k: torch.from_numpy(g[k]).to(gpu) for k in ('rays_o', 'rays_d', 'rgbs')}
     with torch.no_grad():
         whole = net.render_eval(batch, int(g['step']))

@@ -9,10 +9,10 @@ from oracle import stage1_oracle as O
 from oracle import stage2_oracle as O2
 
 
-def stage2_params(requires_grad=True):
+def stage2_params(requires_grad=True, sphere_direction=False):
     from nu_nerf_amd.params import init_stage1_params, init_stage2_params, randomize_for_parity
-    s1 = randomize_for_parity(init_stage1_params(6033), seed=1)
-    p2 = randomize_for_parity(init_stage2_params(6033, 7044, {'sphere_direction': False}), seed=3)
+    s1 = randomize_for_parity(init_stage1_params(6033, sphere_direction=sphere_direction), seed=1)
+    p2 = randomize_for_parity(init_stage2_params(6033, 7044, {'sphere_direction': sphere_direction}), seed=3)
     out = {}
     for k, v in p2.items():
         if k.startswith('color_network.stage1_network.'):
@@ -27,6 +27,10 @@ def stage2_params(requires_grad=True):
 
 
 STAGE2_CFG = dict(O.DEFAULT_CFG, eikonal_weight=0.02, freeze_inv_s_step=5000, sphere_direction=False, refrac_freq=6)
+# the two reference-generated fixtures (oracle/gen_golden_stage2.py VARIANTS): configs/stage2/nerf/*.yaml and the real-capture
+# combination of configs/stage2/real/eikonal_wineglass.yaml:5-13 (`sphere_direction: true`, eikonal_weight 0.1, freeze_inv_s_step 15000)
+VARIANTS = {'nerf': ("stage2_step6000_r24.npz", STAGE2_CFG),
+            'real': ("stage2_real_step6000_r24.npz", dict(STAGE2_CFG, eikonal_weight=0.1, freeze_inv_s_step=15000, sphere_direction=True))}
 
 
 def test_stage2_state_dict_inventory():
@@ -35,10 +39,12 @@ def test_stage2_state_dict_inventory():
     assert [str(k) for k in g['state_dict_keys']] == list(init_stage2_params().keys())
 
 
-def test_stage2_train_step_vs_reference():
+@pytest.mark.parametrize("variant", ["nerf", "real"])
+def test_stage2_train_step_vs_reference(variant):
     from nu_nerf_amd.lbvh import icosphere
-    g = golden("stage2_step6000_r24.npz")
-    params = stage2_params()
+    fixture, STAGE2_CFG = VARIANTS[variant]
+    g = golden(fixture)
+    params = stage2_params(sphere_direction=STAGE2_CFG['sphere_direction'])
     V, Fc = icosphere(3, 0.5)
     scene = O2.BruteScene(V, Fc)
     step = int(g['step'])
