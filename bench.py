@@ -352,13 +352,14 @@ def stage1_leg(args, dist_ctx):
             g['lr'] = lr
         opt.zero_grad(set_to_none=True)
         if not args.unfused_loss:
-            # loss assembly on the HIP loss kernels; with a reducer the eikonal mean takes this rank's point weight (count ratio
-            # n_local * world / sum n, a device scalar) INSIDE those kernels: the N > 1 step is the N = 1 step + one all-reduce
+            # loss assembly on the HIP loss kernels; with a reducer the subset means take this rank's count ratios (n_local * world /
+            # sum n, device scalars; the eikonal one INSIDE those kernels): the N > 1 step is the N = 1 step + two all-reduces
             total, _, _ = fused_stage1_loss(net, batch_for(it), step, losses, reducer=reducer)
         else:
             out = net.train_step_rays(batch_for(it), step)
-            if reducer is not None:     # eikonal mean over the union of all ranks' inner points (exact data parallelism)
-                out['gradient_error'] = out['gradient_error'] * reducer.point_weight(eng.last_ctx['P_in_dev'], dev)
+            if reducer is not None:     # subset means over the union of all ranks' subsets (parallel.dp_weight_outputs)
+                from nu_nerf_amd.parallel import dp_weight_outputs
+                dp_weight_outputs(out, reducer, net)
             total, _ = total_loss(out, losses, step)
         total.backward()
         if reducer is not None:

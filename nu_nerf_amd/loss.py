@@ -265,23 +265,26 @@ def fused_stage1_loss(renderer, batch, step, losses, rand=None, reducer=None):
     InitSDFRegLoss and MaskLoss entries keep their (O(1)-sized) torch form and are added on.  Returns (total, log, outputs)
     with the same log keys and values as `total_loss` gives on the unfused outputs.
 
-    reducer (parallel.GradAllReducer, world > 1): the eikonal mean becomes this rank's share of the mean over the union of all
-    ranks' inner points (`reducer.point_weight`, a device scalar handed to the loss kernels), so the data-parallel step runs
-    the SAME fused assembly as the single-GPU step and its all-reduced gradient equals the single-process one."""
+    reducer (parallel.GradAllReducer, world > 1): every mean over a data-dependent subset -- eikonal, transmission / metallic
+    regularisers, occlusion loss, the real-capture outer regulariser's candidate rays -- becomes this rank's share of the mean over
+    the union of all ranks' subsets (`parallel.dp_weight_outputs`; the eikonal weight goes to the loss kernels as a device scalar),
+    so the data-parallel step runs the SAME fused assembly as the single-GPU step and its all-reduced gradient equals the
+    single-process one up to the two approximations stated at dp_weight_outputs (the 2048-point occlusion cap, the init-SDF
+    normalisers of the first 1000 steps)."""
+    from .parallel import dp_weight_outputs
     pw = None
-    if reducer is not None and reducer.world > 1:
-        pw_of = lambda: reducer.point_weight(renderer.engine().last_ctx['P_in_dev'], batch['rays_o'].device)
-    else:
-        pw_of = None
-    if renderer.cfg['rgb_loss'] != 'charbonier' or not any(isinstance(ls, NeRFRenderLoss) for ls in losses):
+    dp = reducer is not None and reducer.world > 1
+    real_cand = getattr(renderer, 'candidate_rays', False)
+    if renderer.cfg['rgb_loss'] != 'charbonier' or not any(isinstance(ls, NeRFRenderLoss) for ls in losses) or (dp and real_cand):
+        # (the candidate-ray regulariser of the real-capture renderer takes its weight on the eager outputs)
         out = renderer.train_step_rays(batch, step, rand=rand)
-        if pw_of is not None:
-            out['gradient_error'] = out['gradient_error'] * pw_of()
+        if dp:
+            dp_weight_outputs(out, reducer, renderer)
         total, log = total_loss(out, losses, step)
         return total, log, out
     out = renderer.train_step_rays(batch, step, rand=rand, fused=True)
-    if pw_of is not None:
-        pw = pw_of()
+    if dp:
+        pw = dp_weight_outputs(out, reducer, renderer, fused_eikonal=True)['inner']
     raw = out.pop('_raw')
     w_eik = w_reg = w_nrm = 0.0
     rest = []

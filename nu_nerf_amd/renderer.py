@@ -260,6 +260,8 @@ class NeROShapeRenderer(nn.Module):
         'fixed_camera': False,
     }
 
+    candidate_rays = False      # the outer regulariser takes every ray (renderer_zerothick.py:780-781); renderer_std: candidate rays
+
     def __init__(self, cfg, training=True):
         super().__init__()
         self.cfg = {**self.default_cfg, **cfg}
@@ -515,6 +517,7 @@ class NeROShapeRenderer(nn.Module):
                 'color_bkgr': rgb_bg if cand is None else rgb_bg[cand],
                 'color_spec': color_spec if cand is None else color_spec[cand],
             }
+        self._last_cand = cand                      # candidate-ray mask of the real-capture outer regulariser (None: every ray takes part)
         self._extra_outputs(outputs, nrm_sum)
         var = self.deviation_network.variance
         inv_s = torch.exp(var * 10.0).clip(1e-6, 1e6)
@@ -571,6 +574,7 @@ class NeROShapeRenderer(nn.Module):
         probability of the reflected ray traced through the SDF (no grad)."""
         cfg = self.cfg
         dev = occ_raw.device
+        self._n_occ = 0
         if step < cfg['occ_loss_step']:
             return torch.zeros(1, device=dev)
         P_in = c['P_in']
@@ -581,6 +585,7 @@ class NeROShapeRenderer(nn.Module):
             sdf, n = a['YX'][:, 0], a['n']
             mask = (torch.norm(x, dim=-1) < 0.999) & (torch.sum(n * dirs, -1) < 0) & (torch.abs(sdf) < cfg['occ_sdf_thresh'])
             idx = torch.nonzero(mask)[:, 0]
+            self._n_occ = min(int(idx.numel()), int(cfg['occ_loss_max_pn']))   # points in the mean below (data parallelism: parallel.dp_weight_outputs)
             if idx.numel() > cfg['occ_loss_max_pn']:
                 if perm is None:
                     perm = torch.randperm(idx.numel(), device=dev)

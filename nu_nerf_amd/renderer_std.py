@@ -17,6 +17,7 @@ from .renderer import NeROShapeRenderer as _ZeroThickRenderer
 
 class NeROShapeRenderer(_ZeroThickRenderer):
     default_cfg = {**_ZeroThickRenderer.default_cfg, 'train_ray_num': 1024, 'downsample_ratio': 1.0, 'get_mask': False}
+    candidate_rays = True       # colour_spec / colour_bkgr on candidate rays only (renderer.py:710-725): a data-dependent subset
 
     def _spec_query_points(self, rays_o, rays_d, z_vals):
         S = z_vals.shape[1]

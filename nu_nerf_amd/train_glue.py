@@ -191,11 +191,12 @@ def train_step(network, optimizer, lr_manager, losses, step, batch=None, reducer
         optimizer.step()
         return total.detach(), log_info, lr
     outputs = network({'step': step}) if batch is None else network.train_step_rays(batch, step)
-    if reducer is not None and reducer.world > 1:
-        # per-point means (eikonal) become this rank's share of the mean over the union of all ranks' inner points, so the
-        # all-reduced gradient equals the single-process gradient on the global batch (parallel.GradAllReducer.point_weight)
-        eng = network.engine()
-        outputs['gradient_error'] = outputs['gradient_error'] * reducer.point_weight(eng.last_ctx['P_in_dev'], outputs['gradient_error'].device)
+    if reducer is not None and reducer.world > 1 and type(network).__name__ == 'NeROShapeRenderer':
+        # means over data-dependent subsets (eikonal, material regularisers, occlusion loss, candidate rays) become this rank's share
+        # of the mean over the union of all ranks' subsets: the all-reduced gradient is the single-process gradient on the global
+        # batch (parallel.dp_weight_outputs, which also states the two approximations that remain)
+        from .parallel import dp_weight_outputs
+        dp_weight_outputs(outputs, reducer, network)
     log_info = {}
     for loss in losses:
         log_info.update(loss(outputs, {'step': step}, step))

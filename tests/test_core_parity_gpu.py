@@ -325,6 +325,92 @@ def test_fused_loss_with_the_data_parallel_point_weight(gpu):
             assert rel_err(q.grad, p.grad) < 1e-5, (n, rel_err(q.grad, p.grad))
 
 
+class _TwoShardReducer:
+    """Stands in for parallel.GradAllReducer with world = 2 inside ONE process (no torch.distributed, no child process): the counts a
+    real all-reduce would sum are known because both shards are rendered here; phase 1 records each shard's counts, phase 2 hands out
+    n_local * world / sum n."""
+    world = 2
+
+    def __init__(self):
+        self.rec, self.totals, self.shard = {}, None, 0
+
+    def count_weights(self, counts, device):
+        n = torch.stack([c.reshape(-1)[0].to(device=device, dtype=torch.float32) if torch.is_tensor(c) else torch.tensor(float(c), device=device)
+                         for c in counts])
+        if self.totals is None:
+            self.rec[self.shard] = n
+            return torch.ones_like(n)
+        return torch.where(self.totals > 0, n * 2 / torch.clamp(self.totals, min=1.0), torch.ones_like(n))
+
+
+@exact_fp32_only
+@pytest.mark.parametrize("fused", [True, False])
+def test_two_ray_shards_average_to_the_union_batch_gradient(gpu, fused):
+    """SURVEY 8(e) on the real kernels: a 2 x 48-ray batch rendered as two disjoint shards one after the other, each loss assembled
+    with the count ratios of parallel.dp_weight_outputs (inner points -> eikonal, transmission / metallic regularisers; the
+    occlusion-loss points), the two gradient sets averaged -- what the all-reduce does -- against the gradient of the 96-ray union
+    batch rendered at once.  Step 20000: occlusion + outer-regulariser losses on, inv_s trainable.  Per-ray terms average exactly
+    (equal ray counts); the subset means are exact through the weights; what is left is summation order: every gradient within 2e-5
+    of its norm.  Under sharding the 2048-point occlusion cap applies per shard (here 96 rays stay far below it, so the test is
+    exact; with the cap active N shards use up to N x 2048 points -- stated in parallel.dp_weight_outputs and DESIGN section 7), and
+    the init-SDF normalisers (first 1000 steps only) are per-shard ratios -- not exercised at this step."""
+    from nu_nerf_amd.loss import name2loss, SPHEREPOT_LOSSES, total_loss, fused_stage1_loss
+    from nu_nerf_amd.parallel import dp_weight_outputs
+    g = golden("train_step20000_r48.npz")
+    h = golden("train_step0_r48.npz")
+    step = 20000
+    cat = lambda k: torch.from_numpy(np.concatenate([g[k], h[k]], 0)).to(gpu)
+    batch = {k: cat(k) for k in ('rays_o', 'rays_d', 'rgbs')}
+    u1, u2 = cat('u1'), cat('u2')
+    loss_names = SPHEREPOT_LOSSES + ['transmission_reg', 'metallic_reg']
+    losses = [name2loss[n](CFG) for n in loss_names]
+
+    def run(sl, reducer):
+        net = make_net(gpu)
+        b = {k: v[sl].contiguous() for k, v in batch.items()}
+        rand = (u1[sl].contiguous(), u2[sl].contiguous())
+        if fused:
+            total, _, _ = fused_stage1_loss(net, b, step, losses, rand=rand, reducer=reducer)
+        else:
+            out = net.train_step_rays(b, step, rand=rand)
+            if reducer is not None:
+                dp_weight_outputs(out, reducer, net)
+            total, _ = total_loss(out, losses, step)
+        total.backward()
+        torch.cuda.synchronize()
+        return float(total.detach()), {n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None}, net
+
+    whole_loss, whole, net_w = run(slice(0, 96), None)
+    assert 0 < net_w._n_occ < 2048 and net_w.engine().last_ctx['P_in'] > 0
+    red = _TwoShardReducer()
+    shards = (slice(0, 48), slice(48, 96))
+    for i, sl in enumerate(shards):                     # phase 1: the counts each rank would contribute
+        red.shard = i
+        run(sl, red)
+    red.totals = red.rec[0] + red.rec[1]
+    assert float(red.rec[0][0]) != float(red.rec[1][0])                  # the shards really differ in their inner-point counts
+    assert abs(float(red.totals[0]) - net_w.engine().last_ctx['P_in']) < 0.5 and abs(float(red.totals[1]) - net_w._n_occ) < 0.5
+    parts = []
+    for i, sl in enumerate(shards):                     # phase 2: the weighted shard steps
+        red.shard = i
+        parts.append(run(sl, red))
+    avg_loss = 0.5 * (parts[0][0] + parts[1][0])
+    assert abs(avg_loss - whole_loss) <= 2e-6 * abs(whole_loss), (avg_loss, whole_loss)
+    assert set(parts[0][1]) == set(parts[1][1]) == set(whole)
+    worst = 0.0
+    for n, ref in whole.items():
+        got = 0.5 * (parts[0][1][n] + parts[1][1][n])
+        err = float((got - ref).double().norm() / (ref.double().norm() + 1e-30))
+        worst = max(worst, err)
+        assert err <= 2e-5, (n, err)
+    # and the weights matter: without them the eikonal / occlusion shares are wrong by the count ratio
+    red_off = None
+    plain = [run(sl, red_off)[1] for sl in shards]
+    n0 = 'sdf_network.lin4.weight_v'
+    off = float((0.5 * (plain[0][n0] + plain[1][n0]) - whole[n0]).double().norm() / whole[n0].double().norm())
+    assert off > 10 * max(worst, 1e-7), (off, worst)
+
+
 @exact_fp32_only
 @pytest.mark.parametrize("py_seq", [False, True])
 def test_full_arena_flushes_in_one_stream_mode_and_fails_closed_when_forked(gpu, monkeypatch, py_seq):

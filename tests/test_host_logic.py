@@ -182,6 +182,36 @@ def _dp_worker(rank, world, port, q):
     dist.all_reduce(share)
     ok &= abs(float(share) / world - float(torch.arange(40.).mean())) < 1e-4
     ok &= all(p.grad is None for n, p in m.named_parameters() if n.startswith(('color_network.iors', 'infinity_far_bkgr')))
+    # several subset sizes in ONE all-reduce (inner points, occlusion-loss points, candidate rays); a subset that is empty on every
+    # rank gets weight 1, one that is empty on this rank only gets 0
+    cw = red.count_weights([10 if rank == 0 else 30, torch.tensor([4 if rank == 0 else 0]), 0], torch.device('cpu'))
+    ok &= bool(torch.allclose(cw, torch.tensor([0.5, 2.0, 1.0]) if rank == 0 else torch.tensor([1.5, 0.0, 1.0])))
+    # gathered path with a gradient that exists on ONE rank only (stage 2: a rank whose rays all miss the object trains no inner
+    # network that step): the union over ranks decides, the other rank contributes zeros, both end with the same averaged gradient
+    for p in red.params:
+        p.grad = None
+    a, b = named[names[0]], named[names[1]]
+    a.grad = torch.full_like(a, float(rank + 1))
+    if rank == 0:
+        b.grad = torch.full_like(b, 4.0)
+    before = red.gathered_calls
+    red.all_reduce()
+    ok &= red.gathered_calls == before + 1 and bool(torch.all(a.grad == 1.5)) and b.grad is not None and bool(torch.all(b.grad == 2.0))
+    ok &= all(p.grad is None for p in red.params[2:])
+    # the stage-2 module: the same reducer class; dead parameters at any nesting depth stay out of the bucket, aliases count once
+    from nu_nerf_amd.stage2 import Stage2Renderer
+    from nu_nerf_amd.lbvh import icosphere
+    from nu_nerf_amd.parallel import stage1_trainable_names
+    s2 = Stage2Renderer({'name': 's2', 'network': 'stage2', 'is_nerf': True, 'shader_config': {'sphere_direction': False, 'human_light': False},
+                         'stage1_cfg': {'is_nerf': True}, 'stage1_mesh_arrays': icosphere(1, 0.5)}, training=False)
+    n2 = stage1_trainable_names(s2)
+    ok &= len(n2) == len(set(n2)) and not any('iors.' in n or 'infinity_far_bkgr.' in n for n in n2)
+    ok &= any(n.startswith('IORs_pred.') for n in n2) and any(n.startswith('stage1_network.sdf_network.') for n in n2)
+    red2 = GradAllReducer(s2, world)
+    p0 = red2.params[0]
+    p0.grad = torch.full_like(p0, float(rank))
+    red2.all_reduce()
+    ok &= bool(torch.all(p0.grad == 0.5))
     batch = {'rays_o': torch.arange(10.)[:, None].repeat(1, 3), 'rgbs': torch.arange(10.)[:, None].repeat(1, 3)}
     sh = shard_rays(batch, rank, world)
     ok &= sh['rays_o'].shape[0] == 5 and float(sh['rays_o'][0, 0]) == 5.0 * rank
