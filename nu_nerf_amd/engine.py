@@ -640,6 +640,34 @@ class Stage1Engine:
             abytes = 4.0 * groups * (M * (ktrue or K) + M * (ntrue or N) * nmat + N * (ktrue or K))
             kt['nt'].append((e0, e1, 2.0 * M * (ntrue or N) * (ktrue or K) * groups, abytes))
 
+    def nt_desc(self, A, lda, B, ldb, M, N, K, C, ldc, epi, *, C2=0, ldc2=0, bias=0, H=0, ldh=0, D=0, ldd=0, Cadd=0, ldadd=0, zero_to=0,
+                act_cols=0, alpha=1.0, groups=1, sA=0, sB=0, sC=0, sC2=0, sBias=0, sH=0, sD=0, sCadd=0, mask=None):
+        """One problem of an `nt_batch` launch (the arguments of `nt`)."""
+        return GemmNT(A, lda, B, ldb, M, N, K, C, ldc, C2, ldc2, bias, H, ldh, D, ldd, Cadd, ldadd, zero_to, act_cols,
+                      alpha, groups, sA, sB, sC, sC2, sBias, sH, sD, sCadd, epi, self.bf16,
+                      mask.data_ptr() if mask is not None else 0, mask._nu_nct if mask is not None else 0, 0)
+
+    def nt_batch(self, descs):
+        """Several independent NT problems in as few persistent launches as possible (nu_gemm_nt_batch: runs of one epilogue kind
+        share ONE tile list) -- level j of the light predictors of a stage-2 shading call.  Bit-identical to one `nt` per problem."""
+        descs = [g for g in descs if g.M > 0]
+        if not descs:
+            return
+        arr = (GemmNT * len(descs))(*descs)
+        kt = self._ktime if self.ktime_on else None
+        if kt is not None:
+            e0, e1 = self._event_pair()
+            e0.record()
+        L.check(self.lib.nu_gemm_nt_batch(arr, len(descs), self.stream()), "nu_gemm_nt_batch")
+        if kt is not None:
+            e1.record()
+            fl = by = 0.0
+            for g in descs:
+                nmat = 1 + (1 if g.C2 else 0) + (1 if (g.H and not (g.mask and g.epi in (EPI_MUL_DRELU, EPI_B_RELU))) else 0) + (1 if g.D else 0) + (1 if g.Cadd else 0)
+                fl += 2.0 * g.M * g.N * g.K * g.groups
+                by += 4.0 * g.groups * (g.M * g.K + g.M * g.N * nmat + g.N * g.K)
+            kt['nt'].append((e0, e1, fl, by))
+
     def begin_kernel_timing(self, reserve=0, py_reserve=None):
         """Bracket every GEMM launch with HIP events on the launch stream (bench.py's roofline leg).  The network-level C
         entries record the events themselves (NuOpCtx.ev); the Python-sequenced path records them here.  The event pairs cost

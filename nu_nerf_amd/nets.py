@@ -182,6 +182,82 @@ class StackFn(torch.autograd.Function):
         return None, None, dX[:, :ctx.K], None, _token_grad(eng, flat, ctx.names)
 
 
+class StacksFn(torch.autograd.Function):
+    """SEVERAL make_predictor stacks of one shading call as one op: the stacks are independent of each other, so level j of all of
+    them is one launch (engine.nt_batch: one persistent tile list) and their weight gradients one queue (engine.wgrad_batch) -- at
+    the 10^2-10^4 rows of a stage-2 shading call every one of these launches fills a fraction of the chip.  Same kernels and the
+    same per-row arithmetic as one StackFn per stack; one zero-filled flat gradient buffer and one unpack for the lot (the stacks'
+    layers are consecutive in the engine's layer table)."""
+
+    @staticmethod
+    def forward(ctx, eng, stacks, layers_union, names, token, *Xs):
+        from .engine import EPI_BIAS_RELU
+        Xps, Hss = [], []
+        for layers, X in zip(stacks, Xs):
+            rows, K = X.shape
+            Kp = layers[0].Kp
+            if K == Kp:
+                Xp = X.detach().contiguous()
+            else:
+                Xp = eng.zeros(rows, Kp)
+                Xp[:, :K] = X.detach()
+            Xps.append(Xp)
+            Hss.append([eng.empty(rows, 256) for _ in range(3)])
+        for j in range(3):
+            eng.nt_batch([eng.nt_desc(addr(Xp if j == 0 else Hs[j - 1]), layers[j].Kp if j == 0 else 256, addr(*layers[j].Wp), layers[j].Kp,
+                                      Xp.shape[0], 256, layers[j].Kp, addr(Hs[j]), 256, EPI_BIAS_RELU, bias=addr(layers[j].b),
+                                      mask=eng.relu_mask(Hs[j], Xp.shape[0], 256))
+                          for layers, Xp, Hs in zip(stacks, Xps, Hss)])
+        outs = []
+        for layers, Xp, Hs in zip(stacks, Xps, Hss):
+            head = layers[3]
+            out = eng.empty(Xp.shape[0], 4)
+            eng.skinny_fwd(addr(Hs[2]), 256, Xp.shape[0], 256, addr(*head.Wp), 256, addr(head.b), head.N, addr(out), 4)
+            outs.append(out[:, :head.N].clone())
+        ctx.eng, ctx.stacks, ctx.Xps, ctx.Hss, ctx.names, ctx.Ks = eng, stacks, Xps, Hss, names, [X.shape[1] for X in Xs]
+        ctx.layers_union = layers_union
+        return tuple(outs)       # (an output nobody differentiates arrives as zeros in backward: every stack's packed gradient is rewritten)
+
+    @staticmethod
+    def backward(ctx, *douts):
+        from .engine import EPI_MUL_DRELU, EPI_PLAIN
+        eng, stacks, Xps, Hss = ctx.eng, ctx.stacks, ctx.Xps, ctx.Hss
+        eng.op_begin()
+        flat = eng.zeros(eng.n_grad)
+        live = list(range(len(stacks)))
+        dXs = [None] * len(stacks)
+        with eng.wgrad_batch() as wb:
+            dAs = {}
+            for k in live:
+                layers, Xp, Hs = stacks[k], Xps[k], Hss[k]
+                rows, head = Xp.shape[0], layers[3]
+                dy = wb.keep(douts[k].contiguous())                    # [rows, n_out]: read with its own leading dimension
+                dH3 = wb.keep(eng.empty(rows, 256))
+                eng.skinny_bwd(addr(dy), head.N, addr(Hs[2]), 256, rows, 256, addr(*head.Wp), 256, head.N, addr(dH3), 256, 1, 0,
+                               addr(*head.dWp), head.ldd, addr(flat, head.db_off))
+                dAs[k] = dH3
+                dXs[k] = eng.empty(rows, layers[0].Kp)
+            for j in (2, 1, 0):
+                descs = []
+                for k in live:
+                    layers, Xp, Hs = stacks[k], Xps[k], Hss[k]
+                    rows, lay = Xp.shape[0], layers[j]
+                    u, ldu = (Xp, lay.Kp) if j == 0 else (Hs[j - 1], 256)
+                    eng.wgrad(addr(dAs[k]), 256, addr(u), ldu, rows, 256, lay.Kp, addr(*lay.dWp), lay.ldd, addr(flat, lay.db_off))
+                    if j > 0:
+                        nxt = wb.keep(eng.empty(rows, 256))
+                        descs.append(eng.nt_desc(addr(dAs[k]), 256, addr(*lay.WpT), lay.ldT, rows, 256, 256, addr(nxt), 256, EPI_MUL_DRELU,
+                                                 H=addr(Hs[j - 1]), ldh=256, mask=getattr(Hs[j - 1], '_nu_mask', None)))
+                        dAs[k] = nxt
+                    else:
+                        descs.append(eng.nt_desc(addr(dAs[k]), 256, addr(*lay.WpT), lay.ldT, rows, lay.Kp, 256, addr(dXs[k]), lay.Kp, EPI_PLAIN))
+                eng.nt_batch(descs)
+        eng.unpack_grads(flat, ctx.layers_union)
+        eng.op_end()
+        ctx.Hss = ctx.Xps = None
+        return (None, None, None, None, _token_grad(eng, flat, ctx.names)) + tuple(dX[:, :K] for dX, K in zip(dXs, ctx.Ks))
+
+
 class MaterialsFn(torch.autograd.Function):
     """The four material predictors batched (metallic, roughness, albedo, transmission) on [feature, x]."""
 
@@ -217,20 +293,21 @@ class MaterialsFn(torch.autograd.Function):
         if dM is not None:
             dMraw[:, :6] = dM
         db0, db12, db6 = eng.mat_db
-        dM3 = e(P, 1024)
-        eng.skinny_bwd(addr(dMraw), 8, addr(s['M3']), 1024, P, 1024, addr(eng.Ws6), 1024, 6, addr(dM3), 1024, 1, 0,
-                       addr(eng.dWs6), 1024, addr(flat, db6))
-        dA = dM3
-        for j, Hin in ((2, s['M2']), (1, s['M1'])):
-            eng.wgrad(addr(dA), 1024, addr(Hin), 1024, P, 256, 256, addr(eng.dWpM[j]), 256, addr(flat, db12[j]),
-                      groups=4, sA0=256, sB0=256, sW=65536, sDb=256)
-            nxt = e(P, 1024)
-            eng.nt(addr(dA), 1024, addr(eng.WpTM[j]), 256, P, 256, 256, addr(nxt), 1024, EPI_MUL_DRELU,
-                   H=addr(Hin), ldh=1024, groups=4, sA=256, sB=65536, sC=256, sH=256, mask=getattr(Hin, '_nu_mask', None))
-            dA = nxt
-        eng.wgrad(addr(dA), 1024, addr(s['YX']), 288, P, 1024, 288, addr(eng.dWpM0), 288, addr(flat, db0))
-        dYX = e(P, 288)
-        eng.nt(addr(dA), 1024, addr(eng.WpTM0), 1024, P, 288, 1024, addr(dYX), 288, EPI_PLAIN)
+        with eng.wgrad_batch() as wb:                 # the op's three weight gradients: one queue, launched together
+            dM3 = wb.keep(e(P, 1024))
+            eng.skinny_bwd(addr(dMraw), 8, addr(s['M3']), 1024, P, 1024, addr(eng.Ws6), 1024, 6, addr(dM3), 1024, 1, 0,
+                           addr(eng.dWs6), 1024, addr(flat, db6))
+            dA = dM3
+            for j, Hin in ((2, s['M2']), (1, s['M1'])):
+                eng.wgrad(addr(dA), 1024, addr(Hin), 1024, P, 256, 256, addr(eng.dWpM[j]), 256, addr(flat, db12[j]),
+                          groups=4, sA0=256, sB0=256, sW=65536, sDb=256)
+                nxt = wb.keep(e(P, 1024))
+                eng.nt(addr(dA), 1024, addr(eng.WpTM[j]), 256, P, 256, 256, addr(nxt), 1024, EPI_MUL_DRELU,
+                       H=addr(Hin), ldh=1024, groups=4, sA=256, sB=65536, sC=256, sH=256, mask=getattr(Hin, '_nu_mask', None))
+                dA = nxt
+            eng.wgrad(addr(dA), 1024, addr(s['YX']), 288, P, 1024, 288, addr(eng.dWpM0), 288, addr(flat, db0))
+            dYX = e(P, 288)
+            eng.nt(addr(dA), 1024, addr(eng.WpTM0), 1024, P, 288, 1024, addr(dYX), 288, EPI_PLAIN)
         eng.unpack_grads(flat, eng.mat_layers)
         eng.op_end()
         ctx.s = None
@@ -266,18 +343,19 @@ class IorFn(torch.autograd.Function):
         rows = Xp.shape[0]
         flat = eng.zeros(eng.n_grad)
         dy = (dout.contiguous() if dout is not None else eng.zeros(rows)).reshape(rows, 1).contiguous()
-        d2 = eng.empty(rows, 256)
-        eng.skinny_bwd(addr(dy), 1, addr(H[2]), 256, rows, 256, addr(*ls[3].Wp), 256, 1, addr(d2), 256, 0, 0,
-                       addr(*ls[3].dWp), ls[3].ldd, addr(flat, ls[3].db_off))
-        eng.wgrad(addr(d2), 256, addr(H[1]), 256, rows, 256, 256, addr(*ls[2].dWp), ls[2].ldd, addr(flat, ls[2].db_off))
-        d1 = eng.empty(rows, 256)
-        eng.nt(addr(d2), 256, addr(*ls[2].WpT), ls[2].ldT, rows, 256, 256, addr(d1), 256, EPI_MUL_DRELU, H=addr(H[1]), ldh=256)
-        eng.wgrad(addr(d1), 256, addr(H[0]), 256, rows, 256, 256, addr(*ls[1].dWp), ls[1].ldd, addr(flat, ls[1].db_off))
-        d0 = eng.empty(rows, 256)
-        eng.nt(addr(d1), 256, addr(*ls[1].WpT), ls[1].ldT, rows, 256, 256, addr(d0), 256, EPI_MUL_DRELU, H=addr(H[0]), ldh=256)
-        eng.wgrad(addr(d0), 256, addr(Xp), 64, rows, 256, 64, addr(*ls[0].dWp), ls[0].ldd, addr(flat, ls[0].db_off))
-        dX = eng.empty(rows, 64)
-        eng.nt(addr(d0), 256, addr(*ls[0].WpT), ls[0].ldT, rows, 64, 256, addr(dX), 64, EPI_PLAIN)
+        with eng.wgrad_batch():               # the op's weight gradients: one queue (every operand is a local that outlives the block)
+            d2 = eng.empty(rows, 256)
+            eng.skinny_bwd(addr(dy), 1, addr(H[2]), 256, rows, 256, addr(*ls[3].Wp), 256, 1, addr(d2), 256, 0, 0,
+                           addr(*ls[3].dWp), ls[3].ldd, addr(flat, ls[3].db_off))
+            eng.wgrad(addr(d2), 256, addr(H[1]), 256, rows, 256, 256, addr(*ls[2].dWp), ls[2].ldd, addr(flat, ls[2].db_off))
+            d1 = eng.empty(rows, 256)
+            eng.nt(addr(d2), 256, addr(*ls[2].WpT), ls[2].ldT, rows, 256, 256, addr(d1), 256, EPI_MUL_DRELU, H=addr(H[1]), ldh=256)
+            eng.wgrad(addr(d1), 256, addr(H[0]), 256, rows, 256, 256, addr(*ls[1].dWp), ls[1].ldd, addr(flat, ls[1].db_off))
+            d0 = eng.empty(rows, 256)
+            eng.nt(addr(d1), 256, addr(*ls[1].WpT), ls[1].ldT, rows, 256, 256, addr(d0), 256, EPI_MUL_DRELU, H=addr(H[0]), ldh=256)
+            eng.wgrad(addr(d0), 256, addr(Xp), 64, rows, 256, 64, addr(*ls[0].dWp), ls[0].ldd, addr(flat, ls[0].db_off))
+            dX = eng.empty(rows, 64)
+            eng.nt(addr(d0), 256, addr(*ls[0].WpT), ls[0].ldT, rows, 64, 256, addr(dX), 64, EPI_PLAIN)
         eng.unpack_grads(flat, ls)
         eng.op_end()
         ctx.H = ctx.Xp = None
@@ -329,23 +407,24 @@ class IorPairFn(torch.autograd.Function):
 
         def st(pa, pb):
             return (pb - pa) // 4
-        d2 = eng.empty(2, rows, 256)
-        for z, ls in enumerate((la, lb)):
-            eng.skinny_bwd(addr(dy, z * rows), 1, addr(H[2], z * sH), 256, rows, 256, addr(*ls[3].Wp), 256, 1, addr(d2, z * sH), 256, 0, 0,
-                           addr(*ls[3].dWp), ls[3].ldd, addr(flat, ls[3].db_off))
-        d_prev = d2
-        for k in (2, 1):
-            eng.wgrad(addr(d_prev), 256, addr(H[k - 1]), 256, rows, 256, 256, addr(*la[k].dWp), la[k].ldd, addr(flat, la[k].db_off),
-                      groups=2, sA0=sH, sB0=sH, sW=st(addr(*la[k].dWp), addr(*lb[k].dWp)), sDb=lb[k].db_off - la[k].db_off)
-            d_next = eng.empty(2, rows, 256)
-            eng.nt(addr(d_prev), 256, addr(*la[k].WpT), la[k].ldT, rows, 256, 256, addr(d_next), 256, EPI_MUL_DRELU, H=addr(H[k - 1]), ldh=256,
-                   groups=2, sA=sH, sB=st(addr(*la[k].WpT), addr(*lb[k].WpT)), sC=sH, sH=sH)
-            d_prev = d_next
-        eng.wgrad(addr(d_prev), 256, addr(Xp), 64, rows, 256, 64, addr(*la[0].dWp), la[0].ldd, addr(flat, la[0].db_off),
-                  groups=2, sA0=sH, sB0=0, sW=st(addr(*la[0].dWp), addr(*lb[0].dWp)), sDb=lb[0].db_off - la[0].db_off)
-        dX = eng.empty(2, rows, 64)
-        eng.nt(addr(d_prev), 256, addr(*la[0].WpT), la[0].ldT, rows, 64, 256, addr(dX), 64, EPI_PLAIN,
-               groups=2, sA=sH, sB=st(addr(*la[0].WpT), addr(*lb[0].WpT)), sC=rows * 64)
+        with eng.wgrad_batch() as wb:         # the op's weight gradients: one queue; the intermediate cotangents are held until it is launched
+            d2 = eng.empty(2, rows, 256)
+            for z, ls in enumerate((la, lb)):
+                eng.skinny_bwd(addr(dy, z * rows), 1, addr(H[2], z * sH), 256, rows, 256, addr(*ls[3].Wp), 256, 1, addr(d2, z * sH), 256, 0, 0,
+                               addr(*ls[3].dWp), ls[3].ldd, addr(flat, ls[3].db_off))
+            d_prev = d2
+            for k in (2, 1):
+                eng.wgrad(addr(d_prev), 256, addr(H[k - 1]), 256, rows, 256, 256, addr(*la[k].dWp), la[k].ldd, addr(flat, la[k].db_off),
+                          groups=2, sA0=sH, sB0=sH, sW=st(addr(*la[k].dWp), addr(*lb[k].dWp)), sDb=lb[k].db_off - la[k].db_off)
+                d_next = wb.keep(eng.empty(2, rows, 256))
+                eng.nt(addr(d_prev), 256, addr(*la[k].WpT), la[k].ldT, rows, 256, 256, addr(d_next), 256, EPI_MUL_DRELU, H=addr(H[k - 1]), ldh=256,
+                       groups=2, sA=sH, sB=st(addr(*la[k].WpT), addr(*lb[k].WpT)), sC=sH, sH=sH)
+                d_prev = d_next
+            eng.wgrad(addr(d_prev), 256, addr(Xp), 64, rows, 256, 64, addr(*la[0].dWp), la[0].ldd, addr(flat, la[0].db_off),
+                      groups=2, sA0=sH, sB0=0, sW=st(addr(*la[0].dWp), addr(*lb[0].dWp)), sDb=lb[0].db_off - la[0].db_off)
+            dX = eng.empty(2, rows, 64)
+            eng.nt(addr(d_prev), 256, addr(*la[0].WpT), la[0].ldT, rows, 64, 256, addr(dX), 64, EPI_PLAIN,
+                   groups=2, sA=sH, sB=st(addr(*la[0].WpT), addr(*lb[0].WpT)), sC=rows * 64)
         eng.unpack_grads(flat, la)
         eng.unpack_grads(flat, lb)
         eng.op_end()
@@ -435,3 +514,17 @@ class Stage1Nets:
     def predictor(self, name, X):
         layers, names, params = self.stack[name]
         return StackFn.apply(self.eng, layers, X, names, self.token())
+
+    def predictors(self, which, Xs):
+        """Raw heads of several predictor stacks of ONE shading call (`which` in the engine's table order, e.g. ('outer_light',
+        'inner_light', 'inner_weight')) as one op: level j of all stacks is one launch (StacksFn)."""
+        key = tuple(which)
+        u = self.__dict__.setdefault('_unions', {}).get(key)
+        if u is None:
+            layers_union = [lay for nm in which for lay in self.stack[nm][0]]
+            names_union = [n for nm in which for n in self.stack[nm][1]]
+            _own_range(self.eng, names_union)                 # one contiguous range of the flat buffer (asserted)
+            u = self._unions[key] = (tuple(self.stack[nm][0] for nm in which), layers_union, names_union)
+        if os.environ.get('NU_S2_STACKS') == '0' or any(X.shape[0] == 0 for X in Xs):      # development switch (A/B): one op per stack
+            return tuple(self.predictor(nm, X) for nm, X in zip(which, Xs))
+        return StacksFn.apply(self.eng, u[0], u[1], u[2], self.token(), *Xs)

@@ -80,10 +80,12 @@ def shade(nets, scfg, lut, points, normals, view_dirs, feats, s2=False, is_inter
     m_raw = nets.materials(feats, points)
     rf = -1 if s2 else int(scfg.get('refrac_freq', 6))
     OL, IL, IW, RL, nov1, SD = O.shade_encode(nets.eng, points, normals, view_dirs, m_raw, sphere, pos_freq, rf)
-    ol, il, iw = nets.predictor('outer_light', OL), nets.predictor('inner_light', IL), nets.predictor('inner_weight', IW)
+    # the stacks of one shading call are independent of each other: ONE op, level j of all of them in one launch (nets.StacksFn)
     rl = None
-    if not s2:
-        rl = nets.predictor('refrac_light', RL)
+    if s2:
+        ol, il, iw = nets.predictors(('outer_light', 'inner_light', 'inner_weight'), (OL, IL, IW))
+    else:
+        ol, il, iw, rl = nets.predictors(('outer_light', 'inner_light', 'inner_weight', 'refrac_light'), (OL, IL, IW, RL))
         if rl_max < exp_max:     # AppShadingNetwork_SpecInner's refrac_light caps at exp(-0.2) (field.py:1373): clamp the raw head,
             rl = torch.clamp(rl, max=rl_max)     # the kernel's own min(., exp_max) is then the identity
     if aux is not None:          # what the occlusion probe of the caller needs (occ_info of field.py:1533-1537)
