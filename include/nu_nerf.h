@@ -370,6 +370,9 @@ int nu_sdf_mlp_fwd(NuOpCtx* ctx, const NuSdfNet* net, const float* X, int x_ld, 
  * want_feat = 0).  Serves the hierarchical sampler (renderer_zerothick.py:525-612: 64 + 3 x 16 queries per ray), the occlusion
  * probe (field.py:501-554), extract_fields (field.py:1286-1307) and the stage-2 inner up-sampler (renderer_zerothick.py:1742-1760). */
 int nu_sdf_fused_fwd(const NuSdfNet* net, const float* X, int x_ld, int P, float* sdf, hipStream_t stream);
+/* the same in the bf16-STORAGE arithmetic (NuOpCtx.h16: bf16 weight tables NuLin.Wp16, activations rounded to bf16 between layers,
+ * v_mfma_f32_32x32x16_bf16 with fp32 accumulation): bit-identical to nu_sdf_mlp_fwd(..., want_feat = 0) under h16 */
+int nu_sdf_fused16_fwd(const NuSdfNet* net, const float* X, int x_ld, int P, float* sdf, hipStream_t stream);
 int nu_sdf_mlp_normal(NuOpCtx* ctx, const NuSdfNet* net, NuSdfBufs* bufs, hipStream_t stream);
 int nu_sdf_mlp_bwd(NuOpCtx* ctx, const NuSdfNet* net, NuSdfBufs* bufs, const float* dYX, const float* nbar, float* dx,
                    hipStream_t stream);

@@ -818,6 +818,12 @@ class Stage1Engine:
             sdf = e(P)
             L.check(lib.nu_sdf_fused_fwd(ctypes.byref(self._sdf_net), c_p(X), x_ld, P, c_p(addr(sdf)), S), "nu_sdf_fused_fwd")
             return {'P': P, 'sdf': sdf}
+        if not keep and not want_feat and self.h16 and self._fused_sdf and getattr(self, '_sdf_net', None) is not None:
+            # bf16 storage: the same network in ONE kernel (csrc/fused_sdf.hip, sdf_fused16_fwd_kernel), bit-identical to the layered
+            # bf16-storage path below -- a point costs 12 bytes in and 4 out instead of 1 KB per layer
+            sdf = e(P)
+            L.check(lib.nu_sdf_fused16_fwd(ctypes.byref(self._sdf_net), c_p(X), x_ld, P, c_p(addr(sdf)), S), "nu_sdf_fused16_fwd")
+            return {'P': P, 'sdf': sdf}
         a = {'P': P}
         a['E'] = e(P, 64)
         a['U4'] = e(P, 256)

@@ -71,3 +71,34 @@ def test_code_object_targets_gfx950_only():
     assert b"gfx950" in data
     for other in (b"gfx942", b"gfx90a", b"sm_90"):
         assert other not in data
+
+
+def test_hot_kernels_register_budget_from_the_code_object(lib):
+    """Reads the code-object metadata of the built objects (scripts/kernel_regs.py: llvm-readelf --notes on the device ELF inside
+    nu_nerf_amd/build/*.o).  The exact-fp32 default kernels -- NT (single problem and batched), the weight-gradient kernels, the
+    fused SDF forwards -- must not spill a single VGPR and use no scratch memory.  The bf16-storage NT kernel (gemm_nt16b_kernel) is
+    built for THREE workgroups per CU (168 VGPRs): its bf16-operand instantiations may spill at most 8 registers in the per-tile
+    prologue / epilogue (none in the chunk loop) -- measured on config 4, same box: the spill-free two-workgroup build is 16 % slower
+    per step (44.2 vs 38.2 ms, profiles/r04/README.md), occupancy is what this latency-bound kernel lives on -- and the instantiations
+    with an fp32 A operand (one more 16-register prefetch set) at most 32."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    from kernel_regs import kernel_table
+    bdir = os.path.join(ROOT, "nu_nerf_amd", "build")
+    seen = 0
+    for obj in ("gemm_nt", "gemm_tn", "fused_sdf"):
+        for name, r in kernel_table(os.path.join(bdir, obj + ".o")):
+            hot = name.startswith(("gemm_nt2_kernel<", "gemm_nt2b_kernel<", "gemm_tn2_kernel<", "gemm_tn2b_kernel<", "gemm_tnb_kernel<",
+                                   "gemm_tn_kernel<false, 0>", "gemm_tn_kernel<true, 0>", "sdf_fused"))
+            if hot:
+                seen += 1
+                assert r["vgpr_spill"] == 0 and r["scratch"] == 0, (name, r)
+    assert seen >= 40
+    n16 = 0
+    for name, r in kernel_table(os.path.join(bdir, "gemm_nt16.o")):
+        if name.startswith("gemm_nt16b_kernel<"):
+            n16 += 1
+            cap = 8 if ", true>" in name else 32
+            assert r["vgpr_spill"] <= cap and r["vgpr"] <= 168, (name, r)
+            assert r["lds"] <= 53 * 1024, (name, r)             # three workgroups per CU
+    assert n16 == 18

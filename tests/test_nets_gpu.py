@@ -109,7 +109,11 @@ def test_predictor_stack_and_materials(nets, gpu):
     assert rel_err(fg.grad.cpu(), fo.grad) < 1e-4 and rel_err(xg.grad.cpu(), xo.grad) < 1e-4
 
 
-@pytest.mark.parametrize("P", [1, 31, 64, 1000, 8192, 20000])
+CFG16 = {'is_nerf': True, 'n_samples': 32, 'n_importance': 32, 'n_bg_samples': 16, 'freeze_inv_s_step': 15000,
+         'apply_occ_loss': True, 'occ_loss_step': 15000, 'eikonal_weight': 0.1, 'mlp_dtype': 'bf16'}
+
+
+@pytest.mark.parametrize("P", [1, 31, 64, 1000, 8192, 20000, 30001])
 def test_fused_sdf_forward_is_bit_identical_to_the_layered_path(gpu, P):
     """csrc/fused_sdf.hip: the no-gradient SDF forward as one kernel (field.py:133-153 + the embedding :47-61 + the skip concat
     :142-143) -- same MFMA k order, same softplus, same head reduction as the layer-by-layer path, so the results are equal BIT for
@@ -130,6 +134,19 @@ def test_fused_sdf_forward_is_bit_identical_to_the_layered_path(gpu, P):
         layered = eng.sdf_forward(addr(X), x_ld, P, keep=False, want_feat=False)['sdf'].clone()
         eng._fused_sdf = True
         assert torch.equal(fused, layered), float((fused - layered).abs().max())
+    # the bf16-storage arithmetic (mlp_dtype 'bf16', BASELINE config 4) has a fused kernel of its own (sdf_fused16_fwd_kernel): bit
+    # for bit the layered bf16-storage path (bf16 weight tables, activations rounded to bf16 between layers, fp32 accumulation)
+    if P in (1, 31, 1000, 20000, 30001):           # 32-, 64- and 128-row tiles (the last: 512 threads, two row groups per weight stream)
+        net16 = make_net(gpu, cfg=dict(CFG16))
+        e16 = net16.engine()
+        assert e16.h16
+        e16.pack()
+        X16 = (torch.rand(P, 3, device=gpu) * 2 - 1) * 0.9
+        e16._fused_sdf = True
+        f16 = e16.sdf_forward(addr(X16), 3, P, keep=False, want_feat=False)['sdf'].clone()
+        e16._fused_sdf = False
+        l16 = e16.sdf_forward(addr(X16), 3, P, keep=False, want_feat=False)['sdf'].clone()
+        assert torch.equal(f16, l16), float((f16 - l16).abs().max())
     # float64 reference of SDFNetwork.forward with the module's own weights
     sd = {k: v.detach().double() for k, v in net.state_dict().items() if k.startswith('sdf_network.')}
     x = X[:, :3].double()
