@@ -79,12 +79,17 @@ def cpu_baseline(rays_cpu, step0, budget_s=20.0):
         if it > 0:
             times.append(dt)
         it += 1
-        if (time.time() - t_start > budget_s and len(times) >= 1) or len(times) >= 8:
+        if (time.time() - t_start > budget_s and len(times) >= 5) or len(times) >= 8:
             break
-    ms = 1e3 * float(np.mean(times))
+    # the MEDIAN of at least five iterations, with the spread: on a 128-thread host a single iteration moves by +-30 % (36 rays/s in
+    # round 3 against 50 in rounds 1-2 came from the mean of five)
+    ms = 1e3 * float(np.median(times))
     return {"value": R / (ms / 1e3), "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{len(times)} full iterations (fwd+bwd+Adam) of {R} rays x 160 samples after 1 warm-up, "
-                      f"{ms:.0f} ms/iter, torch CPU fp32, os.cpu_count()={os.cpu_count()}"}
+            "statistic": "median", "iterations": len(times),
+            "spread_rays_per_s": [round(R / max(times), 1), round(R / min(times), 1)],
+            "sample": f"{len(times)} full iterations (fwd+bwd+Adam) of {R} rays x 160 samples after 1 warm-up, median "
+                      f"{ms:.0f} ms/iter (min {1e3 * min(times):.0f}, max {1e3 * max(times):.0f}), torch CPU fp32, "
+                      f"os.cpu_count()={os.cpu_count()}"}
 
 
 def spawn_ranks_or_die(args):
@@ -274,7 +279,7 @@ def stage2_leg(args):
     return res
 
 
-def find_traffic_profile(R, world, real_capture, mlp_dtype, object_rays, h16, p_in, p_out):
+def find_traffic_profile(R, world, real_capture, mlp_dtype, object_rays, h16, p_in, p_out, nt_launches=None):
     """HBM traffic per launch of the dominant kernel from a committed rocprofv3 PMC pass (FETCH_SIZE / WRITE_SIZE in separate
     --pmc runs, gfx950 corrections applied by scripts/summarize_pmc.py) -- but only when that pass was collected on THIS
     workload: same configuration and mean inner / outer point counts within 5 % of this run's; otherwise (None, None, None):
@@ -300,6 +305,11 @@ def find_traffic_profile(R, world, real_capture, mlp_dtype, object_rays, h16, p_
             continue
         pi, po = w.get('mean_inner_points', 0), w.get('mean_outer_points', 0)
         if pi <= 0 or po <= 0 or abs(pi - p_in) > 0.05 * pi or abs(po - p_out) > 0.05 * po:
+            continue
+        # bytes PER LAUNCH only carry over to a run with the same launch structure (round 4 merged launches: a round-3 pass
+        # averaged over 120 NT launches per step says nothing about a step of 104)
+        lps = w.get('nt_launches_per_step')
+        if nt_launches is not None and (lps is None or abs(lps - nt_launches) > 0.03 * nt_launches):
             continue
         return (d.get('gemm_nt_kernel', {}).get('hbm_bytes_per_launch'), d.get('gemm_tn_kernel', {}).get('hbm_bytes_per_launch'),
                 os.path.relpath(f, ROOT))
@@ -449,7 +459,7 @@ def stage1_leg(args, dist_ctx):
     if ktime is not None:
         tf = ktime['flops'] / max(ktime['seconds'], 1e-12) / 1e12
         traffic, traffic_tn, traffic_src = find_traffic_profile(R, world, args.real_capture, args.mlp_dtype, args.object_rays,
-                                                                eng.h16, p_in, p_out)
+                                                                eng.h16, p_in, p_out, nt_launches=ktime['launches'] / max(timed_steps, 1))
         br_ms = float(np.sum(step_ms[bracketed]))
         common = {"algorithmic_bytes_per_launch": ktime['bytes'] / max(ktime['launches'], 1),
                   "algorithmic_flops_per_launch": ktime['flops'] / max(ktime['launches'], 1),
@@ -458,7 +468,7 @@ def stage1_leg(args, dist_ctx):
                   "event_pool_exhausted": bool(ktime['event_capacity_reached'] or ktime['python_event_pool_exhausted']),
                   "gemm_time_share": ktime['seconds'] / (elapsed * timed_steps / args.steps),
                   "traffic_source": traffic_src if traffic is not None else
-                  "null: no committed PMC pass matches this run's configuration and mean point counts within 5 %",
+                  "null: no committed PMC pass matches this run's configuration, launch structure and mean point counts within 5 %",
                   "wgrad": {"achieved": ktime['tn_flops'] / max(ktime['tn_seconds'], 1e-12) / 1e12,
                             "launches": ktime['tn_launches'],
                             "algorithmic_bytes_per_launch": ktime['tn_bytes'] / max(ktime['tn_launches'], 1),

@@ -233,10 +233,14 @@ int nu_partition_write(const float* o, const float* d, const float* z, int R, in
 int nu_neus_alpha_fwd(const float* YX, int ldy, const float* nrm, const float* pt, const int* idx, int P,
                       const float* variance, float anneal, float* alpha_rm, float* gerr, float* color_rm,
                       hipStream_t stream);
+/* dvar (optional): d L / d variance, a sum over all points -- per-block partials go to `workspace`
+ * (nu_neus_alpha_bwd_workspace_bytes(P)) and ONE deferred reduction problem is appended to descs (finished by
+ * nu_slab_reduce_batched, like every weight gradient): deterministic, and no state inside the library */
+long long nu_neus_alpha_bwd_workspace_bytes(int P);
 int nu_neus_alpha_bwd(const float* YX, int ldy, const float* nrm, const float* pt, const int* idx, int P,
                       const float* variance, float anneal, const float* dalpha_rm, const float* dgerr,
                       const float* dn_shade, const float* dcolor_rm, float* dYX, int lddy, float* nbar, float* dvar,
-                      hipStream_t stream);
+                      void* workspace, long long workspace_bytes, NuReduceDesc* descs, int* ndesc, int cap, hipStream_t stream);
 /* density_activation + colour activation of compute_density_alpha (:515-516, :691-692) */
 int nu_nerf_act_fwd(const float* sigma, int lds, const float* rgb, int ldr, const float* pt, const int* idx, int P,
                     float* alpha_rm, float* color_rm, hipStream_t stream);

@@ -9,6 +9,7 @@
 //   compute_density_alpha  network/renderer_zerothick.py:687-693, :515-516
 //   AppShadingNetwork mix  network/field.py:698-740  (+ :658-665 light mixing)
 #include "nu_common.h"
+#include "gemm.h"
 
 #define NU_PT 8
 #define NU_MAXCHUNK 4  // samples per lane: supports up to 256 samples per ray
@@ -233,13 +234,10 @@ extern "C" int nu_neus_alpha_fwd(const float* YX, int ldy, const float* nrm, con
 
 // backward: dalpha_rm (ray-major), dgerr[p] (per-point cotangent of gradient_error), dn_shade (may be null)
 //   -> dYX[p, 0] = d sdf ;  nbar[p, 0:3] = total cotangent of the raw normal ;  dvar += d variance
-// The variance gradient is a sum over all points: every block leaves its partial in a device array and the block that finishes
-// LAST adds them up in index order -- no float atomics, so the gradient does not depend on the order the blocks happened to run in
-// (it used to: one atomicAdd per block made d variance differ by an ulp from run to run).  One launch at a time per process
-// (the launcher is only ever called on the engine's main stream).
-#define NU_DVAR_MAX_BLOCKS 65536
-__device__ float nu_dvar_partial[NU_DVAR_MAX_BLOCKS];
-__device__ unsigned nu_dvar_done;
+// The variance gradient is a sum over all points: every block leaves its partial (already scaled by d inv_s / d variance) in a
+// slab of the CALLER's workspace, and the deterministic batched split reduction the weight gradients use (nu_slab_reduce_batched)
+// adds the slab up in a fixed order -- no float atomics (one atomicAdd per block used to make d variance differ by an ulp from run
+// to run), and no state in the library: two engines, or two streams, may train their variances at the same time.
 __global__ __launch_bounds__(256) void neus_alpha_bwd_kernel(const float* __restrict__ YX, int ldy,
                                                              const float* __restrict__ nrm, const float* __restrict__ pt,
                                                              const int* __restrict__ idx, int P,
@@ -249,7 +247,7 @@ __global__ __launch_bounds__(256) void neus_alpha_bwd_kernel(const float* __rest
                                                              const float* __restrict__ dn_shade,
                                                              const float* __restrict__ dcolor_rm,
                                                              float* __restrict__ dYX, int lddy, float* __restrict__ nbar,
-                                                             float* __restrict__ dvar) {
+                                                             float* __restrict__ dvar_partial) {
     __shared__ float red[4];
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     float dinv = 0.f;
@@ -275,44 +273,33 @@ __global__ __launch_bounds__(256) void neus_alpha_bwd_kernel(const float* __rest
             nbar[p * 3LL + c] = (ga * v.dalpha_dcos + gno) * d[c] + ke * n[c] + (dn_shade ? dn_shade[p * 3LL + c] : 0.f);
         dinv = ga * v.dalpha_dinvs;
     }
-    if (dvar) {
+    if (dvar_partial) {
         dinv = nu_wave_sum(dinv);
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dinv;
         __syncthreads();
-        __shared__ bool last;
         if (threadIdx.x == 0) {
-            nu_dvar_partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
-            __threadfence();
-            last = atomicAdd(&nu_dvar_done, 1u) == gridDim.x - 1;
-        }
-        __syncthreads();
-        if (last) {                                  // whole block: strided partial sums, then a fixed tree
-            __threadfence();
-            float s = 0.f;
-            for (unsigned i = threadIdx.x; i < gridDim.x; i += 256) s += __builtin_nontemporal_load(&nu_dvar_partial[i]);
-            __shared__ float tree[256];
-            tree[threadIdx.x] = s;
-            __syncthreads();
-            for (int o = 128; o > 0; o >>= 1) {
-                if ((int)threadIdx.x < o) tree[threadIdx.x] += tree[threadIdx.x + o];
-                __syncthreads();
-            }
-            if (threadIdx.x == 0) {
-                const bool pass = raw >= 1e-6f && raw <= 1e6f;
-                if (pass && tree[0] != 0.f) *dvar += tree[0] * raw * 10.0f;
-                nu_dvar_done = 0;
-            }
+            const bool pass = raw >= 1e-6f && raw <= 1e6f;           // inside the clip range: d inv_s / d variance = 10 inv_s
+            dvar_partial[blockIdx.x] = pass ? ((red[0] + red[1]) + (red[2] + red[3])) * raw * 10.0f : 0.f;
         }
     }
 }
+extern "C" long long nu_neus_alpha_bwd_workspace_bytes(int P) { return (long long)nu_cdiv(P > 0 ? P : 1, 256) * sizeof(float); }
 extern "C" int nu_neus_alpha_bwd(const float* YX, int ldy, const float* nrm, const float* pt, const int* idx, int P,
                                  const float* variance, float anneal, const float* dalpha_rm, const float* dgerr,
                                  const float* dn_shade, const float* dcolor_rm, float* dYX, int lddy, float* nbar,
-                                 float* dvar, hipStream_t stream) {
+                                 float* dvar, void* workspace, long long workspace_bytes, NuReduceDesc* descs, int* ndesc, int cap,
+                                 hipStream_t stream) {
     if (P <= 0) return NU_OK;
-    if (dvar && nu_cdiv(P, 256) > NU_DVAR_MAX_BLOCKS) return NU_ERR_ARG;
-    hipLaunchKernelGGL(neus_alpha_bwd_kernel, dim3(nu_cdiv(P, 256)), dim3(256), 0, stream, YX, ldy, nrm, pt, idx, P,
-                       variance, anneal, dalpha_rm, dgerr, dn_shade, dcolor_rm, dYX, lddy, nbar, dvar);
+    const int nblk = nu_cdiv(P, 256);
+    float* partial = nullptr;
+    if (dvar) {         // d variance = sum of the per-block partials: one deferred reduction problem (finished by nu_slab_reduce_batched / nu_ctx_flush)
+        if (!workspace || !descs || !ndesc || workspace_bytes < nu_neus_alpha_bwd_workspace_bytes(P)) return NU_ERR_WORKSPACE;
+        partial = static_cast<float*>(workspace);
+        const int rc = nu_reduce_push(descs, ndesc, cap, partial, nblk, 1, 1, 1, 1, dvar, 1, 1.0f, 0);
+        if (rc != NU_OK) return rc;
+    }
+    hipLaunchKernelGGL(neus_alpha_bwd_kernel, dim3(nblk), dim3(256), 0, stream, YX, ldy, nrm, pt, idx, P,
+                       variance, anneal, dalpha_rm, dgerr, dn_shade, dcolor_rm, dYX, lddy, nbar, partial);
     return nu_launch_status();
 }
 

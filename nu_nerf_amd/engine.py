@@ -163,7 +163,7 @@ class Stage1Engine:
         self.ld_rl = rup(2 * self.refrac_dim, 32)
         lib = self.lib
         for fn in ("nu_wgrad_workspace_bytes", "nu_skinny_bwd_workspace_bytes", "nu_colsum_workspace_bytes",
-                   "nu_gemm_tn_workspace_bytes"):
+                   "nu_gemm_tn_workspace_bytes", "nu_neus_alpha_bwd_workspace_bytes"):
             getattr(lib, fn).restype = c_ll
         assert lib.nu_pack_desc_size() == ctypes.sizeof(PackDesc), "PackDesc ABI mismatch"
         assert lib.nu_reduce_desc_size() == ctypes.sizeof(ReduceDesc), "ReduceDesc ABI mismatch"
@@ -266,16 +266,35 @@ class Stage1Engine:
     _TWO_STREAM_SAMPLES = int(os.environ.get('NU_TWO_STREAM_SAMPLES', 200000))
     _FUSED_SDF_MAX_POINTS = int(os.environ.get('NU_FUSED_SDF_MAX_POINTS', 40000))
 
-    def _fork(self):
+    def _fork(self, mark=True):
+        """mark=False (stage 2): the ops of this engine that run on the two streams are totally ordered by events (op_begin /
+        op_end), so a mid-pass flush of its arena is safe and NuOpCtx.forked stays clear -- nothing to restore if the window is
+        left by an exception."""
         if getattr(self, '_side', None) is None:
             self._side = torch.cuda.Stream(self.dev)
         self._side.wait_stream(torch.cuda.current_stream(self.dev))
-        self._ctx.forked = 1          # until _join: no mid-pass flush of the shared arena (fail closed, NuOpCtx.forked)
+        if mark:
+            self._ctx.forked = 1      # until _join: no mid-pass flush of the shared arena (fail closed, NuOpCtx.forked)
         return self._side
 
     def _join(self):
         torch.cuda.current_stream(self.dev).wait_stream(self._side)
         self._ctx.forked = 0
+
+    def forked(self):
+        """`with eng.forked() as side:` -- the fork / join pair as a context: whatever the block raises (a full arena fails closed
+        with NuNerfLibraryError while two streams share it), the caller's stream waits for the side stream again and NuOpCtx.forked
+        is cleared, so a later single-stream pass on this engine may flush mid-pass as usual."""
+        eng = self
+
+        class _Forked:
+            def __enter__(self):
+                return eng._fork()
+
+            def __exit__(self, et, ev, tb):
+                eng._join()
+                return False
+        return _Forked()
 
     # Stage 2 runs the ops of ONE engine on two streams (the inner segment on the side stream, the IoR / thickness networks on the
     # caller's): they share this engine's reduction arena and descriptor list, which a flush resets.  The host issues the ops one
@@ -1402,6 +1421,28 @@ class Stage1Engine:
         return out
 
     # ------------------------------------------------------------------ render_core
+    def _render_forward_inner(self, ctx, out, o, d, P_in, pt_in, idx_in, alpha_rm, color_rm, anneal, spec_pts):
+        """The inner-point chain of render_forward (SDF, normal, NeuS alpha, shading) on the caller's stream."""
+        lib, S_, e = self.lib, self.stream(), self.empty
+        # unit ray directions for the per-ray mirror query (dirs[:,0,:] in the reference)
+        du = torch.nn.functional.normalize(d, dim=-1).contiguous()
+        if P_in > 0:
+            a = self.sdf_forward(addr(pt_in), 8, P_in, keep=True)
+            self.sdf_normal(a)
+            gerr = e(P_in)
+            var = self.p['deviation_network.variance']
+            L.check(lib.nu_neus_alpha_fwd(c_p(addr(a['YX'])), 288, c_p(addr(a['n'])), c_p(addr(pt_in)), c_p(addr(idx_in)),
+                                          P_in, c_p(addr(var)), c_f(anneal), c_p(addr(alpha_rm)), c_p(addr(gerr)),
+                                          c_p(addr(color_rm)), S_), "nu_neus_alpha_fwd")
+            s = self.shading_forward(a, pt_in, idx_in, P_in, color_rm, extra_dirs=du, extra_pts=spec_pts)
+            ctx.update(sdf=a, shade=s)
+            out['gradient_error'] = gerr
+            out['spec_raw'] = s['OLo'][3 * P_in:, :3]
+            out['occ_raw'] = s['IWo']
+            out['sdf_in'] = a['YX'][:, 0]
+            out['aux'] = s['aux']
+            out['normal_raw'] = a['n']
+
     def render_forward(self, o, d, z, anneal, want_weights=False, spec_pts=None):
         """Stage-1 render_core forward (renderer_zerothick.py:725-820) on R rays with S samples each.
         Returns (outputs dict of tensors, ctx) ; one host sync (the inner-point count)."""
@@ -1425,32 +1466,19 @@ class Stage1Engine:
                    inner_rm=inner_rm, alpha_rm=alpha_rm, color_rm=color_rm, anneal=float(anneal))
         two = P_out > 0 and P_in > 0 and R * S <= self._TWO_STREAM_SAMPLES
         ctx['two_streams'] = two
-        if two:
-            with torch.cuda.stream(self._fork()):
-                ctx['nerf'] = self.nerf_forward(pt_out, idx_out, P_out, alpha_rm, color_rm)
-        elif P_out > 0:
-            ctx['nerf'] = self.nerf_forward(pt_out, idx_out, P_out, alpha_rm, color_rm)
         out = {}
-        # unit ray directions for the per-ray mirror query (dirs[:,0,:] in the reference)
-        du = torch.nn.functional.normalize(d, dim=-1).contiguous()
-        if P_in > 0:
-            a = self.sdf_forward(addr(pt_in), 8, P_in, keep=True)
-            self.sdf_normal(a)
-            gerr = e(P_in)
-            var = self.p['deviation_network.variance']
-            L.check(lib.nu_neus_alpha_fwd(c_p(addr(a['YX'])), 288, c_p(addr(a['n'])), c_p(addr(pt_in)), c_p(addr(idx_in)),
-                                          P_in, c_p(addr(var)), c_f(anneal), c_p(addr(alpha_rm)), c_p(addr(gerr)),
-                                          c_p(addr(color_rm)), S_), "nu_neus_alpha_fwd")
-            s = self.shading_forward(a, pt_in, idx_in, P_in, color_rm, extra_dirs=du, extra_pts=spec_pts)
-            ctx.update(sdf=a, shade=s)
-            out['gradient_error'] = gerr
-            out['spec_raw'] = s['OLo'][3 * P_in:, :3]
-            out['occ_raw'] = s['IWo']
-            out['sdf_in'] = a['YX'][:, 0]
-            out['aux'] = s['aux']
-            out['normal_raw'] = a['n']
-        if two:
-            self._join()
+        fk = self.forked() if two else None
+        side = fk.__enter__() if two else None
+        try:
+            if two:
+                with torch.cuda.stream(side):
+                    ctx['nerf'] = self.nerf_forward(pt_out, idx_out, P_out, alpha_rm, color_rm)
+            elif P_out > 0:
+                ctx['nerf'] = self.nerf_forward(pt_out, idx_out, P_out, alpha_rm, color_rm)
+            self._render_forward_inner(ctx, out, o, d, P_in, pt_in, idx_in, alpha_rm, color_rm, anneal, spec_pts)
+        finally:
+            if two:
+                fk.__exit__(None, None, None)
         weights = e(R, S) if want_weights else None
         rgb, acc, rgb_bg, nrm_sum = e(R, 3), e(R), e(R, 3), e(R)
         L.check(lib.nu_composite_fwd(c_p(addr(alpha_rm)), c_p(addr(color_rm)), c_p(addr(inner_rm)), R, S,
@@ -1477,8 +1505,23 @@ class Stage1Engine:
                                      R, S, c_p(addr(d_rgb)), c_p(addr(d_acc)), c_p(addr(d_rgb_bg)), c_p(addr(d_nrm_sum)),
                                      c_p(addr(dalpha_rm)), c_p(addr(dcolor_rm)), S_), "nu_composite_bwd")
         two = ctx.get('two_streams', False)
+        fk = self.forked() if two else None
+        side = fk.__enter__() if two else None
+        try:
+            self._render_backward_inner(ctx, two, side, flat, dalpha_rm, dcolor_rm, d_gerr, d_spec_raw, d_occ_raw, d_sdf_in, train_inv_s,
+                                        d_nrm_sum, d_trans, d_metal)
+        finally:
+            if two:
+                fk.__exit__(None, None, None)
+        self.unpack_grads(flat)
+        return flat
+
+    def _render_backward_inner(self, ctx, two, side, flat, dalpha_rm, dcolor_rm, d_gerr, d_spec_raw, d_occ_raw, d_sdf_in, train_inv_s,
+                               d_nrm_sum, d_trans, d_metal):
+        lib, S_, e = self.lib, self.stream(), self.empty
+        R, S, P_in, P_out = ctx['R'], ctx['S'], ctx['P_in'], ctx['P_out']
         if two:
-            with torch.cuda.stream(self._fork()):
+            with torch.cuda.stream(side):
                 self.nerf_backward(ctx['nerf'], ctx['pt_out'], ctx['idx_out'], dalpha_rm, dcolor_rm, flat)
         elif P_out > 0:
             self.nerf_backward(ctx['nerf'], ctx['pt_out'], ctx['idx_out'], dalpha_rm, dcolor_rm, flat)
@@ -1505,19 +1548,21 @@ class Stage1Engine:
                                             d_spec_raw=d_spec_raw, d_occ_raw=d_occ_raw, d_mat_raw=d_mat)
             nbar = e(P_in, 3)
             var = self.p['deviation_network.variance']
+            ws = nb = 0
+            if train_inv_s:        # per-block partials of d variance: a slab of the reduction arena, summed with the weight gradients
+                if self._ctx.ndesc + 1 > self._rd_cap:
+                    self._forced_flush()
+                ws, nb = self._arena_take(lib.nu_neus_alpha_bwd_workspace_bytes(P_in))
             L.check(lib.nu_neus_alpha_bwd(c_p(addr(a['YX'])), 288, c_p(addr(a['n'])), c_p(addr(ctx['pt_in'])),
                                           c_p(addr(ctx['idx_in'])), P_in, c_p(addr(var)), c_f(ctx['anneal']),
                                           c_p(addr(dalpha_rm)), c_p(addr(d_gerr)),
                                           c_p(addr(dn)), c_p(addr(dcolor_rm) if d_nrm_sum is not None else 0), c_p(addr(dYX)), 288,
                                           c_p(addr(nbar)),
-                                          c_p(addr(flat, self.var_off) if train_inv_s else 0), S_), "nu_neus_alpha_bwd")
+                                          c_p(addr(flat, self.var_off) if train_inv_s else 0), c_p(ws), c_ll(nb), self._rd, self._ndesc_p,
+                                          self._rd_cap, S_), "nu_neus_alpha_bwd")
             if d_sdf_in is not None:
                 dYX[:, 0] += d_sdf_in
             self.sdf_backward(a, dYX, nbar, flat)
-        if two:
-            self._join()
-        self.unpack_grads(flat)
-        return flat
 
     # ------------------------------------------------------------------ occlusion probe (no grad)
     def occ_probe(self, pts, dirs, sn0=64, sn1=16):

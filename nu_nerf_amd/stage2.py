@@ -392,7 +392,7 @@ class Stage2Renderer(nn.Module):
             inv_s = inv_s.detach()
         if len(segs) > 1 and segs[1]['start'].shape[0] > 0 and N0 <= self._TWO_STREAM_RAYS and dev.type == 'cuda':
             main = torch.cuda.current_stream(dev)
-            side = n2.eng._fork()
+            side = n2.eng._fork(mark=False)      # (this engine's ops on the two streams are ordered by op_begin / op_end events)
             for t in [segs[1][k] for k in ('start', 'v', 'z', 'dirs')] + [inv_s]:
                 t.record_stream(side)
             with torch.cuda.stream(side):

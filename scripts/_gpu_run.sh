@@ -1,8 +1,9 @@
 set -e
-R=$GRAFT_REPO_ROOT
-cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/pc4 -- python3 $R/bench.py --real-capture --rays 8192 --mlp-dtype bf16 --steps 10 --warmup 4 --no-extra --no-cpu-baseline --no-kernel-timing > $R/gpurun_out/pc4.json 2> $R/gpurun_out/pc4.err
-cd $R
-python3 scripts/kstats.py gpurun_out/pc4 14 45 > gpurun_out/kstats_c4_tm64.txt
-rm -rf gpurun_out/pc4
-grep nt16b gpurun_out/kstats_c4_tm64.txt
+cd $GRAFT_REPO_ROOT
+python -m pytest tests -m gpu -x -q 2>&1 | tail -5
+NU_BENCH_DEVICE=0 NU_BENCH_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 20 --warmup 5 > gpurun_out/r4_rehearsal_n2.json 2> gpurun_out/r4_rehearsal_n2.err || (tail -20 gpurun_out/r4_rehearsal_n2.err; exit 1)
+python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/r4_rehearsal_n2.json').read().strip().split('\n')[-1])
+print('N=2 rehearsal', d['n_gpus'], d['ms_per_step'], d['value'], d['config'].get('grad_all_reduce'), d['config'].get('loss_assembly'))
+PY

@@ -2,7 +2,7 @@
 SQ_ACTIVE_INST_ANY; collected with --kernel-trace) for the two GEMM kernels: effective shader clock under the kernel
 (GRBM_GUI_ACTIVE / 8 XCDs / duration, MI355X_MICROARCH.md 'DVFS give-back'), matrix-pipe busy fraction at that clock
 (MFMA busy cycles / (1024 SIMDs x cycles)), and where the waves' cycles go."""
-import collections, csv, json, sys
+import re, collections, csv, json, sys
 
 cc_csv, kt_csv, out_json = sys.argv[1:4]
 dur = {}
@@ -12,7 +12,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(float))
 seen = collections.defaultdict(set)
 for r in csv.DictReader(open(cc_csv)):
     name = r['Kernel_Name']
-    k = 'gemm_nt_kernel' if ('gemm_nt_kernel' in name or 'gemm_nt2_kernel' in name) else ('gemm_tn_kernel' if ('gemm_tn_kernel' in name or 'gemm_tn256_kernel' in name or 'gemm_tn2_kernel' in name) else None)
+    k = 'gemm_nt_kernel' if re.search(r'gemm_nt(2b?)?_kernel', name) else ('gemm_tn_kernel' if re.search(r'gemm_tn(2b?|b|256)?_kernel', name) else None)
     if not k:
         continue
     acc[k][r['Counter_Name']] += float(r['Counter_Value'])

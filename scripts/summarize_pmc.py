@@ -1,7 +1,7 @@
 """Summarise rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE collected in separate runs, as MI355X_MICROARCH.md's HBM
 section prescribes) into HBM bytes per launch for the GEMM kernels.  gfx950 correction: FETCH_SIZE counts 128-B
 requests as 64 B for wide coalesced streams -> doubled; units are KiB."""
-import collections, csv, json, sys
+import collections, csv, json, re, sys
 
 def agg(path, name):
     out = collections.defaultdict(lambda: [0, 0.0])
@@ -9,8 +9,10 @@ def agg(path, name):
         if r['Counter_Name'] != name:
             continue
         kn = r['Kernel_Name']
-        k = 'gemm_nt_kernel' if ('gemm_nt_kernel' in kn or 'gemm_nt2_kernel' in kn or 'gemm_nt16' in kn) else ('gemm_tn_kernel' if ('gemm_tn_kernel' in kn or 'gemm_tn256_kernel' in kn or 'gemm_tn2_kernel' in kn or 'gemm_tn16' in kn) else
-             ('calib_read4' if 'calib_read4' in kn else ('calib_read16' if 'calib_read16' in kn else None)))
+        # every NT launch (single problem, batched, bf16 storage) / every weight-gradient launch (single, batched, both tile sizes)
+        k = ('gemm_nt_kernel' if re.search(r'gemm_nt(2b?|16b?)?_kernel', kn) else
+             'gemm_tn_kernel' if re.search(r'gemm_tn(2b?|b|16|16x256|256)?_kernel', kn) else
+             'calib_read4' if 'calib_read4' in kn else 'calib_read16' if 'calib_read16' in kn else None)
         if k:
             out[k][0] += 1
             out[k][1] += float(r['Counter_Value'])
@@ -27,6 +29,9 @@ if bench_json:
     res['workload_record'] = {"rays": c['rays_per_gpu'], "real_capture": 'real-capture' in c['workload'], "mlp_dtype": {'f32': 'fp32', 'bf16': 'bf16'}.get(b['dtype'], b['dtype']),
                               "bf16_storage": b['dtype'] == 'bf16', "mean_inner_points": c['mean_inner_points'],
                               "mean_outer_points": c['mean_outer_points'], "steps": b['steps'], "warmup": b['warmup']}
+for k in ('gemm_nt_kernel', 'gemm_tn_kernel'):          # launches per step: a later run must have the same launch structure to quote these per-launch bytes
+    if bench_json and k in f:
+        res['workload_record'][k.replace('gemm_', '').replace('_kernel', '') + '_launches_per_step'] = f[k][0] / float(b['steps'] + b['warmup'])
 for k in f:
     n = f[k][0]
     res[k] = {"launches": n, "fetch_bytes_per_launch": 2.0 * 1024 * f[k][1] / n, "write_bytes_per_launch": 1024 * w[k][1] / max(w[k][0], 1),

@@ -296,6 +296,11 @@ class _FixedWeightReducer:
     def point_weight(self, n_local, device):
         return torch.full((1,), 1.4, device=device)
 
+    def count_weights(self, counts, device):          # (inner points, occlusion-loss points, candidate rays): only the first is uneven here
+        w = torch.ones(len(counts), device=device)
+        w[0] = 1.4
+        return w
+
 
 def test_fused_loss_with_the_data_parallel_point_weight(gpu):
     """under data parallelism the eikonal mean is this rank's share of the mean over all ranks' inner points.  The
