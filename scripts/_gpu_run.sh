@@ -1,9 +1,11 @@
-set -e
 cd $GRAFT_REPO_ROOT
-python -m pytest tests -m gpu -x -q 2>&1 | tail -5
-NU_BENCH_DEVICE=0 NU_BENCH_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 20 --warmup 5 > gpurun_out/r4_rehearsal_n2.json 2> gpurun_out/r4_rehearsal_n2.err || (tail -20 gpurun_out/r4_rehearsal_n2.err; exit 1)
-python - <<'PY'
-import json
-d=json.loads(open('gpurun_out/r4_rehearsal_n2.json').read().strip().split('\n')[-1])
-print('N=2 rehearsal', d['n_gpus'], d['ms_per_step'], d['value'], d['config'].get('grad_all_reduce'), d['config'].get('loss_assembly'))
-PY
+STEPS=10 WARMUP=4 bash scripts/collect_profiles.sh r04_c4 --real-capture --rays 8192 --mlp-dtype bf16 2>&1 | tail -6
+STEPS=30 WARMUP=6 bash scripts/collect_profiles.sh r04_512 --rays 512 2>&1 | tail -6
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/pthick -- python3 $R/bench.py --workload stage2 --thick --rays 1024 --steps 20 --warmup 5 --no-extra --no-cpu-baseline --no-kernel-timing > $R/gpurun_out/pthick.json 2> $R/gpurun_out/pthick.err
+cd $R
+python3 scripts/kstats.py gpurun_out/pthick 25 60 > gpurun_out/kstats_thick_b.txt
+rm -rf gpurun_out/pthick
+python scripts/launch_census.py thick 1024 > gpurun_out/census_thick_1024_r4b.txt 2>&1 || true
+grep -n "torch-launched\|^\[" gpurun_out/census_thick_1024_r4b.txt | head
