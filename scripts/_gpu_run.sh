@@ -1,11 +1,12 @@
 cd $GRAFT_REPO_ROOT
-STEPS=10 WARMUP=4 bash scripts/collect_profiles.sh r04_c4 --real-capture --rays 8192 --mlp-dtype bf16 2>&1 | tail -6
-STEPS=30 WARMUP=6 bash scripts/collect_profiles.sh r04_512 --rays 512 2>&1 | tail -6
-cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/pthick -- python3 $R/bench.py --workload stage2 --thick --rays 1024 --steps 20 --warmup 5 --no-extra --no-cpu-baseline --no-kernel-timing > $R/gpurun_out/pthick.json 2> $R/gpurun_out/pthick.err
-cd $R
-python3 scripts/kstats.py gpurun_out/pthick 25 60 > gpurun_out/kstats_thick_b.txt
-rm -rf gpurun_out/pthick
-python scripts/launch_census.py thick 1024 > gpurun_out/census_thick_1024_r4b.txt 2>&1 || true
-grep -n "torch-launched\|^\[" gpurun_out/census_thick_1024_r4b.txt | head
+python -m pytest tests/test_gemm_gpu.py tests/test_nets_gpu.py -m gpu -x -q 2>&1 | tail -3
+for i in 1 2; do
+for x in 0 1; do
+NU_TN_XCD=$x python bench.py --steps 20 --warmup 5 --no-extra --no-cpu-baseline > gpurun_out/xcd_${x}_$i.json 2> gpurun_out/xcd_${x}_$i.err
+python - <<EOF
+import json
+d=json.loads(open('gpurun_out/xcd_${x}_$i.json').read().strip().splitlines()[-1])
+print('xcd',$x,d['ms_per_step'],d['roofline']['wgrad']['achieved'],d['roofline']['wgrad']['avg_launch_us'],d['roofline']['wgrad']['launches'])
+EOF
+done
+done
