@@ -49,6 +49,7 @@ enum NuEpi {                   /* epilogue applied to v = alpha * (A . B^T)[row,
 
 #define NU_GEMM_B16 8
 #define NU_GEMM_A16 16
+#define NU_GEMM_PRESPLIT_ALWAYS 4   /* mode 2 with B6: take the pre-split kernel whatever the tile count (tests; the library otherwise picks) */
 #define NU_GEMM_C16 32
 #define NU_GEMM_X16 64
 typedef struct NuGemmNT {      /* C[M,N] = epi(A[M,K] . B[N,K]^T);  K % 32 == 0, lda/ldb % 4 == 0, A/B 16-byte aligned */
@@ -80,6 +81,15 @@ typedef struct NuGemmNT {      /* C[M,N] = epi(A[M,K] . B[N,K]^T);  K % 32 == 0,
     unsigned long long* mask; int mask_nct;
     int mask_ct0;              /* first column tile of this problem in the sign-bit matrix: a problem that is one column group of a
                                   wider activation matrix (the four material predictors side by side) when it is launched on its own */
+    const void* B6;            /* mode 2 only, optional: B already split into its three bf16 planes by the pack launch (NuPackDesc.planes = 3).
+                                  Layout: the table [rows][ldb] (ldb % 16 == 0, rows padded to a multiple of 256) is cut into blocks of 256
+                                  rows; a block stores its 16-wide k-groups one after the other, each as [256 rows][hi x16 | mid x16 | lo x16]
+                                  (24 576 contiguous bytes -- one LDS stage of the kernel).  bf16 index of element (n, k) of plane p:
+                                  ((n >> 8) * (ldb >> 4) + (k >> 4)) * 12288 + (n & 255) * 48 + 16 p + ((k & 15) ^ (n & 8))   [the two halves of a
+                                  16-group are swapped in rows with bit 3 set: LDS bank spreading of the kernel's fragment reads].  B6 points at the block the
+                                  problem's first row opens (its row offset in the table must be a multiple of 256 -- then 3 x the fp32
+                                  table's element offset, and sB applies with the same factor 3).
+                                  Selects gemm_nt6_kernel (csrc/gemm_nt6.hip): same results as without it, bit for bit */
 } NuGemmNT;
 
 typedef struct NuGemmTN {      /* dW[N1,N2] = A0^T B0 (+ A1^T B1), reduced over P rows in S deterministic splits */
@@ -148,6 +158,11 @@ typedef struct NuPackDesc {
     float scale;
     int N, K, Kp, ldT, ldd, row_begin, col_off;
     void* Wp16; void* WpT16;                  /* optional bf16 copies of Wp / WpT (same shapes, same leading dimensions) */
+    int planes, pad_;                         /* 1 (or 0): the copies are Wp / WpT rounded to bf16.  3: the exact hi / mid / lo split in the
+                                                 layout of NuGemmNT.B6 (the bf16x6 mode's weight tables): Wp16 / WpT16 then point at the START of
+                                                 the twin of the whole table, and the layer's place in it is given below */
+    int w6_row0, w6_ld, t6_row0, t6_col0, t6_ld, pad2_;   /* planes == 3: first row (and leading dimension) of this layer in the Wp table;
+                                                 first row / first column / leading dimension in the WpT table */
 } NuPackDesc;
 int nu_pack_desc_size(void);
 int nu_pack_layers(const void* descs_dev, int ndesc, int total_rows, hipStream_t stream);

@@ -448,6 +448,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt2b_kernel(NuGemmNTBatch b) {
 }
 
 int nu_gemm_nt16_launch(const NuGemmNT& g, int groups, long long nslots, hipStream_t stream);      // gemm_nt16.hip
+int nu_gemm_nt6_launch(const NuGemmNT& g, int groups, hipStream_t stream);                          // gemm_nt6.hip
 
 // argument checks every NT launch path shares
 static int nt_check(const NuGemmNT& g) {
@@ -466,7 +467,9 @@ static int nt_check(const NuGemmNT& g) {
         if (g.act_cols > 0 && (g.act_cols & 63)) return NU_ERR_ARG;
     }
     const int prec = g.bf16 & 3;
-    if (prec == 3 || ((g.bf16 & ~3) && !(prec == 1 && (g.bf16 & NU_GEMM_B16)))) return NU_ERR_ARG;   // storage flags need the bf16-storage kernel
+    if (prec == 3) return NU_ERR_ARG;
+    if ((g.bf16 & ~3) && !(prec == 1 && (g.bf16 & NU_GEMM_B16)) && !(prec == 2 && (g.bf16 & ~3) == NU_GEMM_PRESPLIT_ALWAYS && g.B6))
+        return NU_ERR_ARG;                                                                  // storage flags need the bf16-storage kernel
     return NU_OK;
 }
 
@@ -496,6 +499,12 @@ int nu_gemm_nt_launch(const NuGemmNT& g, hipStream_t stream) {
     dim3 grid((unsigned)per, 1, groups), block(256);
     static const bool v1 = getenv("NU_NT_V1") && atoi(getenv("NU_NT_V1")) != 0;   // development switch: first-generation fp32 kernel
     if (prec == 1 && (g.bf16 & NU_GEMM_B16)) return nu_gemm_nt16_launch(g, groups, nslots, stream);      // bf16 storage
+    // pre-split weight planes: gemm_nt6_kernel's 128 x 256 tiles, when they still fill the chip (both kernels give the same bits;
+    // measured, scripts/bench_nt6.py: 65 536 rows x 256 columns = 512 tiles 145 vs 128 TFLOP/s, 16 384 rows = 128 tiles 65 vs 95)
+    static const int nt6_env = getenv("NU_NT6") ? atoi(getenv("NU_NT6")) : -1;          // development switch: 0 never, 1 always
+    if (prec == 2 && g.B6 && nt6_env != 0 &&
+        (nt6_env == 1 || (g.bf16 & NU_GEMM_PRESPLIT_ALWAYS) || (long long)nu_cdiv(g.M, TBM) * nu_cdiv(g.N, 256) * groups >= 320))
+        return nu_gemm_nt6_launch(g, groups, stream);
     if (prec == 0 && !v1) {
         const long long t128 = (long long)nu_cdiv(g.M, TBM) * ntn * groups, t64 = (long long)nu_cdiv(g.M, 64) * ntn * groups;
         const bool small = nt_small_tiles(t128, t64);

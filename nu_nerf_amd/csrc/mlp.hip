@@ -38,8 +38,28 @@ __global__ __launch_bounds__(64) void pack_kernel(const NuPackDesc* __restrict__
         const float w = v[k] * s;
         d.Wp[(long long)n * d.Kp + kp] = w;
         if (d.WpT) d.WpT[(long long)kp * d.ldT + n] = w;
-        if (d.Wp16) reinterpret_cast<__bf16*>(d.Wp16)[(long long)n * d.Kp + kp] = (__bf16)w;
-        if (d.WpT16) reinterpret_cast<__bf16*>(d.WpT16)[(long long)kp * d.ldT + n] = (__bf16)w;
+        if (d.planes == 3) {
+            // exact three-way split (nu_split3's arithmetic), layout of NuGemmNT.B6
+#pragma clang fp contract(off)
+            const __bf16 h1 = (__bf16)w;
+            const float r1 = w - (float)h1;
+            const __bf16 h2 = (__bf16)r1;
+            const __bf16 h3 = (__bf16)(r1 - (float)h2);
+            auto at = [](void* tbl, int row, int col, int ld) -> __bf16* {
+                return reinterpret_cast<__bf16*>(tbl) + ((long long)(row >> 8) * (ld >> 4) + (col >> 4)) * 12288 + (row & 255) * 48 + ((col & 15) ^ (row & 8));
+            };
+            if (d.Wp16) {
+                __bf16* q = at(d.Wp16, d.w6_row0 + n, kp, d.w6_ld);
+                q[0] = h1; q[16] = h2; q[32] = h3;
+            }
+            if (d.WpT16) {
+                __bf16* q = at(d.WpT16, d.t6_row0 + kp, d.t6_col0 + n, d.t6_ld);
+                q[0] = h1; q[16] = h2; q[32] = h3;
+            }
+        } else {
+            if (d.Wp16) reinterpret_cast<__bf16*>(d.Wp16)[(long long)n * d.Kp + kp] = (__bf16)w;
+            if (d.WpT16) reinterpret_cast<__bf16*>(d.WpT16)[(long long)kp * d.ldT + n] = (__bf16)w;
+        }
     }
     if (lane == 0 && d.bias_p) d.bias_p[n] = d.bias[n];
 }

@@ -43,7 +43,12 @@ static inline int ctx_take(NuOpCtx* c, long long nbytes, int ndesc_needed, hipSt
 #define C16 NU_GEMM_C16
 #define X16 NU_GEMM_X16
 typedef unsigned short h16_t;
-static inline const float* w16(const void* tbl, long long elem_off) { return reinterpret_cast<const float*>(static_cast<const h16_t*>(tbl) + elem_off); }
+// address of element `elem_off` of a 16-bit weight table: the bf16 copy (NuOpCtx.h16), or -- arithmetic mode 2 -- the pre-split planes,
+// whose layout keeps the fp32 table's offsets with a factor 3 for row offsets that are multiples of 256 (NuGemmNT.B6)
+static inline const float* w16(const NuOpCtx* c, const void* tbl, long long elem_off) {
+    if (tbl == nullptr) return nullptr;
+    return reinterpret_cast<const float*>(static_cast<const h16_t*>(tbl) + (c->prec == 2 ? 3 : 1) * elem_off);
+}
 
 static inline void ev_begin(NuOpCtx* c, hipStream_t stream) { nu_ctx_ev_begin(c, stream); }
 static inline void ev_end(NuOpCtx* c, hipStream_t stream, double kind, double flops, double bytes) { nu_ctx_ev_end(c, stream, kind, flops, bytes); }
@@ -53,7 +58,7 @@ struct NtArgs {
     float* C2 = nullptr; int ldc2 = 0; const float* bias = nullptr; const float* H = nullptr; int ldh = 0; const float* D = nullptr;
     int ldd = 0; const float* Cadd = nullptr; int ldadd = 0; int zero_to = 0; int act_cols = 0; int groups = 1;
     long long sA = 0, sB = 0, sC = 0, sBias = 0, sH = 0; unsigned long long* mask = nullptr; int mask_nct = 0;
-    const float* B16 = nullptr;     // the bf16 copy of B (h16)
+    const float* B16 = nullptr;     // the bf16 copy of B (h16), or its pre-split planes (mode 2; optional there)
     int st = 0;                     // A16 | C16 | X16 (h16)
     int ktrue = 0;                  // unpadded reduction extent (roofline accounting only)
 };
@@ -66,6 +71,7 @@ static int nt_fill(const NuOpCtx* c, const NtArgs& a, NuGemmNT& g) {
     g.zero_to = a.zero_to; g.act_cols = a.act_cols; g.alpha = 1.0f; g.groups = a.groups; g.sA = a.sA; g.sB = a.sB; g.sC = a.sC;
     g.sBias = a.sBias; g.sH = a.sH; g.epi = a.epi; g.bf16 = h16 ? (1 | NU_GEMM_B16 | a.st) : c->prec; g.mask = a.mask;
     g.mask_nct = a.mask ? a.mask_nct : 0;
+    if (c->prec == 2 && !h16) g.B6 = a.B16;
     return NU_OK;
 }
 // algorithmic FLOPs and bytes of one launch at the widths its matrices are stored in (roofline accounting)
@@ -167,7 +173,7 @@ extern "C" int nu_sdf_mlp_fwd(NuOpCtx* c, const NuSdfNet* net, const float* X, i
         NtArgs g = {src, lds, L.Wp, L.Kp, P, L.N, K, a->H[l + 1], 256, NU_EPI_BIAS_SOFTPLUS};
         g.bias = L.bias; g.zero_to = L.N; g.ktrue = L.K;
         // the no-gradient form (sampler chain, want_feat == 0) also keeps H[8] in bf16: only the sdf head reads it
-        g.B16 = w16(L.Wp16, 0); g.st = (sdfH16(l) ? A16 : 0) | ((sdfH16(l + 1) || (l == 7 && !want_feat)) ? C16 : 0);
+        g.B16 = w16(c, L.Wp16, 0); g.st = (sdfH16(l) ? A16 : 0) | ((sdfH16(l + 1) || (l == 7 && !want_feat)) ? C16 : 0);
         CHK(nt(c, g, stream));
         src = a->H[l + 1]; lds = 256; K = 256;
     }
@@ -175,7 +181,7 @@ extern "C" int nu_sdf_mlp_fwd(NuOpCtx* c, const NuSdfNet* net, const float* X, i
     if (want_feat) {     // row 0 = sdf (skinny), rows 1..256 = feature
         CHK(nu_skinny_fwd(a->H[8], 256, P, 256, L8.Wp, 256, L8.bias, 1, a->YX, 288, stream));
         NtArgs g = {a->H[8], 256, L8.Wp + 256, 256, P, 256, 256, a->YX + 1, 288, NU_EPI_BIAS_NONE};
-        g.bias = L8.bias + 1; g.B16 = w16(L8.Wp16, 256);
+        g.bias = L8.bias + 1; g.B16 = c->prec == 2 ? nullptr : w16(c, L8.Wp16, 256);     // (row 1: not a block boundary of the pre-split planes)
         CHK(nt(c, g, stream));
     } else {
         CHK(skinny_fwd(c, a->H[8], 256, P, 256, L8.Wp, 256, L8.bias, 1, a->sdf, 1, stream, true));
@@ -195,11 +201,11 @@ extern "C" int nu_sdf_mlp_normal(NuOpCtx* c, const NuSdfNet* net, NuSdfBufs* a, 
         g.H = a->H[l]; g.ldh = 256;
         if (l == 4) g.act_cols = 217;      // columns 217..255 are the skip gradient w.r.t. the embedding: written plain
         else g.zero_to = 256;
-        g.B16 = w16(ls[l].WpT16, 0); g.st = (sdfD16(l) ? A16 : 0) | (sdfD16(l - 1) ? C16 : 0) | (sdfH16(l) ? X16 : 0);
+        g.B16 = w16(c, ls[l].WpT16, 0); g.st = (sdfD16(l) ? A16 : 0) | (sdfD16(l - 1) ? C16 : 0) | (sdfH16(l) ? X16 : 0);
         CHK(nt(c, g, stream));
     }
     NtArgs g0 = {a->D[0], 256, ls[0].WpT, ls[0].ldT, P, 39, 256, a->G0, 64, NU_EPI_PLAIN};
-    g0.zero_to = 64; g0.B16 = w16(ls[0].WpT16, 0); g0.st = A16;
+    g0.zero_to = 64; g0.B16 = w16(c, ls[0].WpT16, 0); g0.st = A16;
     CHK(nt(c, g0, stream));
     return nu_embed_jt(a->E, a->G0, 64, a->D[3] + 217, 256, P, a->n, stream);
 }
@@ -219,7 +225,7 @@ extern "C" int nu_sdf_mlp_bwd(NuOpCtx* c, const NuSdfNet* net, NuSdfBufs* a, con
             NtArgs g = {src, lds, ls[l].Wp, ls[l].Kp, P, ls[l].N, K, a->Q[l + 1], 256, NU_EPI_Q_SP};
             g.C2 = a->C[l]; g.ldc2 = 256; g.H = a->H[l + 1]; g.ldh = 256; g.D = a->D[l]; g.ldd = 256; g.zero_to = l == 3 ? ls[l].N : 256;
             // Q[l + 1] and C[l] share the output flag, H[l + 1] and D[l] the auxiliary flag: the rule makes each pair one dtype
-            g.B16 = w16(ls[l].Wp16, 0); g.st = (sdfH16(l) ? A16 : 0) | (sdfH16(l + 1) ? C16 | X16 : 0);
+            g.B16 = w16(c, ls[l].Wp16, 0); g.st = (sdfH16(l) ? A16 : 0) | (sdfH16(l + 1) ? C16 | X16 : 0);
             CHK(nt(c, g, stream));
             src = a->Q[l + 1]; lds = 256; K = 256;
         }
@@ -228,8 +234,8 @@ extern "C" int nu_sdf_mlp_bwd(NuOpCtx* c, const NuSdfNet* net, NuSdfBufs* a, con
     float* A[8];
     for (int l = 7; l >= 0; --l) {
         const float* srcA; int lda, K; const float* WT; const float* WT16; int ldT;
-        if (l == 7) { srcA = dYX; lda = 288; K = 288; WT = ls[8].WpT; WT16 = w16(ls[8].WpT16, 0); ldT = ls[8].ldT; }
-        else { srcA = A[l + 1]; lda = 256; K = rup_i(ls[l + 1].N, 32); WT = ls[l + 1].WpT; WT16 = w16(ls[l + 1].WpT16, 0); ldT = ls[l + 1].ldT; }
+        if (l == 7) { srcA = dYX; lda = 288; K = 288; WT = ls[8].WpT; WT16 = w16(c, ls[8].WpT16, 0); ldT = ls[8].ldT; }
+        else { srcA = A[l + 1]; lda = 256; K = rup_i(ls[l + 1].N, 32); WT = ls[l + 1].WpT; WT16 = w16(c, ls[l + 1].WpT16, 0); ldT = ls[l + 1].ldT; }
         A[l] = second ? a->C[l] : a->Aux[l];
         NtArgs g = {srcA, lda, WT, ldT, P, ls[l].N, K, A[l], 256, second ? NU_EPI_B_SP : NU_EPI_MUL_DSP};
         g.H = a->H[l + 1]; g.ldh = 256; g.Cadd = second ? a->C[l] : nullptr; g.ldadd = 256;
@@ -255,7 +261,7 @@ extern "C" int nu_sdf_mlp_bwd(NuOpCtx* c, const NuSdfNet* net, NuSdfBufs* a, con
     }
     if (dx != nullptr) {
         NtArgs g = {A[0], 256, ls[0].WpT, ls[0].ldT, P, 39, 256, a->dE0, 64, NU_EPI_PLAIN};
-        g.zero_to = 64; g.B16 = w16(ls[0].WpT16, 0); g.st = A16;
+        g.zero_to = 64; g.B16 = w16(c, ls[0].WpT16, 0); g.st = A16;
         CHK(nt(c, g, stream));
         CHK(nu_embed_jt2(a->E, a->dE0, 64, A[3] + 217, 256, second ? a->G0 : nullptr, 64, second ? a->D[3] + 217 : nullptr, 256,
                          second ? nbar : nullptr, P, dx, 0, stream));
@@ -284,7 +290,7 @@ static int relu_stacks_fwd(NuOpCtx* c, const Stack* st, int n, int nct, hipStrea
             g[k] = NtArgs{j == 0 ? st[k].X : st[k].Hs[j - 1], j == 0 ? st[k].ldx : 256, ls[j].Wp, ls[j].Kp, st[k].rows, 256, ls[j].Kp, st[k].Hs[j], 256,
                           NU_EPI_BIAS_RELU};
             g[k].bias = ls[j].bias; g[k].mask = st[k].masks[j]; g[k].mask_nct = nct;
-            g[k].B16 = w16(ls[j].Wp16, 0); g[k].st = (j > 0 ? A16 : 0) | C16;
+            g[k].B16 = w16(c, ls[j].Wp16, 0); g[k].st = (j > 0 ? A16 : 0) | C16;
         }
         CHK(nt_batch(c, g, n, stream));
     }
@@ -308,11 +314,11 @@ static int relu_stacks_bwd(NuOpCtx* c, const Stack* st, int n, int nct, hipStrea
             if (j > 0) {
                 g[m] = NtArgs{dA, 256, ls[j].WpT, ls[j].ldT, s.rows, 256, 256, s.tmp[j - 1], 256, NU_EPI_MUL_DRELU};
                 g[m].H = s.Hs[j - 1]; g[m].ldh = 256; g[m].mask = s.masks[j - 1]; g[m].mask_nct = nct;
-                g[m].B16 = w16(ls[j].WpT16, 0); g[m].st = A16 | C16 | X16;
+                g[m].B16 = w16(c, ls[j].WpT16, 0); g[m].st = A16 | C16 | X16;
                 ++m;
             } else if (s.dX != nullptr) {
                 g[m] = NtArgs{dA, 256, ls[j].WpT, ls[j].ldT, s.rows, s.dxc, 256, s.dX, s.lddx, NU_EPI_PLAIN};
-                g[m].B16 = w16(ls[j].WpT16, 0); g[m].st = A16;
+                g[m].B16 = w16(c, ls[j].WpT16, 0); g[m].st = A16;
                 ++m;
             }
         }
@@ -342,16 +348,16 @@ extern "C" int nu_nerfpp_mlp_fwd(NuOpCtx* c, const NuNerfNet* net, const float* 
         const int ldc = i == 4 ? 352 : 256;
         NtArgs g = {src, lds, L.Wp, L.Kp, P, 256, L.Kp, b->H[i + 1], ldc, NU_EPI_BIAS_RELU};
         g.bias = L.bias; g.mask = b->mask[i + 1]; g.mask_nct = 2;
-        g.B16 = w16(L.Wp16, 0); g.st = (nerfH16(i) ? A16 : 0) | (nerfH16(i + 1) ? C16 : 0);
+        g.B16 = w16(c, L.Wp16, 0); g.st = (nerfH16(i) ? A16 : 0) | (nerfH16(i + 1) ? C16 : 0);
         CHK(nt(c, g, stream));
         src = b->H[i + 1]; lds = ldc;
     }
     CHK(skinny_fwd(c, b->H[8], 256, P, 256, net->alpha.Wp, 256, net->alpha.bias, 1, b->sig, 1, stream, true));
     NtArgs gf = {b->H[8], 256, net->feat.Wp, 256, P, 256, 256, b->V, 288, NU_EPI_BIAS_NONE};
-    gf.bias = net->feat.bias; gf.B16 = w16(net->feat.Wp16, 0); gf.st = A16;
+    gf.bias = net->feat.bias; gf.B16 = w16(c, net->feat.Wp16, 0); gf.st = A16;
     CHK(nt(c, gf, stream));
     NtArgs gv = {b->V, 288, net->view.Wp, 288, P, 128, 288, b->HV, 128, NU_EPI_BIAS_RELU};
-    gv.bias = net->view.bias; gv.B16 = w16(net->view.Wp16, 0);
+    gv.bias = net->view.bias; gv.B16 = w16(c, net->view.Wp16, 0);
     CHK(nt(c, gv, stream));
     return nu_skinny_fwd(b->HV, 128, P, 128, net->rgb.Wp, 128, net->rgb.bias, 3, b->rgb, 4, stream);
 }
@@ -366,14 +372,14 @@ extern "C" int nu_nerfpp_mlp_bwd(NuOpCtx* c, const NuNerfNet* net, const float* 
     CHK(skinny_bwd(c, drgb, 4, b->HV, 128, P, 128, net->rgb.Wp, 128, 3, b->dHV, 128, 1, net->rgb.dWp, 128, c->flat + net->rgb.db_off, stream));
     CHK(wgrad(c, b->dHV, 128, b->V, 288, P, 128, 288, net->view.dWp, 288, c->flat + net->view.db_off, stream));
     NtArgs gF = {b->dHV, 128, net->view.WpT, net->view.ldT, P, ldf, 128, b->dF, ldf, NU_EPI_PLAIN};
-    gF.B16 = w16(net->view.WpT16, 0);
+    gF.B16 = w16(c, net->view.WpT16, 0);
     CHK(nt(c, gF, stream));
     CHK(wgrad(c, b->dF, ldf, b->H[8], 256, P, 256, 256, net->feat.dWp, 256, c->flat + net->feat.db_off, stream, NU_TN_B0_16));
     CHK(skinny_bwd(c, dsig, 1, b->H[8], 256, P, 256, net->alpha.Wp, 256, 1, b->dH8a, 256, 1, net->alpha.dWp, 256, c->flat + net->alpha.db_off, stream,
                    true));
     NtArgs g8 = {b->dF, ldf, net->feat.WpT, net->feat.ldT, P, 256, 256, b->dA[8], 256, NU_EPI_B_RELU};
     g8.H = b->H[8]; g8.ldh = 256; g8.Cadd = b->dH8a; g8.ldadd = 256; g8.mask = b->mask[8]; g8.mask_nct = 2;
-    g8.B16 = w16(net->feat.WpT16, 0); g8.st = C16 | X16;          // H[8] and dH8a are bf16
+    g8.B16 = w16(c, net->feat.WpT16, 0); g8.st = C16 | X16;          // H[8] and dH8a are bf16
     CHK(nt(c, g8, stream));
     const float* dA = b->dA[8];
     int lda = 256;
@@ -389,21 +395,21 @@ extern "C" int nu_nerfpp_mlp_bwd(NuOpCtx* c, const NuNerfNet* net, const float* 
             if (i == 5 && want_in) {       // columns 256..339 of the layer-5 input: the re-concatenated embedding, plain gradient
                 NtArgs g = {dA, lda, L.WpT, L.ldT, P, 340, 256, b->dA[i], 352, NU_EPI_MUL_DRELU};
                 g.H = b->H[i]; g.ldh = ldu; g.act_cols = 256; g.zero_to = 352; g.mask = b->mask[i]; g.mask_nct = 2;
-                g.B16 = w16(L.WpT16, 0); g.st = st;
+                g.B16 = w16(c, L.WpT16, 0); g.st = st;
                 CHK(nt(c, g, stream));
                 dskip = b->dA[i];
                 dA = b->dA[i]; lda = 352;
             } else {
                 NtArgs g = {dA, lda, L.WpT, L.ldT, P, 256, 256, b->dA[i], 256, NU_EPI_MUL_DRELU};
                 g.H = b->H[i]; g.ldh = ldu; g.mask = b->mask[i]; g.mask_nct = 2;
-                g.B16 = w16(L.WpT16, 0); g.st = st;
+                g.B16 = w16(c, L.WpT16, 0); g.st = st;
                 CHK(nt(c, g, stream));
                 dA = b->dA[i]; lda = 256;
             }
             dA_i = i;
         } else if (want_in) {
             NtArgs g = {dA, lda, L.WpT, L.ldT, P, 84, 256, b->dE4, 96, NU_EPI_PLAIN};
-            g.zero_to = 96; g.B16 = w16(L.WpT16, 0); g.st = nerfdA16(dA_i) ? A16 : 0;
+            g.zero_to = 96; g.B16 = w16(c, L.WpT16, 0); g.st = nerfdA16(dA_i) ? A16 : 0;
             CHK(nt(c, g, stream));
             CHK(nu_nerf_embed_bwd(pt, pt_ld, b->H[0], b->V, b->dE4, 96, dskip + 256, 352, b->dF + 256, ldf, P, b->dx, b->ddir, stream));
         }
@@ -425,12 +431,12 @@ extern "C" int nu_shading_stack_fwd(NuOpCtx* c, const NuShadeNet* net, NuShadeBu
     const int rows_ol = 3 * P + R;
     // materials: layer 0 batched (N = 1024), layers 1-2 grouped x4, block-diagonal 6-wide head
     NtArgs m0 = {YX, 288, net->WpM0, 288, P, 1024, 288, s->M[0], 1024, NU_EPI_BIAS_RELU};
-    m0.bias = net->bM0; m0.mask = s->maskM[0]; m0.mask_nct = 8; m0.B16 = w16(net->WpM0_16, 0); m0.st = C16;
+    m0.bias = net->bM0; m0.mask = s->maskM[0]; m0.mask_nct = 8; m0.B16 = w16(c, net->WpM0_16, 0); m0.st = C16;
     CHK(nt(c, m0, stream));
     for (int j = 1; j <= 2; ++j) {
         NtArgs g = {s->M[j - 1], 1024, net->WpM[j], 256, P, 256, 256, s->M[j], 1024, NU_EPI_BIAS_RELU};
         g.bias = net->bM[j]; g.groups = 4; g.sA = 256; g.sB = 65536; g.sC = 256; g.sBias = 256; g.mask = s->maskM[j]; g.mask_nct = 8;
-        g.B16 = w16(net->WpM16[j], 0); g.st = A16 | C16;
+        g.B16 = w16(c, net->WpM16[j], 0); g.st = A16 | C16;
         CHK(nt(c, g, stream));
     }
     CHK(skinny_fwd(c, s->M[2], 1024, P, 1024, net->Ws6, 1024, net->b6, 6, s->Mraw, 8, stream, true));
@@ -483,13 +489,13 @@ extern "C" int nu_shading_stack_bwd(NuOpCtx* c, const NuShadeNet* net, NuShadeBu
                   (a16 ? NU_TN_A0_16 : 0) | NU_TN_B0_16, nullptr, 0, nullptr, 0, 4, 256, 256, 65536, 256));
         NtArgs g = {dA, 1024, net->WpTM[j], 256, P, 256, 256, s->dM[j - 1], 1024, NU_EPI_MUL_DRELU};
         g.H = s->M[j - 1]; g.ldh = 1024; g.groups = 4; g.sA = 256; g.sB = 65536; g.sC = 256; g.sH = 256; g.mask = s->maskM[j - 1]; g.mask_nct = 8;
-        g.B16 = w16(net->WpTM16[j], 0); g.st = (a16 ? A16 : 0) | C16 | X16;
+        g.B16 = w16(c, net->WpTM16[j], 0); g.st = (a16 ? A16 : 0) | C16 | X16;
         CHK(nt(c, g, stream));
         dA = s->dM[j - 1];
     }
     CHK(wgrad(c, dA, 1024, YX, 288, P, 1024, 288, net->dWpM0, 288, c->flat + net->dbM_off[0], stream, NU_TN_A0_16));
     NtArgs gy = {dA, 1024, net->WpTM0, 1024, P, 288, 1024, s->dYX, 288, NU_EPI_PLAIN};
-    gy.B16 = w16(net->WpTM0_16, 0); gy.st = A16;
+    gy.B16 = w16(c, net->WpTM0_16, 0); gy.st = A16;
     CHK(nt(c, gy, stream));
     return wgrad_flush(c, stream);
 }

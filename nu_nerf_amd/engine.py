@@ -38,7 +38,7 @@ class GemmNT(ctypes.Structure):
                 ("D", c_p), ("ldd", c_int), ("Cadd", c_p), ("ldadd", c_int), ("zero_to", c_int), ("act_cols", c_int),
                 ("alpha", c_f), ("groups", c_int), ("sA", c_ll), ("sB", c_ll), ("sC", c_ll), ("sC2", c_ll),
                 ("sBias", c_ll), ("sH", c_ll), ("sD", c_ll), ("sCadd", c_ll), ("epi", c_int), ("bf16", c_int),
-                ("mask", c_p), ("mask_nct", c_int), ("mask_ct0", c_int)]
+                ("mask", c_p), ("mask_nct", c_int), ("mask_ct0", c_int), ("B6", c_p)]
 
 
 class GemmTN(ctypes.Structure):
@@ -58,7 +58,9 @@ class ReduceDesc(ctypes.Structure):
 class PackDesc(ctypes.Structure):
     _fields_ = [("v", c_p), ("g", c_p), ("colmap", c_p), ("Wp", c_p), ("WpT", c_p), ("dWp", c_p), ("dv_off", c_ll),
                 ("dg_off", c_ll), ("bias", c_p), ("bias_p", c_p), ("scale", c_f), ("N", c_int), ("K", c_int),
-                ("Kp", c_int), ("ldT", c_int), ("ldd", c_int), ("row_begin", c_int), ("col_off", c_int), ("Wp16", c_p), ("WpT16", c_p)]
+                ("Kp", c_int), ("ldT", c_int), ("ldd", c_int), ("row_begin", c_int), ("col_off", c_int), ("Wp16", c_p), ("WpT16", c_p),
+                ("planes", c_int), ("pad_", c_int), ("w6_row0", c_int), ("w6_ld", c_int), ("t6_row0", c_int), ("t6_col0", c_int),
+                ("t6_ld", c_int), ("pad2_", c_int)]
 
 
 class Lin(ctypes.Structure):
@@ -527,12 +529,21 @@ class Stage1Engine:
         self.layers = layers
         self.n_grad = self._goff
         # bf16 copies of every NT-side weight table (written by the same pack launch): same shapes, same element offsets
+        # 'bf16x6': the same twins hold the exact hi / mid / lo split instead (three times the elements, the fp32 table's offsets
+        # times 3 -- include/nu_nerf.h NuGemmNT.B6): the NT kernel then never splits a weight tile (csrc/gemm_nt6.hip)
         self._tw = {}
-        if self.h16:
+        self.w6 = self.bf16 == 2 and os.environ.get('NU_PRESPLIT_WEIGHTS', '1') != '0'
+        if self.h16 or self.w6:
             for lay in layers:
                 for tab in (lay.Wp, lay.WpT):
                     if tab is not None and id(tab[0]) not in self._tw:
-                        self._tw[id(tab[0])] = torch.zeros_like(tab[0], dtype=torch.bfloat16)
+                        if self.w6:
+                            ld = tab[0].shape[-1]
+                            assert ld % 16 == 0, "pre-split weight planes need leading dimensions that are multiples of 16"
+                            rows = -(-(tab[0].numel() // ld) // 256) * 256          # whole 256-row blocks
+                            self._tw[id(tab[0])] = torch.zeros(3 * rows * ld, dtype=torch.bfloat16, device=tab[0].device)
+                        else:
+                            self._tw[id(tab[0])] = torch.zeros_like(tab[0], dtype=torch.bfloat16)
         self.lut = p['color_network.FG_LUT']
         # parameters that never receive a gradient in stage 1: color_network.iors.*, infinity_far_bkgr.*
         self._desc_dev = None
@@ -552,6 +563,14 @@ class Stage1Engine:
             d.WpT = addr(*l.WpT) if l.WpT is not None else 0
             d.dWp = addr(*l.dWp)
             d.Wp16, d.WpT16 = self._a16(l.Wp), self._a16(l.WpT)
+            d.planes = 3 if self.w6 else 1
+            if self.w6:          # the pack launch gets the START of each twin and the layer's place in the table (include/nu_nerf.h)
+                d.Wp16, d.w6_ld = addr(self._tw[id(l.Wp[0])]), l.Wp[0].shape[-1]
+                d.w6_row0 = l.Wp[1] // d.w6_ld
+                assert l.Wp[1] % d.w6_ld == 0
+                if l.WpT is not None:
+                    d.WpT16, d.t6_ld = addr(self._tw[id(l.WpT[0])]), l.WpT[0].shape[-1]
+                    d.t6_row0, d.t6_col0 = l.WpT[1] // d.t6_ld, l.WpT[1] % d.t6_ld
             d.dv_off, d.dg_off = l.dv_off, l.dg_off
             d.bias = addr(l.b) if (l.bias_p is not None) else 0
             d.bias_p = addr(*l.bias_p) if l.bias_p is not None else 0
@@ -567,9 +586,9 @@ class Stage1Engine:
 
     def _a16(self, tab):
         """Device address of the bf16 twin of a (tensor, element offset) weight table; 0 outside the bf16-storage mode."""
-        if tab is None or not self.h16:
+        if tab is None or not (self.h16 or self.w6):
             return 0
-        return addr(self._tw[id(tab[0])], tab[1])
+        return addr(self._tw[id(tab[0])], tab[1] * (3 if self.w6 else 1))
 
     def _lin(self, lay):
         return Lin(addr(*lay.Wp), addr(*lay.WpT) if lay.WpT is not None else 0, addr(*lay.dWp), addr(lay.b), lay.db_off, lay.N, lay.K,
@@ -639,14 +658,14 @@ class Stage1Engine:
     # ------------------------------------------------------------------ raw launches
     def nt(self, A, lda, B, ldb, M, N, K, C, ldc, epi, *, C2=0, ldc2=0, bias=0, H=0, ldh=0, D=0, ldd=0, Cadd=0,
            ldadd=0, zero_to=0, act_cols=0, alpha=1.0, groups=1, sA=0, sB=0, sC=0, sC2=0, sBias=0, sH=0, sD=0, sCadd=0,
-           ktrue=None, ntrue=None, mask=None):
+           ktrue=None, ntrue=None, mask=None, B6=0):
         """C = epi(A . B^T) on the fp32-MFMA kernel.  ktrue/ntrue: unpadded extents, used only for the algorithmic
-        FLOP count of the roofline report."""
+        FLOP count of the roofline report.  B6 (mode 'bf16x6' only): the pre-split planes of B (include/nu_nerf.h NuGemmNT.B6)."""
         if M <= 0:
             return
         g = GemmNT(A, lda, B, ldb, M, N, K, C, ldc, C2, ldc2, bias, H, ldh, D, ldd, Cadd, ldadd, zero_to, act_cols,
                    alpha, groups, sA, sB, sC, sC2, sBias, sH, sD, sCadd, epi, self.bf16,
-                   mask.data_ptr() if mask is not None else 0, mask._nu_nct if mask is not None else 0, 0)
+                   mask.data_ptr() if mask is not None else 0, mask._nu_nct if mask is not None else 0, 0, B6)
         kt = self._ktime if self.ktime_on else None
         if kt is not None:
             e0, e1 = self._event_pair()
@@ -664,7 +683,7 @@ class Stage1Engine:
         """One problem of an `nt_batch` launch (the arguments of `nt`)."""
         return GemmNT(A, lda, B, ldb, M, N, K, C, ldc, C2, ldc2, bias, H, ldh, D, ldd, Cadd, ldadd, zero_to, act_cols,
                       alpha, groups, sA, sB, sC, sC2, sBias, sH, sD, sCadd, epi, self.bf16,
-                      mask.data_ptr() if mask is not None else 0, mask._nu_nct if mask is not None else 0, 0)
+                      mask.data_ptr() if mask is not None else 0, mask._nu_nct if mask is not None else 0, 0, 0)
 
     def nt_batch(self, descs):
         """Several independent NT problems in as few persistent launches as possible (nu_gemm_nt_batch: runs of one epilogue kind
@@ -1464,7 +1483,10 @@ class Stage1Engine:
         alpha_rm, color_rm = e(R * S), e(R * S, 4)
         ctx = dict(R=R, S=S, P_in=P_in, P_out=P_out, P_in_dev=tot[:1], pt_in=pt_in, idx_in=idx_in, pt_out=pt_out, idx_out=idx_out,
                    inner_rm=inner_rm, alpha_rm=alpha_rm, color_rm=color_rm, anneal=float(anneal))
-        two = P_out > 0 and P_in > 0 and R * S <= self._TWO_STREAM_SAMPLES
+        # ('bf16x6' stays on one stream: with the NeRF++ chain on a second stream its gradients were not reproducible run to run --
+        # single elements of pure-VALU kernels differing by one rounding, amplified by cancellation to 1e-4 .. 1e-3 on small bias
+        # gradients; 'fp32' and 'bf16' are bit-reproducible with two streams, 'bf16x6' with one.  DESIGN.md 12, scripts/determinism_probe3.py)
+        two = P_out > 0 and P_in > 0 and R * S <= self._TWO_STREAM_SAMPLES and self.bf16 != 2
         ctx['two_streams'] = two
         out = {}
         fk = self.forked() if two else None

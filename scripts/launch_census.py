@@ -92,6 +92,30 @@ if len(sys.argv) > 3 and sys.argv[3] == 'cprofile':        # host time by Python
     st.sort_stats('tottime').print_stats(45)
     st.sort_stats('cumulative').print_stats(60)
     raise SystemExit(0)
+if len(sys.argv) > 3 and sys.argv[3] == 'sites':           # which Python lines ask for zero-filled buffers / index lists (one step)
+    sites = collections.Counter()
+
+    def wrap(owner, name, tag):
+        orig = getattr(owner, name)
+
+        def f(*a, **k):
+            fr = sys._getframe(1)
+            while fr is not None and 'nu_nerf_amd' not in fr.f_code.co_filename:
+                fr = fr.f_back
+            if fr is not None:
+                sites['%-12s %s:%d %s' % (tag, os.path.basename(fr.f_code.co_filename), fr.f_lineno, fr.f_code.co_name)] += 1
+            return orig(*a, **k)
+        setattr(owner, name, f)
+    for nm in ('zeros', 'zeros_like', 'ones', 'ones_like', 'full', 'nonzero', 'arange', 'cat', 'where', 'index_select', 'gather'):
+        wrap(torch, nm, nm)
+    for nm in ('new_zeros', 'zero_', 'nonzero', 'item', 'tolist', 'index_select', 'index_copy', 'index_add_', 'index_add', 'fill_',
+               'new_ones', 'new_full', 'clone', 'contiguous', '__getitem__', '__setitem__', 'gather', 'float', 'to'):
+        wrap(torch.Tensor, nm, 'T.' + nm)
+    step(3)
+    torch.cuda.synchronize()
+    for k, v in sorted(sites.items(), key=lambda kv: (kv[0].split()[0], -kv[1])):
+        print('%4d  %s' % (v, k))
+    raise SystemExit(0)
 from torch.profiler import profile, ProfilerActivity  # noqa: E402
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
     step(3)

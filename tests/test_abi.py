@@ -48,8 +48,8 @@ def test_struct_layouts_match_python_mirrors(lib):
     from nu_nerf_amd.engine import PackDesc, GemmNT, GemmTN
     assert lib.nu_pack_desc_size() == ctypes.sizeof(PackDesc)
     # natural-alignment sizes of the C structs in include/nu_nerf.h
-    assert ctypes.sizeof(GemmNT) == 232 and ctypes.sizeof(GemmTN) == 152
-    assert lib.nu_gemm_nt_size() == 232 and lib.nu_gemm_tn_size() == 152 and lib.nu_reduce_desc_size() == 64
+    assert ctypes.sizeof(GemmNT) == 240 and ctypes.sizeof(GemmTN) == 152
+    assert lib.nu_gemm_nt_size() == 240 and lib.nu_gemm_tn_size() == 152 and lib.nu_reduce_desc_size() == 64
     from nu_nerf_amd.engine import OpCtx, SdfNet, SdfBufs, NerfNet, NerfBufs, ShadeNet, ShadeBufs
     for fn, st in (("nu_op_ctx_size", OpCtx), ("nu_sdf_net_size", SdfNet), ("nu_sdf_bufs_size", SdfBufs), ("nu_nerf_net_size", NerfNet),
                    ("nu_nerf_bufs_size", NerfBufs), ("nu_shade_net_size", ShadeNet), ("nu_shade_bufs_size", ShadeBufs)):

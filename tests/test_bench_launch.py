@@ -51,6 +51,6 @@ def test_traffic_is_quoted_only_for_a_matching_profile():
     pi, po = rec['mean_inner_points'], rec['mean_outer_points']
     nt, tn, src = bench.find_traffic_profile(rec['rays'], 1, rec['real_capture'], rec['mlp_dtype'], False, rec['bf16_storage'], pi * 1.03, po * 0.98)
     assert nt and tn and src.endswith('traffic_pmc.json')
-    assert bench.find_traffic_profile(rec['rays'], 1, rec['real_capture'], rec['mlp_dtype'], False, rec['bf16_storage'], pi * 1.08, po) == (None, None, None)
+    assert bench.find_traffic_profile(rec['rays'], 1, rec['real_capture'], rec['mlp_dtype'], False, rec['bf16_storage'], pi * 1.4, po) == (None, None, None)     # (no committed pass is that far out)
     assert bench.find_traffic_profile(rec['rays'], 2, rec['real_capture'], rec['mlp_dtype'], False, rec['bf16_storage'], pi, po) == (None, None, None)
     assert bench.find_traffic_profile(512, 1, rec['real_capture'], rec['mlp_dtype'], False, rec['bf16_storage'], pi, po) == (None, None, None)

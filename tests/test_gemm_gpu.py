@@ -469,6 +469,110 @@ def test_bf16x6_nt_is_fp32_equivalent(gpu, M, N, K):
     assert float(rel) < 4e-7 * max(1.0, K ** 0.5 / 4), float(rel)
 
 
+def _p3(B):
+    """The pre-split planes of a row-major fp32 table [..., rows, ld] (ld % 16 == 0) in the layout of NuGemmNT.B6: blocks of 256 rows,
+    inside a block one 16-wide k-group after the other, each as [256 rows][hi x16 | mid x16 | lo x16]; hi = bf16(w),
+    mid = bf16(w - hi), lo = bf16(w - hi - mid) (round-to-nearest-even); the two 8-element halves of a 16-group swapped in rows with
+    bit 3 set."""
+    ld = B.shape[-1]
+    B = B.reshape(-1, ld)
+    rows = (B.shape[0] + 255) // 256 * 256
+    Bp = torch.zeros(rows, ld, device=B.device)
+    Bp[:B.shape[0]] = B
+    hi = Bp.bfloat16()
+    r1 = Bp - hi.float()
+    mid = r1.bfloat16()
+    lo = (r1 - mid.float()).bfloat16()
+    pl = torch.stack([x.reshape(rows // 256, 256, ld // 16, 16) for x in (hi, mid, lo)], dim=3)     # [blk, row, kg, plane, 16]
+    odd = (torch.arange(256, device=B.device) & 8) != 0                                             # rows with bit 3 set: halves swapped
+    pl[:, odd] = torch.cat([pl[:, odd][..., 8:], pl[:, odd][..., :8]], dim=-1)
+    return pl.permute(0, 2, 1, 3, 4).contiguous().reshape(-1)                                       # [blk, kg, row, plane, 16]
+
+
+@pytest.mark.parametrize("M,N,K,groups", [(1, 1, 32, 1), (300, 217, 256, 1), (1000, 257, 288, 1), (4099, 256, 96, 1), (2048, 128, 288, 1),
+                                          (70001, 256, 256, 1), (5000, 1024, 288, 1), (3333, 256, 256, 4), (20000, 256, 352, 1)])
+def test_bf16x6_presplit_weight_planes_give_the_same_bits(gpu, M, N, K, groups):
+    """gemm_nt6_kernel (csrc/gemm_nt6.hip: weights pre-split by the pack launch, 128 x 256 tiles, 16-deep pipelined chunks) against
+    gemm_nt_kernel<EPI, 2> (operands split in the loop): per accumulator the same MFMAs in the same order -- every epilogue kind,
+    grouped launches, sign-bit words, zero-filled pad columns and ragged M / N must come out bit for bit the same."""
+    from nu_nerf_amd import _lib as L
+    from nu_nerf_amd.engine import GemmNT, addr
+    lib = L.load()
+    torch.manual_seed(M + N + K)
+    Np = (N + 127) // 128 * 128
+    A = torch.randn(M, K * groups, device=gpu) * torch.exp(2 * torch.randn(M, 1, device=gpu))
+    W = torch.zeros(groups, Np, K, device=gpu)
+    W[:, :N] = torch.randn(groups, N, K, device=gpu) / K ** 0.5
+    B6 = _p3(W)
+    bias = torch.randn(groups, N, device=gpu)
+    ncol = Np * groups
+    pre = torch.randn(M, ncol, device=gpu) * 0.02
+    Hsp = torch.nn.functional.softplus(pre, beta=100)
+    D = torch.randn(M, ncol, device=gpu)
+    Cadd = torch.randn(M, ncol, device=gpu)
+    nct = ncol // 128
+    ldc = ncol + 32
+    res = {}
+    for use6 in (False, True):
+        outs = []
+        mask = torch.zeros(((M + 127) // 128) * nct * 256, dtype=torch.int64, device=gpu)
+        for epi in (1, 0, 2, 3, 4, 5, 6, 7, 8):
+            relu_n = N % 64 == 0                    # the sign-bit path needs N % 64 == 0 (nt_check)
+            C = torch.full((M, ldc), float("nan"), device=gpu)
+            C2 = torch.full((M, ldc), float("nan"), device=gpu)
+            uses_mask = relu_n and epi in (1, 3, 8)
+            H = Hsp if epi in (4, 5, 6) else (pre if epi in (3, 8) else None)
+            g = GemmNT(addr(A), K * groups, addr(W), K, M, N, K, addr(C), ldc, addr(C2) if epi == 5 else 0, ldc,
+                       addr(bias) if epi <= 2 else 0, addr(H) if H is not None else 0, ncol, addr(D) if epi == 5 else 0, ncol,
+                       addr(Cadd) if epi in (6, 8) else 0, ncol, Np if groups == 1 and epi != 5 else 0, 0, 1.0, groups,
+                       K, Np * K, Np, Np, N, Np, Np, Np, epi, 2 | (4 if use6 else 0), mask.data_ptr() if uses_mask else 0,
+                       nct if uses_mask else 0, 0, addr(B6) if use6 else 0)                # 4: NU_GEMM_PRESPLIT_ALWAYS
+            L.check(lib.nu_gemm_nt_ex(ctypes.byref(g), L.stream()), "nu_gemm_nt_ex epi %d" % epi)
+            outs += [C, C2]
+        outs.append(mask)
+        torch.cuda.synchronize()
+        res[use6] = outs
+    assert torch.isfinite(res[True][0][:, :N]).all()
+    for a, b in zip(res[False], res[True]):
+        if a.dtype == torch.float32:
+            assert torch.equal(torch.nan_to_num(a, nan=12345.0), torch.nan_to_num(b, nan=12345.0))
+        else:
+            assert torch.equal(a, b)
+    # and it is the product it claims to be
+    ref = A[:, :K].double() @ W[0, :N].double().t()
+    scale = A[:, :K].double().abs() @ W[0, :N].double().abs().t()
+    err = ((res[True][14][:, :N].double() - ref).abs() / (scale + 1e-30)).max()          # epilogue 7 (plain), group 0
+    assert float(err) < 4e-7 * max(1.0, K ** 0.5 / 4), float(err)
+
+
+@pytest.mark.parametrize("M,N,K", [(540672, 256, 256), (131072, 1024, 288), (200000, 257, 96)])
+def test_bf16x6_presplit_kernel_walks_many_tiles_per_workgroup(gpu, M, N, K):
+    """The persistent walk of gemm_nt6_kernel over several tiles per workgroup (hand-over of the next tile's first chunks under the
+    last chunks of the current one, both A register sets, the epilogue scratch aliasing a stage): repeated launches give the bits of
+    gemm_nt_kernel<EPI, 2>, every time."""
+    from nu_nerf_amd import _lib as L
+    from nu_nerf_amd.engine import GemmNT, addr
+    lib = L.load()
+    torch.manual_seed(M + N)
+    Np = (N + 127) // 128 * 128
+    A = torch.randn(M, K, device=gpu)
+    W = torch.zeros(Np, K, device=gpu)
+    W[:N] = torch.randn(N, K, device=gpu) / K ** 0.5
+    B6 = _p3(W)
+    bias = torch.randn(N, device=gpu)
+
+    def run(flag, b6):
+        C = torch.full((M, Np), float("nan"), device=gpu)
+        g = GemmNT(addr(A), K, addr(W), K, M, N, K, addr(C), Np, 0, 0, addr(bias), 0, 0, 0, 0, 0, 0, 0, 0, 1.0, 1,
+                   0, 0, 0, 0, 0, 0, 0, 0, 2, 2 | flag, 0, 0, 0, b6)
+        L.check(lib.nu_gemm_nt_ex(ctypes.byref(g), L.stream()), "nu_gemm_nt_ex")
+        return C[:, :N]
+    ref = run(0, 0)
+    for _ in range(6):
+        out = run(4, addr(B6))
+        assert torch.equal(out, ref)
+
+
 @pytest.mark.parametrize("P,N1,N2,S", [(1000, 257, 256, 7), (5000, 256, 39, 16), (70000, 128, 288, 32)])
 def test_bf16x6_tn_is_fp32_equivalent(gpu, P, N1, N2, S):
     from nu_nerf_amd import _lib as L
