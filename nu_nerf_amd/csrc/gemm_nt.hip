@@ -502,8 +502,11 @@ int nu_gemm_nt_launch(const NuGemmNT& g, hipStream_t stream) {
     // pre-split weight planes: gemm_nt6_kernel's 128 x 256 tiles, when they still fill the chip (both kernels give the same bits;
     // measured, scripts/bench_nt6.py: 65 536 rows x 256 columns = 512 tiles 145 vs 128 TFLOP/s, 16 384 rows = 128 tiles 65 vs 95)
     static const int nt6_env = getenv("NU_NT6") ? atoi(getenv("NU_NT6")) : -1;          // development switch: 0 never, 1 always
+    // ... and for the epilogues without a second auxiliary matrix: Q_SP / B_SP / B_RELU run twice per 128 x 256 tile with more live
+    // registers than the build has (58-63 spilled) -- in the step 215 vs 168 us (Q_SP), 169 vs 155 (B_SP), 755 vs 543 (B_RELU)
+    const bool nt6_epi = g.epi != NU_EPI_Q_SP && g.epi != NU_EPI_B_SP && g.epi != NU_EPI_B_RELU;
     if (prec == 2 && g.B6 && nt6_env != 0 &&
-        (nt6_env == 1 || (g.bf16 & NU_GEMM_PRESPLIT_ALWAYS) || (long long)nu_cdiv(g.M, TBM) * nu_cdiv(g.N, 256) * groups >= 320))
+        (nt6_env == 1 || (g.bf16 & NU_GEMM_PRESPLIT_ALWAYS) || (nt6_epi && (long long)nu_cdiv(g.M, TBM) * nu_cdiv(g.N, 256) * groups >= 320)))
         return nu_gemm_nt6_launch(g, groups, stream);
     if (prec == 0 && !v1) {
         const long long t128 = (long long)nu_cdiv(g.M, TBM) * ntn * groups, t64 = (long long)nu_cdiv(g.M, 64) * ntn * groups;
