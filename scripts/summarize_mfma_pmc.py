@@ -12,7 +12,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(float))
 seen = collections.defaultdict(set)
 for r in csv.DictReader(open(cc_csv)):
     name = r['Kernel_Name']
-    k = 'gemm_nt_kernel' if re.search(r'gemm_nt(2b?)?_kernel', name) else ('gemm_tn_kernel' if re.search(r'gemm_tn(2b?|b|256)?_kernel', name) else None)
+    k = 'gemm_nt_kernel' if re.search(r'gemm_nt(2b?|6|16b?)?_kernel', name) else ('gemm_tn_kernel' if re.search(r'gemm_tn(2b?|b|256|16|16x256)?_kernel', name) else None)
     if not k:
         continue
     acc[k][r['Counter_Name']] += float(r['Counter_Value'])

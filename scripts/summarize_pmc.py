@@ -10,7 +10,7 @@ def agg(path, name):
             continue
         kn = r['Kernel_Name']
         # every NT launch (single problem, batched, bf16 storage) / every weight-gradient launch (single, batched, both tile sizes)
-        k = ('gemm_nt_kernel' if re.search(r'gemm_nt(2b?|16b?)?_kernel', kn) else
+        k = ('gemm_nt_kernel' if re.search(r'gemm_nt(2b?|16b?|6)?_kernel', kn) else
              'gemm_tn_kernel' if re.search(r'gemm_tn(2b?|b|16|16x256|256)?_kernel', kn) else
              'calib_read4' if 'calib_read4' in kn else 'calib_read16' if 'calib_read16' in kn else None)
         if k:
@@ -26,7 +26,7 @@ if bench_json:
     b = json.loads(open(bench_json).read().strip().splitlines()[-1])
     c = b['config']
     # what bench.py matches a later run against before it quotes these numbers as that run's `roofline.traffic`
-    res['workload_record'] = {"rays": c['rays_per_gpu'], "real_capture": 'real-capture' in c['workload'], "mlp_dtype": {'f32': 'fp32', 'bf16': 'bf16'}.get(b['dtype'], b['dtype']),
+    res['workload_record'] = {"rays": c['rays_per_gpu'], "real_capture": 'real-capture (is_nerf' in c['workload'], "mlp_dtype": 'bf16x6' if b['dtype'].startswith('bf16x6') else {'f32': 'fp32', 'bf16': 'bf16'}.get(b['dtype'], b['dtype']),
                               "bf16_storage": b['dtype'] == 'bf16', "mean_inner_points": c['mean_inner_points'],
                               "mean_outer_points": c['mean_outer_points'], "steps": b['steps'], "warmup": b['warmup']}
 for k in ('gemm_nt_kernel', 'gemm_tn_kernel'):          # launches per step: a later run must have the same launch structure to quote these per-launch bytes
