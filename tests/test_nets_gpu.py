@@ -164,3 +164,29 @@ def test_fused_sdf_forward_is_bit_identical_to_the_layered_path(gpu, P):
         if l < 8:
             h = torch.nn.functional.softplus(h, beta=100)
     torch.testing.assert_close(fused.double(), h[:, 0], rtol=2e-5, atol=2e-6)
+
+
+def test_pack_writes_the_presplit_weight_planes_of_every_table(gpu):
+    """mlp_dtype 'bf16x6': the pack launch writes, next to every fp32 weight table, its exact hi / mid / lo bf16 split in the layout
+    gemm_nt6_kernel reads (include/nu_nerf.h NuGemmNT.B6: 256-row blocks, k-group major, half-swap in rows with bit 3 set).  Every
+    table of the engine -- per-layer tables, the stacked material tables (row offsets), the transposed tables (column offsets) -- must
+    equal the same split computed from the fp32 table on the host side (test_gemm_gpu._p3), bit for bit."""
+    from test_gemm_gpu import _p3
+    from test_stage1_gpu import make_net
+    net = make_net(gpu, cfg=dict(CFG16, mlp_dtype='bf16x6'))
+    eng = net.engine()
+    assert eng.bf16 == 2 and eng.w6 and not eng.h16
+    eng.pack()
+    torch.cuda.synchronize()
+    seen = 0
+    for lay in eng.layers:
+        for tab in (lay.Wp, lay.WpT):
+            if tab is None:
+                continue
+            t = tab[0]
+            twin = eng._tw[id(t)]
+            want = _p3(t.reshape(-1, t.shape[-1]))
+            assert twin.numel() == want.numel(), (lay.name if hasattr(lay, 'name') else '?', tuple(t.shape))
+            assert torch.equal(twin.view(torch.int16), want.view(torch.int16)), (tuple(t.shape), tab[1])
+            seen += 1
+    assert seen >= 60
