@@ -463,3 +463,27 @@ def test_stage2_thick_module_has_the_reference_state_dict_and_registry_entry():
     assert tuple(sd['color_network_inner.refrac_light.0.weight_v'].shape) == (256, 30)
     np.testing.assert_allclose(sd['color_network_inner.outer_light.6.bias'].numpy(), np.log(0.5), rtol=1e-6)
     np.testing.assert_allclose(sd['sdf_network_inner.lin8.bias'].numpy(), -0.5, rtol=1e-6)          # geometric init, bias 0.5
+
+
+def test_presplit_weight_plane_layout_matches_the_documented_index_formula():
+    """include/nu_nerf.h NuGemmNT.B6: bf16 index of element (n, k) of plane p =
+    ((n >> 8) * (ld >> 4) + (k >> 4)) * 12288 + (n & 255) * 48 + 16 p + ((k & 15) ^ (n & 8)), planes = exact hi / mid / lo split.
+    The host-side builder the GPU tests compare the pack launch against (tests/test_gemm_gpu._p3) must follow that formula."""
+    import torch
+    from test_gemm_gpu import _p3
+    torch.manual_seed(3)
+    for rows, ld in ((300, 64), (512, 288), (130, 1024)):
+        W = torch.randn(rows, ld) * torch.exp(2 * torch.randn(rows, 1))
+        flat = _p3(W)
+        assert flat.numel() == 3 * ((rows + 255) // 256 * 256) * ld
+        hi = W.bfloat16()
+        mid = (W - hi.float()).bfloat16()
+        lo = (W - hi.float() - mid.float()).bfloat16()
+        assert torch.equal(hi.float() + mid.float() + lo.float(), W)          # the split is exact
+        g = torch.Generator().manual_seed(rows)
+        for _ in range(400):
+            n = int(torch.randint(0, rows, (1,), generator=g))
+            k = int(torch.randint(0, ld, (1,), generator=g))
+            base = ((n >> 8) * (ld >> 4) + (k >> 4)) * 12288 + (n & 255) * 48 + ((k & 15) ^ (n & 8))
+            for p_, plane in enumerate((hi, mid, lo)):
+                assert flat[base + 16 * p_] == plane[n, k], (rows, ld, n, k, p_)
