@@ -308,11 +308,19 @@ def find_traffic_profile(R, world, real_capture, mlp_dtype, object_rays, h16, p_
             continue
         # bytes PER LAUNCH only carry over to a run with the same launch structure (round 4 merged launches: a round-3 pass
         # averaged over 120 NT launches per step says nothing about a step of 104)
-        lps = w.get('nt_launches_per_step')
-        if nt_launches is not None and (lps is None or abs(lps - nt_launches) > 0.03 * nt_launches):
+        # this run counts a batch of problems launched back to back as ONE launch (its event pair); the pass counts kernels.  A pass
+        # that recorded its own event-launch count is matched on that and its per-kernel bytes are rescaled to bytes per event launch
+        lps, eps = w.get('nt_launches_per_step'), w.get('nt_event_launches_per_step')
+        ref = eps if eps else lps
+        if nt_launches is not None and (ref is None or abs(ref - nt_launches) > 0.03 * nt_launches):
             continue
-        return (d.get('gemm_nt_kernel', {}).get('hbm_bytes_per_launch'), d.get('gemm_tn_kernel', {}).get('hbm_bytes_per_launch'),
-                os.path.relpath(f, ROOT))
+        nt_b, tn_b = d.get('gemm_nt_kernel', {}).get('hbm_bytes_per_launch'), d.get('gemm_tn_kernel', {}).get('hbm_bytes_per_launch')
+        if eps and lps and nt_b:
+            nt_b *= lps / eps
+        teps, tlps = w.get('tn_event_launches_per_step'), w.get('tn_launches_per_step')
+        if teps and tlps and tn_b:
+            tn_b *= tlps / teps
+        return nt_b, tn_b, os.path.relpath(f, ROOT)
     return None, None, None
 
 

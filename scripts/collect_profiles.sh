@@ -19,7 +19,7 @@ rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_
 cd $R
 python3 scripts/kstats.py $OUT/stats $((STEPS + WARMUP)) 40 > $OUT/kstats.txt 2>&1
 cp $(ls $OUT/stats/*/*kernel_stats.csv | head -1) $OUT/kernel_stats.csv
-python3 scripts/summarize_pmc.py $(ls $OUT/fetch/*/*counter_collection.csv | head -1) $(ls $OUT/write/*/*counter_collection.csv | head -1) $OUT/traffic_pmc.json $OUT/bench_fetch.json > $OUT/traffic.txt 2>&1
+python3 scripts/summarize_pmc.py $(ls $OUT/fetch/*/*counter_collection.csv | head -1) $(ls $OUT/write/*/*counter_collection.csv | head -1) $OUT/traffic_pmc.json $OUT/bench_fetch.json $OUT/bench_stats.json > $OUT/traffic.txt 2>&1
 python3 scripts/summarize_mfma_pmc.py $(ls $OUT/mfma/*/*counter_collection.csv | head -1) $(ls $OUT/mfma/*/*kernel_trace.csv | head -1) $OUT/mfma_pmc.json > $OUT/mfma.txt 2>&1
 rm -rf $OUT/fetch $OUT/write $OUT/mfma $OUT/stats
 tail -3 $OUT/kstats.txt; tail -5 $OUT/traffic.txt; tail -5 $OUT/mfma.txt

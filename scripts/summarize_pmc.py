@@ -32,6 +32,14 @@ if bench_json:
 for k in ('gemm_nt_kernel', 'gemm_tn_kernel'):          # launches per step: a later run must have the same launch structure to quote these per-launch bytes
     if bench_json and k in f:
         res['workload_record'][k.replace('gemm_', '').replace('_kernel', '') + '_launches_per_step'] = f[k][0] / float(b['steps'] + b['warmup'])
+# bench.py times a batch of problems launched back to back (nt_batch outside the exact-fp32 mode) as ONE launch: the per-launch
+# bytes above are per KERNEL; the event-launch counts of the stats pass let bench.py rescale them to its own launch unit
+if bench_json and len(sys.argv) > 5:
+    bs = json.loads(open(sys.argv[5]).read().strip().splitlines()[-1]).get('roofline', {})
+    if bs.get('launches'):
+        res['workload_record']['nt_event_launches_per_step'] = float(bs['launches'])
+    if bs.get('wgrad', {}).get('launches'):
+        res['workload_record']['tn_event_launches_per_step'] = float(bs['wgrad']['launches'])
 for k in f:
     n = f[k][0]
     res[k] = {"launches": n, "fetch_bytes_per_launch": 2.0 * 1024 * f[k][1] / n, "write_bytes_per_launch": 1024 * w[k][1] / max(w[k][0], 1),
