@@ -492,8 +492,10 @@ def stage1_leg(args, dist_ctx):
         if args.mlp_dtype == 'bf16x6':
             # six bf16 MFMAs per 16-deep k-step: price the achieved rate against the bf16 pipe doing 6x the arithmetic
             res["roofline"] = {"bound": "mfma", "achieved": 6 * tf, "peak": 2516.6, "unit": "TFLOP/s (bf16 MFMA issued)",
-                               "frac": 6 * tf / 2516.6, "traffic": None, "fp32_equivalent_tflops": tf,
-                               "kernel": "gemm_nt_kernel<*, split> (6 x v_mfma_f32_32x32x16_bf16 per k-step)", **common}
+                               "frac": 6 * tf / 2516.6, "traffic": traffic, "fp32_equivalent_tflops": tf,
+                               "traffic_unit": "HBM bytes per launch (rocprofv3 PMC passes, gfx950 corrections applied)",
+                               "kernel": "gemm_nt6_kernel<*> (weights pre-split by the pack launch) / gemm_nt_kernel<*, split> below 320 tiles "
+                                         "(6 x v_mfma_f32_32x32x16_bf16 per k-step)", **common}
         elif args.mlp_dtype != 'fp32':
             # bf16 build: 16x the fp32 MFMA rate, so the GEMMs are bound by streaming their operands; the algorithmic bytes
             # count each matrix at the width it is stored in (bf16 weight tables and hidden activations, fp32 elsewhere)
