@@ -16,6 +16,16 @@ STAMP = os.path.join(HERE, ".libnunerf.stamp")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
          "-fno-gpu-rdc", "-Wno-unused-result", "-I" + CSRC, "-I" + os.path.join(HERE, "..", "include")]
+# NU_BUILD_NO_PK_F32=1: build WITHOUT packed-fp32 VALU instructions (v_pk_mul_f32 / v_pk_add_f32 ...).  A pure-VALU kernel of this library
+# built WITH them returned wrong elements (lanes 48-63 of a wave) in 59 launches of 60 while the library's bf16-MFMA GEMMs ran on another
+# stream, and never without them (scripts/determinism_valu_victim.py, profiles/r04/valu_victim_next_to_bf16_mfma.txt); the two
+# builds are equally fast.  It is NOT the default: without the packed multiplies the compiler contracts other expressions (o + d z of the
+# sample positions becomes an fma; one ulp there is 3e-5 in sin(512 x) of the NeRF++ embedding) and three reference-parity tests land
+# 4-6e-4 from the golden values on one weight gradient, past the 3e-4 they were calibrated to with the packed build.  The default build
+# avoids the failing combination instead: the bf16 / bf16x6 modes never overlap two streams (engine.render_forward, stage2.py), and the
+# fp32-MFMA kernels of the default mode do not trigger it (0 of 60).
+if os.environ.get("NU_BUILD_NO_PK_F32", "0") == "1":
+    FLAGS += ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 
 
 def _sources():

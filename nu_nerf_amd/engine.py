@@ -1483,10 +1483,11 @@ class Stage1Engine:
         alpha_rm, color_rm = e(R * S), e(R * S, 4)
         ctx = dict(R=R, S=S, P_in=P_in, P_out=P_out, P_in_dev=tot[:1], pt_in=pt_in, idx_in=idx_in, pt_out=pt_out, idx_out=idx_out,
                    inner_rm=inner_rm, alpha_rm=alpha_rm, color_rm=color_rm, anneal=float(anneal))
-        # ('bf16x6' stays on one stream: with the NeRF++ chain on a second stream its gradients were not reproducible run to run --
-        # single elements of pure-VALU kernels differing by one rounding, amplified by cancellation to 1e-4 .. 1e-3 on small bias
-        # gradients; 'fp32' and 'bf16' are bit-reproducible with two streams, 'bf16x6' with one.  DESIGN.md 12, scripts/determinism_probe3.py)
-        two = P_out > 0 and P_in > 0 and R * S <= self._TWO_STREAM_SAMPLES and self.bf16 != 2
+        # (the bf16-MFMA modes stay on one stream: a packed-fp32 VALU kernel running beside this library's bf16-MFMA GEMMs returns wrong
+        # elements now and then -- 'bf16x6' gradients were not reproducible run to run with the overlap; the fp32-MFMA kernels of the
+        # default mode do not trigger it.  DESIGN.md 12, scripts/determinism_valu_victim.py, scripts/determinism_probe3.py)
+        two = (P_out > 0 and P_in > 0 and R * S <= self._TWO_STREAM_SAMPLES
+               and (self.bf16 == 0 or os.environ.get('NU_BF16_TWO_STREAMS') == '1'))
         ctx['two_streams'] = two
         out = {}
         fk = self.forked() if two else None

@@ -390,9 +390,9 @@ class Stage2Renderer(nn.Module):
         inv_s = torch.exp(self.deviation_network_inner.variance * 10.0).clip(1e-6, 1e6)
         if self.cfg['freeze_inv_s_step'] is not None and step is not None and step < self.cfg['freeze_inv_s_step']:
             inv_s = inv_s.detach()
-        # ('bf16x6' keeps everything on one stream: DESIGN 12, the two-stream overlap was not reproducible run to run in that mode)
+        # (the bf16-MFMA modes keep everything on one stream: DESIGN 12, packed-fp32 VALU kernels go wrong beside those GEMMs)
         if (len(segs) > 1 and segs[1]['start'].shape[0] > 0 and N0 <= self._TWO_STREAM_RAYS and dev.type == 'cuda'
-                and n2.eng.bf16 != 2):
+                and n2.eng.bf16 == 0):
             main = torch.cuda.current_stream(dev)
             side = n2.eng._fork(mark=False)      # (this engine's ops on the two streams are ordered by op_begin / op_end events)
             for t in [segs[1][k] for k in ('start', 'v', 'z', 'dirs')] + [inv_s]:

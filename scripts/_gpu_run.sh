@@ -1,11 +1,9 @@
 cd $GRAFT_REPO_ROOT
-timeout -k 10 300 python scripts/bench_gemm.py > gpurun_out/bench_gemm_r04.txt 2>&1
-tail -30 gpurun_out/bench_gemm_r04.txt
-python bench.py --steps 10 --warmup 4 --no-cpu-baseline > gpurun_out/r4_bench_check.json 2> gpurun_out/r4_bench_check.err
-python - <<'PY'
-import json
-d=json.loads(open('gpurun_out/r4_bench_check.json').read().strip().splitlines()[-1])
-for e in d.get('extra_workloads', []):
-    rr=e['roofline']
-    print('   ', e['tag'], round(e['ms_per_step'],2), 'frac', round(rr['frac'],3), 'traffic', rr.get('traffic'), rr.get('traffic_source'))
-PY
+timeout -k 10 900 python -m pytest tests -m gpu -q > gpurun_out/suite_fp32.txt 2>&1
+grep -E "^FAILED|passed|failed" gpurun_out/suite_fp32.txt | cut -c1-200
+NU_MLP_DTYPE=bf16x6 timeout -k 10 900 python -m pytest tests -m gpu -q > gpurun_out/suite_x6.txt 2>&1
+grep -E "^FAILED|passed|failed" gpurun_out/suite_x6.txt | cut -c1-200
+NU_MLP_DTYPE=bf16 timeout -k 10 900 python -m pytest tests -m gpu -q > gpurun_out/suite_bf16.txt 2>&1
+grep -E "^FAILED|passed|failed" gpurun_out/suite_bf16.txt | cut -c1-200 | head -12
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+true

@@ -34,6 +34,20 @@ def kernel_table(obj_path):
     return [(re.sub(r"^void ", "", d), r) for d, (_, r) in zip(names, out)]
 
 
+def instruction_count(obj_path, pattern):
+    """Number of disassembled device instructions of one host object whose mnemonic matches the regular expression `pattern`."""
+    with tempfile.TemporaryDirectory() as td:
+        fat, elf = os.path.join(td, "fatbin"), os.path.join(td, "dev.elf")
+        subprocess.check_call(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", obj_path, fat])
+        rc = subprocess.call([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + fat,
+                              "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + elf], stderr=subprocess.DEVNULL)
+        if rc != 0:          # a host-only object (csrc/mlp_ops.hip sequences launches, it holds no kernel)
+            return 0
+        dis = subprocess.check_output([os.path.join(LLVM, "llvm-objdump"), "-d", elf], text=True)
+    rx = re.compile(r"^\s+(" + pattern + r")\b")
+    return sum(1 for line in dis.splitlines() if rx.match(line))
+
+
 if __name__ == "__main__":
     bdir = os.path.join(ROOT, "nu_nerf_amd", "build")
     objs = sys.argv[1:] or sorted(f[:-2] for f in os.listdir(bdir) if f.endswith(".o"))

@@ -102,3 +102,4 @@ def test_hot_kernels_register_budget_from_the_code_object(lib):
             assert r["vgpr_spill"] <= cap and r["vgpr"] <= 168, (name, r)
             assert r["lds"] <= 53 * 1024, (name, r)             # three workgroups per CU
     assert n16 == 18
+
