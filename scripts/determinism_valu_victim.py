@@ -125,3 +125,25 @@ for name, bg in (('nothing', []), ('bf16x6 split GEMMs', bgs)):
         torch.cuda.synchronize()
         bad += 0 if torch.equal(out, ref_t) else 1
     print('torch elementwise victim next to %-40s launches differing: %2d of 40' % (name, bad), flush=True)
+
+
+# ---- (3) the instruction alone: kernels that only issue one kind of MFMA from registers (scripts/mfma_spin.hip; no LDS, no memory traffic)
+spin_path = os.path.join(ROOT, 'scripts', 'libmfma_spin.so')
+if os.path.exists(spin_path):
+    spin = ctypes.CDLL(spin_path)
+    sink = torch.zeros(4, device=dev)
+    for kind, name in ((0, 'v_mfma_f32_32x32x16_bf16 only'), (1, 'v_mfma_f32_16x16x32_bf16 only'), (2, 'v_mfma_f32_32x32x2_f32 only'),
+                       (3, 'v_mfma_f32_32x32x16_f16 only'), (4, 'v_cvt_pk_bf16_f32 only (no MFMA)'), (5, 'LDS b128 traffic only')):
+        bad = 0
+        for r in range(60):
+            dH.fill_(float('nan'))
+            torch.cuda.synchronize()
+            with torch.cuda.stream(side):
+                spin.mfma_spin(kind, 1024, 20000, c_p(addr(sink)), L.stream())
+            for _ in range(3):
+                victim()
+            torch.cuda.synchronize()
+            bad += 0 if torch.equal(dH, ref) else 1
+        print('%-72s victim launches differing: %2d of 60' % ('single-instruction loop: ' + name, bad), flush=True)
+else:
+    print('(scripts/libmfma_spin.so not built: hipcc --offload-arch=gfx950 -O3 -shared -fPIC -o scripts/libmfma_spin.so scripts/mfma_spin.hip)')
