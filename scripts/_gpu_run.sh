@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-timeout -k 10 400 python scripts/determinism_valu_victim.py 2>&1 | grep -v "first differing\|dy of that" | tail -16 | cut -c1-170
+for i in 1 2 3; do timeout -k 10 300 python -m pytest tests/test_stage1_gpu.py -m gpu -q -k "bit_reproducible" 2>&1 | grep -E "^E  |passed|failed" | cut -c1-200 | head -5; done

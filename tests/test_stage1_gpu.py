@@ -382,3 +382,37 @@ def test_ray_store_from_loaded_images_on_the_device(gpu):
         assert ev['ray_rgb'].shape == (3, 2, 3) and ev['gt_rgb'].shape == (3, 2, 3) and ev['gt_mask'].shape == (3, 2, 1)
         half = imgs_info_downsample({'imgs': info['imgs'][1:2], 'Ks': info['Ks'][1:2]}, 0.5)['imgs'][0]
         np.testing.assert_allclose(ev['gt_rgb'].cpu().numpy(), half.permute(1, 2, 0).cpu().numpy(), rtol=0, atol=1e-7)
+
+
+@pytest.mark.parametrize("mlp_dtype", ["fp32", "bf16x6", "bf16"])
+def test_a_train_step_is_bit_reproducible(gpu, mlp_dtype):
+    """The same batch through forward + loss + backward four times on one network: every output and every parameter gradient must
+    come out bit for bit the same (no atomics, deterministic split reductions, fixed launch structure).  fp32 overlaps its NeRF++
+    chain on a second stream at this size; the bf16-MFMA modes must not (a packed-fp32 VALU kernel running beside those
+    GEMMs returns wrong elements now and then -- 'bf16x6' failed this test one repetition in two before it went to one stream)."""
+    from nu_nerf_amd.loss import name2loss, SPHEREPOT_LOSSES, total_loss
+    g = golden("train_step20000_r48.npz")
+    step = int(g['step'])
+    cfg = dict(CFG, mlp_dtype=mlp_dtype)
+    net = make_net(gpu, cfg)
+    batch = {k: torch.from_numpy(g[k]).to(gpu) for k in ('rays_o', 'rays_d', 'rgbs')}
+    rand = (torch.from_numpy(g['u1']).to(gpu), torch.from_numpy(g['u2']).to(gpu))
+    losses = [name2loss[n](cfg) for n in SPHEREPOT_LOSSES]
+    ref = None
+    for rep in range(4):
+        for p in net.parameters():
+            p.grad = None
+        out = net.train_step_rays(batch, step, rand=rand)
+        total, _ = total_loss(out, losses, step)
+        total.backward()
+        torch.cuda.synchronize()
+        assert net.engine().last_ctx['two_streams'] == (mlp_dtype == 'fp32')
+        cur = {n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None}
+        cur['ray_rgb'] = out['ray_rgb'].detach().clone()
+        cur['total'] = total.detach().clone()
+        if ref is None:
+            ref = cur
+            continue
+        assert set(cur) == set(ref)
+        bad = [n for n in ref if not torch.equal(ref[n], cur[n])]
+        assert not bad, (rep, bad[:8])
