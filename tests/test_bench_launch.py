@@ -54,3 +54,21 @@ def test_traffic_is_quoted_only_for_a_matching_profile():
     assert bench.find_traffic_profile(rec['rays'], 1, rec['real_capture'], rec['mlp_dtype'], False, rec['bf16_storage'], pi * 1.4, po) == (None, None, None)     # (no committed pass is that far out)
     assert bench.find_traffic_profile(rec['rays'], 2, rec['real_capture'], rec['mlp_dtype'], False, rec['bf16_storage'], pi, po) == (None, None, None)
     assert bench.find_traffic_profile(512, 1, rec['real_capture'], rec['mlp_dtype'], False, rec['bf16_storage'], pi, po) == (None, None, None)
+
+
+def test_traffic_of_a_pass_with_batched_launches_is_rescaled_to_the_runs_launch_unit():
+    """A counter pass counts KERNEL launches; outside the exact-fp32 mode bench.py times a level of the four light predictors as one
+    launch.  A pass that recorded both counts (config 4: 80 kernels = 64 event launches per step) is matched on the run's own count
+    and its bytes per kernel launch are rescaled to bytes per event launch; a run with another launch structure gets nothing."""
+    import json
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    d = json.load(open(os.path.join(bench.ROOT, 'profiles', 'r04', 'traffic_pmc_config4.json')))
+    w = d['workload_record']
+    assert w['nt_launches_per_step'] == 80.0 and w['nt_event_launches_per_step'] == 64.0
+    nt, tn, src = bench.find_traffic_profile(w['rays'], 1, True, 'bf16', False, True, w['mean_inner_points'], w['mean_outer_points'], nt_launches=64)
+    assert src.endswith('traffic_pmc_config4.json')
+    assert abs(nt - d['gemm_nt_kernel']['hbm_bytes_per_launch'] * 80.0 / 64.0) < 1.0
+    assert abs(tn - d['gemm_tn_kernel']['hbm_bytes_per_launch']) < 1.0                      # 34 kernels = 34 event launches
+    assert bench.find_traffic_profile(w['rays'], 1, True, 'bf16', False, True, w['mean_inner_points'], w['mean_outer_points'],
+                                      nt_launches=80) == (None, None, None)
