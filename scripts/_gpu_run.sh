@@ -1,12 +1,2 @@
 cd $GRAFT_REPO_ROOT
-python bench.py > gpurun_out/r4_bench_default_final.json 2> gpurun_out/r4_bench_default_final.err
-python - <<'PY'
-import json
-d=json.loads(open('gpurun_out/r4_bench_default_final.json').read().strip().splitlines()[-1])
-r=d['roofline']
-print('headline', round(d['ms_per_step'],2), round(d['value']), 'frac', round(r['frac'],4), 'traffic', r['traffic'], r.get('traffic_source'), 'launches', r['launches'], 'wgrad', round(r['wgrad']['achieved'],1))
-for e in d.get('extra_workloads', []):
-    rr=e['roofline']
-    print('   ', e['tag'], round(e['ms_per_step'],2), round(e['rays_per_s']), 'frac', round(rr['frac'],3), 'traffic', rr.get('traffic'), (rr.get('traffic_source') or '')[:50])
-print('   cpu', d['cpu_baseline']['value'], d['cpu_baseline'].get('spread_rays_per_s'))
-PY
+timeout -k 10 400 python scripts/determinism_valu_victim.py 2>&1 | grep -v "first differing\|dy of that" | tail -8 | cut -c1-190

@@ -133,7 +133,8 @@ if os.path.exists(spin_path):
     spin = ctypes.CDLL(spin_path)
     sink = torch.zeros(4, device=dev)
     for kind, name in ((0, 'v_mfma_f32_32x32x16_bf16 only'), (1, 'v_mfma_f32_16x16x32_bf16 only'), (2, 'v_mfma_f32_32x32x2_f32 only'),
-                       (3, 'v_mfma_f32_32x32x16_f16 only'), (4, 'v_cvt_pk_bf16_f32 only (no MFMA)'), (5, 'LDS b128 traffic only')):
+                       (3, 'v_mfma_f32_32x32x16_f16 only'), (4, 'v_cvt_pk_bf16_f32 only (no MFMA)'), (5, 'LDS b128 traffic only'),
+                       (6, 'fp32 -> bf16 conversion -> LDS -> bf16 MFMA (a rounding GEMM loop without the memory stream)')):
         bad = 0
         for r in range(60):
             dH.fill_(float('nan'))

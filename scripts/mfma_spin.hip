@@ -29,6 +29,18 @@ __global__ __launch_bounds__(256) void spin(float* out, int iters, float seed) {
             f32x4 t = {s + i, s - i, s * i, s + 2.f * i};
 #pragma unroll
             for (int e = 0; e < 4; ++e) d0[e] += (float)(__bf16)t[e] + (float)(__bf16)(t[e] * 1.0001f);
+        } else if (KIND == 6) {   // bf16 MFMA fed by fp32 -> bf16 conversions of changing values, through LDS (the shape of a rounding GEMM loop)
+            __shared__ bf16x8 st[256];
+            f32x4 t0 = {s + i, s - i, s * i, s + 2.f * i}, t1 = {s - 3.f * i, s + 5.f * i, s * 0.5f * i, s - 7.f * i};
+            bf16x8 na;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { na[e] = (__bf16)t0[e]; na[4 + e] = (__bf16)t1[e]; }
+            st[threadIdx.x] = na;
+            __syncthreads();
+            const bf16x8 fa = st[(threadIdx.x + 64) & 255], fb = st[(threadIdx.x + 128) & 255];
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, c0, 0, 0, 0); c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb, fa, c1, 0, 0, 0);
+            c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fa, c2, 0, 0, 0); c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb, fb, c3, 0, 0, 0);
+            __syncthreads();
         } else if (KIND == 5) {   // LDS traffic only: ds_write_b128 / ds_read_b128
             __shared__ f32x4 buf[256 * 4];
             buf[threadIdx.x + 256 * (i & 3)] = d0;
@@ -53,6 +65,7 @@ extern "C" int mfma_spin(int kind, int blocks, int iters, float* out, hipStream_
         case 2: hipLaunchKernelGGL((spin<2>), dim3(blocks), dim3(256), 0, stream, out, iters, 0.5f); break;
         case 4: hipLaunchKernelGGL((spin<4>), dim3(blocks), dim3(256), 0, stream, out, iters, 0.5f); break;
         case 5: hipLaunchKernelGGL((spin<5>), dim3(blocks), dim3(256), 0, stream, out, iters, 0.5f); break;
+        case 6: hipLaunchKernelGGL((spin<6>), dim3(blocks), dim3(256), 0, stream, out, iters, 0.5f); break;
         default: hipLaunchKernelGGL((spin<3>), dim3(blocks), dim3(256), 0, stream, out, iters, 0.5f); break;
     }
     return (int)hipGetLastError();
