@@ -1324,7 +1324,11 @@ extern "C" int nu_wgrad_flush(NuOpCtx* c, hipStream_t stream) {
         if (klass[i] == 1 && !tn128_env && (it[i].g.N1 % 256) == 0 && (it[i].g.N2 % 256) == 0) klass[i] = 2;
     if (plan(2, 256, 256) < 192)
         for (int i = 0; i < n; ++i) if (klass[i] == 2) klass[i] = 1;
-    plan(1, 128, 512);
+    // 128 x 128 tiles: FOUR workgroups per CU are resident (126 VGPRs, 36.9 KB of LDS) and this kernel is bound by the issue of its
+    // scalar transposing loads, which more waves hide: a grid of 1024 measured 121.4 TFLOP/s over a step's weight gradients against
+    // 118.0 at 512 (same box, alternating; 512 rays: 7.61 vs 7.74 ms/step)
+    static const int c1_target = getenv("NU_TN_C1_TARGET") ? atoi(getenv("NU_TN_C1_TARGET")) : 1024;     // development switch
+    plan(1, 128, c1_target);
     // ---- launch: singles first, then one launch per class (more when the batch table or the arena cannot take a class at once) ----
     for (int i = 0; i < n; ++i)
         if (klass[i] == 0) { const int rc = wgrad_launch_single(c, it[i], stream); if (rc != NU_OK) return rc; }
