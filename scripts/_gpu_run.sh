@@ -1,6 +1,12 @@
 cd $GRAFT_REPO_ROOT
-timeout -k 10 900 python -m pytest tests -m gpu -q > gpurun_out/suite_fp32.txt 2>&1
-grep -E "^FAILED|passed|failed" gpurun_out/suite_fp32.txt | cut -c1-200
-NU_MLP_DTYPE=bf16x6 timeout -k 10 900 python -m pytest tests -m gpu -q > gpurun_out/suite_x6.txt 2>&1
-grep -E "^FAILED|passed|failed" gpurun_out/suite_x6.txt | cut -c1-200
-true
+python bench.py > gpurun_out/r4_bench_default_final.json 2> gpurun_out/r4_bench_default_final.err
+python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/r4_bench_default_final.json').read().strip().splitlines()[-1])
+r=d['roofline']
+print('headline', round(d['ms_per_step'],2), round(d['value']), 'frac', round(r['frac'],4), 'traffic', r['traffic'], 'launches', r['launches'], 'wgrad', round(r['wgrad']['achieved'],1), r['wgrad']['traffic'])
+for e in d.get('extra_workloads', []):
+    rr=e['roofline']
+    print('   ', e['tag'], round(e['ms_per_step'],2), round(e['rays_per_s']), 'frac', round(rr['frac'],3), 'traffic', rr.get('traffic'))
+print('   cpu', d['cpu_baseline']['value'], d['cpu_baseline'].get('spread_rays_per_s'))
+PY
