@@ -2,6 +2,7 @@
 // wave-private LDS scratch -> row-contiguous 16-byte rows, fused bias / activation / derivative epilogues, ReLU sign-bit words.
 #pragma once
 #include "gemm.h"
+#include <type_traits>
 
 #define TBM 128
 #define TBN 128
@@ -170,51 +171,67 @@ static __device__ __forceinline__ void nt_epilogue(const NuGemmNT& g, const NtEp
                 scr[((r & 3) + 8 * (r >> 2) + 4 * lh) * EPI_LDS + tn * 32 + li] = acc[tt][tn][r];
         if (slab_full) {
             // wave-uniform fast path (every interior tile): straight-line code, no per-lane guards; the auxiliary loads of
-            // four row groups are in flight together; the activation math is branch-free (nu_common.h)
-            constexpr int NB = kNeedH ? NBH : 4;         // row groups in flight
+            // four row groups are in flight together; the activation math is branch-free (nu_common.h).  The two wave-uniform
+            // switches of the slab -- sign-bit words instead of H (UB), columns past act_cols written plain (PL) -- select one of
+            // up to three COPIES of the path, so that no element of it carries a branch or a select for them.
+            auto fast = [&](auto ub_c, auto pl_c) {
+                constexpr bool UB = decltype(ub_c)::value, PL = decltype(pl_c)::value;
+                constexpr int NB = kNeedH ? NBH : 4;         // row groups in flight
 #pragma unroll
-            for (int hb = 0; hb < 8 / NB; ++hb) {
-                f32x4 v4[NB], h4[NB], d4[NB], c4v[NB];
+                for (int hb = 0; hb < 8 / NB; ++hb) {
+                    f32x4 v4[NB], h4[NB], d4[NB], c4v[NB];
 #pragma unroll
-                for (int ii = 0; ii < NB; ++ii) {
-                    const int i = hb * NB + ii;
-                    const long long roff = (long long)(tm * 32 + i * 4);
-                    v4[ii] = *reinterpret_cast<const f32x4*>(&scr[(i * 4 + (lane >> 4)) * EPI_LDS + colq]);
-                    if (kNeedH && !slab_plain && !(kMaskR && mwave)) h4[ii] = nt_ld4<H16>(Hu + roff * g.ldh * ex + oH, x16);
-                    if (kNeedD && !slab_plain) d4[ii] = nt_ld4<H16>(Du + roff * g.ldd * ex + oD, x16);
-                    if (kNeedAdd && !slab_plain) c4v[ii] = nt_ld4<H16>(Au + roff * g.ldadd * ex + oA, x16);
-                }
-#pragma unroll
-                for (int ii = 0; ii < NB; ++ii) {
-                    const int i = hb * NB + ii;
-                    const long long roff = (long long)(tm * 32 + i * 4);
-                    f32x4 o4, o24;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float h = 0.f, o2 = 0.f;
-                        if (kMaskR && mwave) {
-                            const int src = (tm * 8 + i) * 4 + e;           // wave-uniform
-                            const unsigned lo = __builtin_amdgcn_readlane(mlo, src), hi = __builtin_amdgcn_readlane(mhi, src);
-                            h = (((lane < 32 ? lo : hi) >> (lane & 31)) & 1u) ? 1.0f : 0.0f;
-                        } else if (kNeedH && !slab_plain) h = h4[ii][e];
-                        const float v = g.alpha * v4[ii][e];
-                        o4[e] = slab_plain ? v : nu_epi_apply<EPI>(v, bv[e], h, (kNeedD && !slab_plain) ? d4[ii][e] : 0.f,
-                                                                   (kNeedAdd && !slab_plain) ? c4v[ii][e] : 0.f, o2);
-                        o24[e] = o2;
+                    for (int ii = 0; ii < NB; ++ii) {
+                        const int i = hb * NB + ii;
+                        const long long roff = (long long)(tm * 32 + i * 4);
+                        v4[ii] = *reinterpret_cast<const f32x4*>(&scr[(i * 4 + (lane >> 4)) * EPI_LDS + colq]);
+                        if (kNeedH && !PL && !UB) h4[ii] = nt_ld4<H16>(Hu + roff * g.ldh * ex + oH, x16);
+                        if (kNeedD && !PL) d4[ii] = nt_ld4<H16>(Du + roff * g.ldd * ex + oD, x16);
+                        if (kNeedAdd && !PL) c4v[ii] = nt_ld4<H16>(Au + roff * g.ldadd * ex + oA, x16);
                     }
-                    nt_st4<H16>(Cu + roff * g.ldc * ec + oC, o4, c16);
-                    if (kNeedD) nt_st4<H16>(C2u + roff * g.ldc2 * ec + oC2, o24, c16);
-                    if (kMaskW && mwave) {
+#pragma unroll
+                    for (int ii = 0; ii < NB; ++ii) {
+                        const int i = hb * NB + ii;
+                        const long long roff = (long long)(tm * 32 + i * 4);
+                        f32x4 o4, o24;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            const unsigned long long bits = __ballot(o4[e] > 0.f);
-                            const bool mine = lane == (tm * 8 + i) * 4 + e;
-                            wlo = mine ? (unsigned)bits : wlo;
-                            whi = mine ? (unsigned)(bits >> 32) : whi;
+                            float o2 = 0.f;
+                            const float v = g.alpha * v4[ii][e];
+                            if constexpr (PL) {
+                                o4[e] = v;
+                            } else if constexpr (UB) {
+                                // the element's sign bit is bit `lane` of word (tm, i, e): the word, read into an SGPR pair, IS the
+                                // select mask of one v_cndmask (h > 0 ? v : 0 of nu_epi_apply, then + Cadd for B_RELU)
+                                const int src = (tm * 8 + i) * 4 + e;           // wave-uniform
+                                const unsigned long long w = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(mhi, src) << 32) |
+                                                             (unsigned)__builtin_amdgcn_readlane(mlo, src);
+                                float sel;
+                                asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(sel) : "v"(v), "s"(w));
+                                o4[e] = kNeedAdd ? sel + c4v[ii][e] : sel;
+                            } else {
+                                o4[e] = nu_epi_apply<EPI>(v, bv[e], kNeedH ? h4[ii][e] : 0.f, kNeedD ? d4[ii][e] : 0.f,
+                                                          kNeedAdd ? c4v[ii][e] : 0.f, o2);
+                            }
+                            o24[e] = o2;
+                        }
+                        nt_st4<H16>(Cu + roff * g.ldc * ec + oC, o4, c16);
+                        if (kNeedD) nt_st4<H16>(C2u + roff * g.ldc2 * ec + oC2, o24, c16);
+                        if (kMaskW && mwave) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const unsigned long long bits = __ballot(o4[e] > 0.f);
+                                const bool mine = lane == (tm * 8 + i) * 4 + e;
+                                wlo = mine ? (unsigned)bits : wlo;
+                                whi = mine ? (unsigned)(bits >> 32) : whi;
+                            }
                         }
                     }
                 }
-            }
+            };
+            if (kNeedH && slab_plain) fast(std::false_type{}, std::true_type{});
+            else if (kMaskR && mwave) fast(std::true_type{}, std::false_type{});
+            else fast(std::false_type{}, std::false_type{});
         } else if (gcol < zero_to) {
 #pragma unroll 4
             for (int i = 0; i < 8; ++i) {
