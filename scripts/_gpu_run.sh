@@ -1,7 +1,11 @@
 cd $GRAFT_REPO_ROOT
-bash scripts/collect_profiles.sh r04f > gpurun_out/r4f_collect.txt 2>&1
-STEPS=20 WARMUP=5 bash scripts/collect_profiles.sh r04f_s20 >> gpurun_out/r4f_collect.txt 2>&1
-STEPS=10 WARMUP=4 bash scripts/collect_profiles.sh r04f_c4 --real-capture --rays 8192 --mlp-dtype bf16 >> gpurun_out/r4f_collect.txt 2>&1
-STEPS=12 WARMUP=4 bash scripts/collect_profiles.sh r04f_x6 --mlp-dtype bf16x6 >> gpurun_out/r4f_collect.txt 2>&1
-STEPS=30 WARMUP=6 bash scripts/collect_profiles.sh r04f_512 --rays 512 >> gpurun_out/r4f_collect.txt 2>&1
-tail -40 gpurun_out/r4f_collect.txt
+python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r4_bench_driver_style.json 2> gpurun_out/r4_bench_driver_style.err
+python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/r4_bench_driver_style.json').read().strip().splitlines()[-1])
+r=d['roofline']
+print('headline', round(d['ms_per_step'],2), round(d['value']), 'frac', round(r['frac'],4), 'traffic', r['traffic'], 'src', r.get('traffic_source'), 'wgrad', round(r['wgrad']['achieved'],1))
+for e in d.get('extra_workloads', []):
+    rr=e['roofline']
+    print('   ', e['tag'], round(e['ms_per_step'],2), round(e['rays_per_s']), 'frac', round(rr['frac'],3), 'traffic', rr.get('traffic'))
+PY
