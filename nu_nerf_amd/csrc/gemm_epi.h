@@ -174,8 +174,11 @@ static __device__ __forceinline__ void nt_epilogue(const NuGemmNT& g, const NtEp
             // four row groups are in flight together; the activation math is branch-free (nu_common.h).  The two wave-uniform
             // switches of the slab -- sign-bit words instead of H (UB), columns past act_cols written plain (PL) -- select one of
             // up to three COPIES of the path, so that no element of it carries a branch or a select for them.
-            auto fast = [&](auto ub_c, auto pl_c) {
+            auto fast = [&](auto ub_c, auto pl_c, auto c16_c, auto x16_c) {
                 constexpr bool UB = decltype(ub_c)::value, PL = decltype(pl_c)::value;
+                // (bf16-storage kernel: the storage widths of this launch's matrices, compile-time in the copy)
+                constexpr bool c16 = decltype(c16_c)::value, x16 = decltype(x16_c)::value;
+                constexpr int ec = c16 ? 2 : 4, ex = x16 ? 2 : 4;
                 constexpr int NB = kNeedH ? NBH : 4;         // row groups in flight
 #pragma unroll
                 for (int hb = 0; hb < 8 / NB; ++hb) {
@@ -229,9 +232,25 @@ static __device__ __forceinline__ void nt_epilogue(const NuGemmNT& g, const NtEp
                     }
                 }
             };
-            if (kNeedH && slab_plain) fast(std::false_type{}, std::true_type{});
-            else if (kMaskR && mwave) fast(std::true_type{}, std::false_type{});
-            else fast(std::false_type{}, std::false_type{});
+            // ... and, in the bf16-storage kernel, the launch's two storage flags (C / C2; H / D / Cadd): a copy per setting, so that
+            // no load or store of the path carries the width switch
+            auto fast_w = [&](auto ub_c, auto pl_c) {
+                constexpr bool kAux = kNeedH || kNeedD || kNeedAdd;
+                if constexpr (H16) {
+                    if (c16) {
+                        if (kAux && x16) fast(ub_c, pl_c, std::true_type{}, std::true_type{});
+                        else fast(ub_c, pl_c, std::true_type{}, std::false_type{});
+                    } else {
+                        if (kAux && x16) fast(ub_c, pl_c, std::false_type{}, std::true_type{});
+                        else fast(ub_c, pl_c, std::false_type{}, std::false_type{});
+                    }
+                } else {
+                    fast(ub_c, pl_c, std::false_type{}, std::false_type{});
+                }
+            };
+            if (kNeedH && slab_plain) fast_w(std::false_type{}, std::true_type{});
+            else if (kMaskR && mwave) fast_w(std::true_type{}, std::false_type{});
+            else fast_w(std::false_type{}, std::false_type{});
         } else if (gcol < zero_to) {
 #pragma unroll 4
             for (int i = 0; i < 8; ++i) {
