@@ -203,7 +203,7 @@ static __device__ __forceinline__ void nt_epilogue(const NuGemmNT& g, const NtEp
                             const float v = g.alpha * v4[ii][e];
                             if constexpr (PL) {
                                 o4[e] = v;
-                            } else if constexpr (UB) {
+                            } else if constexpr (kMaskR && UB) {
                                 // the element's sign bit is bit `lane` of word (tm, i, e): the word, read into an SGPR pair, IS the
                                 // select mask of one v_cndmask (h > 0 ? v : 0 of nu_epi_apply, then + Cadd for B_RELU)
                                 const int src = (tm * 8 + i) * 4 + e;           // wave-uniform
@@ -220,7 +220,7 @@ static __device__ __forceinline__ void nt_epilogue(const NuGemmNT& g, const NtEp
                         }
                         nt_st4<H16>(Cu + roff * g.ldc * ec + oC, o4, c16);
                         if (kNeedD) nt_st4<H16>(C2u + roff * g.ldc2 * ec + oC2, o24, c16);
-                        if (kMaskW && mwave) {
+                        if constexpr (kMaskW && UB) {          // (UB of a writer: the slab has sign-bit words)
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
                                 const unsigned long long bits = __ballot(o4[e] > 0.f);
@@ -249,7 +249,7 @@ static __device__ __forceinline__ void nt_epilogue(const NuGemmNT& g, const NtEp
                 }
             };
             if (kNeedH && slab_plain) fast_w(std::false_type{}, std::true_type{});
-            else if (kMaskR && mwave) fast_w(std::true_type{}, std::false_type{});
+            else if ((kMaskR || kMaskW) && mwave) fast_w(std::true_type{}, std::false_type{});
             else fast_w(std::false_type{}, std::false_type{});
         } else if (gcol < zero_to) {
 #pragma unroll 4
