@@ -194,6 +194,53 @@ def test_relu_sign_bits_replace_the_activation_in_the_backward_epilogues(gpu):
     torch.testing.assert_close(out3.double(), want, rtol=2e-5, atol=2e-5)
 
 
+@pytest.mark.parametrize("M", [66048, 65990])
+def test_epilogue_fast_path_copies_on_128_row_tiles(gpu, M):
+    """The interior slabs of a launch run one of up to three copies of the epilogue's fast path (gemm_epi.h): sign-bit words
+    (writer and reader), plain columns past act_cols, auxiliary rows -- here all three in launches big enough for the 128-row tiles
+    (>= 512 tiles), with a ragged last row tile in the second case (the slow path next to them).  H is poisoned wherever the sign
+    bits must replace it."""
+    from nu_nerf_amd import _lib as L
+    from nu_nerf_amd.engine import GemmNT, addr
+    lib = L.load()
+    torch.manual_seed(11)
+    K = 64
+    A = torch.randn(M, K, device=gpu)
+    W = torch.randn(256, K, device=gpu) / K ** 0.5
+    bias = torch.randn(256, device=gpu) * 0.3
+    Hout = torch.full((M, 256), float("nan"), device=gpu)
+    mask = torch.zeros(((M + 127) // 128) * 2 * 256, dtype=torch.int64, device=gpu)
+    g = GemmNT(addr(A), K, addr(_packB(W, K)), K, M, 256, K, addr(Hout), 256, 0, 0, addr(bias), 0, 0, 0, 0, 0, 0, 0, 0, 1.0, 1,
+               0, 0, 0, 0, 0, 0, 0, 0, 1, 0, mask.data_ptr(), 2, 0)
+    L.check(lib.nu_gemm_nt_ex(ctypes.byref(g), L.stream()), "writer")
+    ref_h = torch.relu(A.double() @ W.double().t() + bias.double())
+    torch.testing.assert_close(Hout.double(), ref_h, rtol=2e-5, atol=2e-5)
+    pos = Hout > 0
+    # reader (sign bits, H poisoned) + plain columns past act_cols in ONE launch: N = 384, the third column tile is plain
+    dA = torch.randn(M, 256, device=gpu)
+    W3 = torch.randn(384, 256, device=gpu) / 16
+    poison = torch.full((M, 256), float("nan"), device=gpu)
+    out = torch.full((M, 384), float("nan"), device=gpu)
+    g = GemmNT(addr(dA), 256, addr(W3), 256, M, 384, 256, addr(out), 384, 0, 0, 0, addr(poison), 256, 0, 0, 0, 0, 384, 256, 1.0, 1,
+               0, 0, 0, 0, 0, 0, 0, 0, 3, 0, mask.data_ptr(), 2, 0)
+    L.check(lib.nu_gemm_nt_ex(ctypes.byref(g), L.stream()), "reader + plain")
+    v = dA.double() @ W3.double().t()
+    torch.testing.assert_close(out.double(), torch.cat([v[:, :256] * pos, v[:, 256:]], 1), rtol=2e-5, atol=2e-5)
+    # the same reader WITHOUT sign-bit words: the auxiliary-row copy reads H itself; both give the same bits
+    out_h = torch.full((M, 384), float("nan"), device=gpu)
+    g = GemmNT(addr(dA), 256, addr(W3), 256, M, 384, 256, addr(out_h), 384, 0, 0, 0, addr(Hout), 256, 0, 0, 0, 0, 384, 256, 1.0, 1,
+               0, 0, 0, 0, 0, 0, 0, 0, 3, 0, 0, 0, 0)
+    L.check(lib.nu_gemm_nt_ex(ctypes.byref(g), L.stream()), "reader from H")
+    assert torch.equal(out_h, out)
+    # B_RELU on the sign bits with Cadd
+    Cadd = torch.randn(M, 256, device=gpu)
+    out2 = torch.full((M, 256), float("nan"), device=gpu)
+    g = GemmNT(addr(dA), 256, addr(W3), 256, M, 256, 256, addr(out2), 256, 0, 0, 0, addr(poison), 256, 0, 0, addr(Cadd), 256, 0, 0, 1.0, 1,
+               0, 0, 0, 0, 0, 0, 0, 0, 8, 0, mask.data_ptr(), 2, 0)
+    L.check(lib.nu_gemm_nt_ex(ctypes.byref(g), L.stream()), "b_relu")
+    torch.testing.assert_close(out2.double(), v[:, :256] * pos + Cadd.double(), rtol=2e-5, atol=2e-5)
+
+
 def _gemm_struct(A, lda, B, ldb, M, N, K, C, ldc, epi, *, bias=None, H=None, ldh=0, mask=None, nct=0, ct0=0, groups=1, sA=0, sB=0, sC=0,
                  sBias=0, sH=0, zero_to=0, act_cols=0):
     from nu_nerf_amd.engine import GemmNT, addr
