@@ -209,8 +209,10 @@ static __device__ __forceinline__ void nt_epilogue(const NuGemmNT& g, const NtEp
                                 const int src = (tm * 8 + i) * 4 + e;           // wave-uniform
                                 const unsigned long long w = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(mhi, src) << 32) |
                                                              (unsigned)__builtin_amdgcn_readlane(mlo, src);
+                                // (gfx940 family: a VALU read of an SGPR needs two wait states behind the VALU -- here v_readlane -- that
+                                // wrote it; the compiler keeps that distance for its own instructions but cannot see into this one)
                                 float sel;
-                                asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(sel) : "v"(v), "s"(w));
+                                asm("s_nop 1\n\tv_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(sel) : "v"(v), "s"(w));
                                 o4[e] = kNeedAdd ? sel + c4v[ii][e] : sel;
                             } else {
                                 o4[e] = nu_epi_apply<EPI>(v, bv[e], kNeedH ? h4[ii][e] : 0.f, kNeedD ? d4[ii][e] : 0.f,
