@@ -1,9 +1,16 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_gemm_gpu.py tests/test_nets_gpu.py tests/test_bf16_gpu.py tests/test_stage1_gpu.py -x -q -m gpu 2>&1 | grep -E "FAILED|Error|passed|failed" | head
-cat > /tmp/_p.py <<'PY'
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']
-print(sys.argv[1], round(d['ms_per_step'],2), 'ms  NT', round(r['achieved'],1), r['unit'], 'frac', round(r['frac'],3), ' wgrad', round(r['wgrad']['achieved'],1))
+python -m pytest tests -q -m gpu 2>&1 | tail -1 > gpurun_out/r4_final_tests3.txt
+NU_MLP_DTYPE=bf16x6 python -m pytest tests -q -m gpu 2>&1 | tail -1 >> gpurun_out/r4_final_tests3.txt
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 >> gpurun_out/r4_final_tests3.txt
+cat gpurun_out/r4_final_tests3.txt
+python bench.py > gpurun_out/r4_bench_default_final3.json 2> gpurun_out/r4_bench_default_final3.err
+python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/r4_bench_default_final3.json').read().strip().splitlines()[-1])
+r=d['roofline']
+print('headline', round(d['ms_per_step'],2), round(d['value']), 'frac', round(r['frac'],4), 'traffic', r['traffic'], 'launches', r['launches'], 'wgrad', round(r['wgrad']['achieved'],1))
+for e in d.get('extra_workloads', []):
+    rr=e['roofline']
+    print('   ', e['tag'], round(e['ms_per_step'],2), round(e['rays_per_s']), 'frac', round(rr['frac'],3), 'traffic', rr.get('traffic'))
+print('   cpu', d['cpu_baseline']['value'], d['cpu_baseline'].get('spread_rays_per_s'))
 PY
-run() { python bench.py --steps 20 --warmup 6 --no-extra --no-cpu-baseline $@ 2>/dev/null | python /tmp/_p.py "$*"; }
-run; run --real-capture --rays 8192 --mlp-dtype bf16; run; run --real-capture --rays 8192 --mlp-dtype bf16
