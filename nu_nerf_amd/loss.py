@@ -273,7 +273,7 @@ def fused_stage1_loss(renderer, batch, step, losses, rand=None, reducer=None):
     normalisers of the first 1000 steps)."""
     from .parallel import dp_weight_outputs
     pw = None
-    dp = reducer is not None and reducer.world > 1
+    dp = reducer is not None and not getattr(reducer, 'solo', reducer.world <= 1)
     real_cand = getattr(renderer, 'candidate_rays', False)
     if renderer.cfg['rgb_loss'] != 'charbonier' or not any(isinstance(ls, NeRFRenderLoss) for ls in losses) or (dp and real_cand):
         # (the candidate-ray regulariser of the real-capture renderer takes its weight on the eager outputs)

@@ -28,9 +28,12 @@ def stage1_trainable_names(module):
 
 
 class GradAllReducer:
-    def __init__(self, module, world_size, group=None):
+    def __init__(self, module, world_size, group=None, always_collective=False):
         self.world = world_size
         self.group = group
+        # always_collective: issue the collectives on a ONE-rank group too (every weight is exactly 1, the mean divides by 1: the step's
+        # bits do not change) -- the RCCL rehearsal a one-GPU box allows (tests/test_rccl_single_rank_gpu.py)
+        self.solo = world_size <= 1 and not always_collective
         named = dict(module.named_parameters())
         self.params = [named[n] for n in stage1_trainable_names(module)]
         self.numel = sum(p.numel() for p in self.params)
@@ -71,7 +74,7 @@ class GradAllReducer:
         """Sum the gradients over ranks and divide by the world size (in place on every .grad): one collective.
         Parameters whose .grad is None are left alone (no zero gradient is materialised for them): which parameters have a
         gradient is decided by the step index and the loss set, identically on every rank."""
-        if self.world <= 1:
+        if self.solo:
             return
         flat = self._shared_flat()
         if flat is not None:
@@ -107,7 +110,7 @@ class GradAllReducer:
         ONE small all-reduce; a subset that is empty on every rank gets weight 1."""
         n = torch.stack([c.reshape(-1)[0].to(device=device, dtype=torch.float32) if torch.is_tensor(c)
                          else torch.tensor(float(c), device=device) for c in counts])
-        if self.world <= 1:
+        if self.solo:
             return torch.ones_like(n)
         tot = n.clone()
         dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=self.group)
@@ -121,7 +124,7 @@ class GradAllReducer:
             n = n_local.reshape(-1)[:1].to(device=device, dtype=torch.float32)
         else:
             n = torch.tensor([float(n_local)], device=device)
-        if self.world <= 1:
+        if self.solo:
             return torch.ones(1, device=device)
         tot = n.clone()
         dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=self.group)

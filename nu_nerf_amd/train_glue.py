@@ -191,7 +191,7 @@ def train_step(network, optimizer, lr_manager, losses, step, batch=None, reducer
         optimizer.step()
         return total.detach(), log_info, lr
     outputs = network({'step': step}) if batch is None else network.train_step_rays(batch, step)
-    if reducer is not None and reducer.world > 1 and type(network).__name__ == 'NeROShapeRenderer':
+    if reducer is not None and not getattr(reducer, 'solo', reducer.world <= 1) and type(network).__name__ == 'NeROShapeRenderer':
         # means over data-dependent subsets (eikonal, material regularisers, occlusion loss, candidate rays) become this rank's share
         # of the mean over the union of all ranks' subsets: the all-reduced gradient is the single-process gradient on the global
         # batch (parallel.dp_weight_outputs, which also states the two approximations that remain)
