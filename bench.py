@@ -345,7 +345,10 @@ def stage1_leg(args, dist_ctx):
     losses = [name2loss[n](cfg) for n in SPHEREPOT_LOSSES]
     # Adam: the HIP multi-tensor kernel (nu_nerf_amd/train_glue.py; checked against torch.optim.Adam in tests/test_train_glue_gpu.py)
     opt = FusedAdam(net.parameters(), lr=1e-3) if os.environ.get('NU_BENCH_ADAM', 'hip') == 'hip' else torch.optim.Adam(net.parameters(), lr=1e-3, fused=True)
-    reducer = GradAllReducer(net, world) if world > 1 else None
+    # NU_BENCH_ONE_RANK_GROUP=1 (a one-rank launch under torch.distributed.run): the rehearsal a one-GPU box allows of the N > 1 step on the
+    # real transport -- the reducer issues its collectives on the one-rank RCCL group (weights exactly 1, mean over 1: same bits)
+    one_rank_group = world == 1 and coll_backend is not None
+    reducer = GradAllReducer(net, world, always_collective=one_rank_group) if (world > 1 or one_rank_group) else None
 
     # device-resident ray pool; every rank draws a disjoint slice of the same seeded permutation
     n_iter = args.steps + args.warmup
@@ -390,7 +393,7 @@ def stage1_leg(args, dist_ctx):
     for it in range(args.warmup):
         one_step(it)
     torch.cuda.synchronize()
-    if world > 1:
+    if coll_backend is not None:
         dist.barrier()
     torch.cuda.synchronize()
     stats['P_in'] = stats['P_out'] = 0
@@ -418,12 +421,12 @@ def stage1_leg(args, dist_ctx):
         seg_count.append(torch.cuda.memory_stats(dev).get('segment.all.allocated', 0))
     eng._TWO_STREAM_SAMPLES = two_stream_default
     torch.cuda.synchronize()
-    if world > 1:
+    if coll_backend is not None:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     gc.enable()
-    if world > 1:
+    if coll_backend is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -453,6 +456,7 @@ def stage1_leg(args, dist_ctx):
         "config": {"workload": workload,
                    "rays_per_gpu": R, "global_rays": R * world, "samples_per_ray": 160, "start_step": args.start_step,
                    "parallelism": "dp%d" % world, "rccl_ranks": rccl_ranks, "collective_backend": coll_backend,
+                   "rehearsal": "one rank, collectives issued on the one-rank group (NU_BENCH_ONE_RANK_GROUP=1): not a multi-GPU number" if one_rank_group else None,
                    "rays": "object-aimed (make_object_rays)" if args.object_rays else "Spherepot-shaped camera frusta",
                    "loss_assembly": "eager torch registry (--unfused-loss)" if args.unfused_loss else
                    "HIP loss kernels (fused_stage1_loss%s)" % ("; eikonal point weight as a device scalar" if reducer is not None else ""),
@@ -600,16 +604,17 @@ def main():
     dev_index = int(os.environ.get('NU_BENCH_DEVICE', local_rank))
     torch.cuda.set_device(dev_index)
     dev = torch.device('cuda', dev_index)
-    if world > 1:
+    grouped = world > 1 or (os.environ.get('NU_BENCH_ONE_RANK_GROUP') == '1' and 'WORLD_SIZE' in os.environ)
+    if grouped:
         backend = os.environ.get('NU_BENCH_BACKEND', 'nccl')
         if backend == 'nccl':
             dist.init_process_group('nccl', device_id=dev)
         else:
             dist.init_process_group(backend)
-    rccl_ranks = dist.get_world_size() if world > 1 else 1
+    rccl_ranks = dist.get_world_size() if grouped else 1
     if rccl_ranks != args.gpus:
         raise SystemExit(f"bench.py: process group has {rccl_ranks} rank(s), --gpus {args.gpus}")
-    coll_backend = dist.get_backend() if world > 1 else None
+    coll_backend = dist.get_backend() if grouped else None
     dist_ctx = (rank, world, dev, rccl_ranks, coll_backend)
 
     res = stage1_leg(args, dist_ctx)
@@ -617,12 +622,12 @@ def main():
         pool = res.pop('_pool')
         headline = (args.rays == 4096 and args.mlp_dtype == 'fp32' and not args.real_capture and not args.object_rays
                     and not args.unfused_loss)
-        if world == 1 and headline and not args.no_extra:
+        if world == 1 and not grouped and headline and not args.no_extra:
             res["extra_workloads"] = run_extra_legs(args, dist_ctx)
         if world == 1 and not args.no_cpu_baseline and not args.real_capture and args.mlp_dtype == 'fp32':
             res["cpu_baseline"] = cpu_baseline(pool, args.start_step)
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
 
