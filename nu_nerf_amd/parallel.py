@@ -108,8 +108,10 @@ class GradAllReducer:
     def count_weights(self, counts, device):
         """[k] device tensor of n_local_i * world / sum_r n_{r,i} for k subset sizes (python numbers or device-resident counts) in
         ONE small all-reduce; a subset that is empty on every rank gets weight 1."""
-        n = torch.stack([c.reshape(-1)[0].to(device=device, dtype=torch.float32) if torch.is_tensor(c)
-                         else torch.tensor(float(c), device=device) for c in counts])
+        # (python numbers become device scalars through a fill launch, not a host -> device copy: a pageable copy makes the host wait
+        # for the stream, and between the forward and the loss that wait is a gap of the whole enqueue lead -- about 1 ms per step)
+        n = torch.cat([c.reshape(-1)[:1].to(device=device, dtype=torch.float32) if torch.is_tensor(c)
+                       else torch.full((1,), float(c), dtype=torch.float32, device=device) for c in counts])
         if self.solo:
             return torch.ones_like(n)
         tot = n.clone()
@@ -123,7 +125,7 @@ class GradAllReducer:
         if torch.is_tensor(n_local):       # a device-resident count (engine ctx['P_in_dev']): no host -> device copy at all
             n = n_local.reshape(-1)[:1].to(device=device, dtype=torch.float32)
         else:
-            n = torch.tensor([float(n_local)], device=device)
+            n = torch.full((1,), float(n_local), dtype=torch.float32, device=device)
         if self.solo:
             return torch.ones(1, device=device)
         tot = n.clone()
