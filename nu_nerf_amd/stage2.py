@@ -234,7 +234,9 @@ class Stage2Renderer(nn.Module):
         sdf = eng.sdf_forward(addr(pts), 3, M * 64, keep=False, want_feat=False)['sdf']
         z = zn[None, :].expand(M, 64).contiguous()
         o, d = start.contiguous(), dirs.contiguous()
-        uv = torch.linspace(0.5 / 32, 1.0 - 0.5 / 32, steps=32).to(dev)
+        uv = getattr(self, '_uv32', None)         # CPU-computed once, then resident: a pageable host -> device copy per call makes the host
+        if uv is None or uv.device != dev:        # wait for the stream to drain (same bits as the per-call copy it replaces)
+            uv = self._uv32 = torch.linspace(0.5 / 32, 1.0 - 0.5 / 32, steps=32).to(dev)
         var = self.deviation_network_inner.variance
         sn = 64
         for it in range(2):
