@@ -19,6 +19,9 @@ A step = ray fetch (device-resident pool) -> sampler -> render_core forward -> l
                  of MI355X_MICROARCH.md.
   cpu_baseline : the CPU oracle (oracle/stage1_oracle.py, a port of the reference's PyTorch path) timed on this
                  box's host cores on a bounded sample of the same workload (rank 0, N=1 only).
+Rehearsal switches for a one-GPU box (never a multi-GPU number; the line says so in config.rehearsal / collective_backend):
+  NU_BENCH_ONE_RANK_GROUP=1 under `torch.distributed.run --nproc-per-node 1`: the N > 1 step's collectives on a one-rank RCCL group;
+  NU_BENCH_DEVICE=0 NU_BENCH_BACKEND=gloo with --nproc-per-node 2: two ranks time-sharing one card.
 """
 import argparse
 import gc
