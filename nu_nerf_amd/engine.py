@@ -266,6 +266,7 @@ class Stage1Engine:
     # below `_TWO_STREAM_SAMPLES` ray samples the NeRF++ chain runs on a second HIP stream.  Both chains push their split reductions
     # to the shared arena from this (single) host thread; the batched reduction runs after the join.
     _TWO_STREAM_SAMPLES = int(os.environ.get('NU_TWO_STREAM_SAMPLES', 200000))
+    occ_sdf_thresh = None      # set by the renderer for a training step past occ_loss_step: render_forward leaves ctx['occ_idx']
     _FUSED_SDF_MAX_POINTS = int(os.environ.get('NU_FUSED_SDF_MAX_POINTS', 40000))
 
     def _fork(self, mark=True):
@@ -1448,6 +1449,13 @@ class Stage1Engine:
         if P_in > 0:
             a = self.sdf_forward(addr(pt_in), 8, P_in, keep=True)
             self.sdf_normal(a)
+            if self.occ_sdf_thresh is not None:
+                # the occlusion loss's point list (renderer_zerothick.py:699-707) needs only x, the view direction, the SDF and its
+                # normal: its nonzero() -- a host wait -- is taken HERE, with the NeRF++ chain already queued and the shading stack
+                # about to be, instead of after the forward, where the GPU then sat waiting for the loss and backward launches
+                x_, dirs_ = pt_in[:P_in, :3], pt_in[:P_in, 4:7]
+                m_ = (torch.norm(x_, dim=-1) < 0.999) & (torch.sum(a['n'] * dirs_, -1) < 0) & (torch.abs(a['YX'][:, 0]) < self.occ_sdf_thresh)
+                ctx['occ_idx'] = torch.nonzero(m_)[:, 0]
             gerr = e(P_in)
             var = self.p['deviation_network.variance']
             L.check(lib.nu_neus_alpha_fwd(c_p(addr(a['YX'])), 288, c_p(addr(a['n'])), c_p(addr(pt_in)), c_p(addr(idx_in)),

@@ -8,6 +8,7 @@ called from train/trainer_zero.py:58,152): same constructor signature `(cfg, tra
 default-tensor-type flips) so one process per GPU works.
 """
 import math
+import os
 
 import weakref
 
@@ -498,8 +499,13 @@ class NeROShapeRenderer(nn.Module):
         cfg = self.cfg
         frozen = cfg['freeze_inv_s_step'] is not None and step < cfg['freeze_inv_s_step']
         spec_pts, cand = self._spec_query_points(rays_o, rays_d, z_vals)
-        rgb, acc, rgb_bg, gerr, spec_raw, occ_raw, sdf_in, nrm_sum, trans, metal = _RenderCoreFn.apply(
-            eng, rays_o, rays_d, z_vals, float(cos_anneal_ratio), not frozen, self._grad_names, spec_pts, *self._grad_params)
+        early = cfg['apply_occ_loss'] and step >= cfg['occ_loss_step'] and os.environ.get('NU_OCC_IDX_EARLY', '1') == '1'
+        eng.occ_sdf_thresh = float(cfg['occ_sdf_thresh']) if early else None
+        try:
+            rgb, acc, rgb_bg, gerr, spec_raw, occ_raw, sdf_in, nrm_sum, trans, metal = _RenderCoreFn.apply(
+                eng, rays_o, rays_d, z_vals, float(cos_anneal_ratio), not frozen, self._grad_names, spec_pts, *self._grad_params)
+        finally:
+            eng.occ_sdf_thresh = None
         exp_max = eng.exp_max
         if fused and is_train:
             # loss.fused_stage1_loss finishes the step in the HIP loss kernels: white background, clamp, colour_spec activation
@@ -583,8 +589,10 @@ class NeROShapeRenderer(nn.Module):
             x, dirs = pt[:, :3], pt[:, 4:7]
             a, SD = c['sdf'], c['shade']['SD']
             sdf, n = a['YX'][:, 0], a['n']
-            mask = (torch.norm(x, dim=-1) < 0.999) & (torch.sum(n * dirs, -1) < 0) & (torch.abs(sdf) < cfg['occ_sdf_thresh'])
-            idx = torch.nonzero(mask)[:, 0]
+            idx = c.get('occ_idx')            # taken inside the forward when the renderer announced the loss (engine.occ_sdf_thresh)
+            if idx is None:
+                mask = (torch.norm(x, dim=-1) < 0.999) & (torch.sum(n * dirs, -1) < 0) & (torch.abs(sdf) < cfg['occ_sdf_thresh'])
+                idx = torch.nonzero(mask)[:, 0]
             self._n_occ = min(int(idx.numel()), int(cfg['occ_loss_max_pn']))   # points in the mean below (data parallelism: parallel.dp_weight_outputs)
             if idx.numel() > cfg['occ_loss_max_pn']:
                 if perm is None:
